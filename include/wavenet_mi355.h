@@ -1,0 +1,170 @@
+/*
+ * wavenet_mi355.h -- C ABI of libwavenet_mi355.so: the MI355X (gfx950) native WaveNet-vocoder
+ * training / Fast-WaveNet synthesis hot path.
+ *
+ * The reference (Rayhane-mamah/Tacotron-2) has NO native / FFI boundary: its hot path is a chain of
+ * TensorFlow-1 graph ops built by the Python class wavenet_vocoder/models/wavenet.py:WaveNet and run
+ * with session.run (wavenet_vocoder/train.py:303, synthesizer.py:97).  This header is therefore the
+ * boundary the reference *would* bind if it had one; each entry point names the reference code whose
+ * arithmetic it replaces.  The Python mirror of the reference's class API that calls these functions
+ * through ctypes lives in tacotron-2_amd/wavenet_vocoder/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = WN_OK, negative = error; wn_last_error() gives text.
+ *     No C++ exception crosses this boundary.
+ *   - all data pointers are DEVICE pointers (HBM) owned by the caller and borrowed for the call only,
+ *     unless the parameter is documented "host".  Tensors are contiguous in the stated layout.
+ *   - all work is enqueued asynchronously on the caller's stream (`void* stream` is a hipStream_t);
+ *     no hidden device synchronisation.  One wn_ctx per (process, device); not thread-safe.
+ *   - parameters, gradients and optimiser slots are single flat fp32 buffers; the tensors inside them
+ *     keep the reference's TensorFlow layouts ([k,in,out] conv kernels ...) at the offsets reported by
+ *     wn_tensor_info(), under names mirroring the reference's variable scopes.
+ */
+#ifndef WAVENET_MI355_H
+#define WAVENET_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_ABI_VERSION 1
+
+enum wn_status {
+    WN_OK = 0,
+    WN_E_ARG = -1,          /* bad argument / null pointer            */
+    WN_E_SHAPE = -2,        /* shape constraint violated              */
+    WN_E_HIP = -3,          /* HIP runtime error (see wn_last_error)  */
+    WN_E_UNSUPPORTED = -4,  /* valid reference config not built yet   */
+    WN_E_STATE = -5         /* call order violated (e.g. bwd before fwd) */
+};
+
+enum wn_input_type { WN_INPUT_RAW = 0, WN_INPUT_MULAW = 1, WN_INPUT_MULAW_QUANTIZE = 2 }; /* hparams.py:187 */
+enum wn_upsample_type {                                                                    /* hparams.py:219 */
+    WN_UP_NEAREST = 0, WN_UP_2D = 1, WN_UP_SUBPIXEL = 2, WN_UP_1D = 3, WN_UP_RESIZE = 4
+};
+enum wn_activation { WN_ACT_NONE = 0, WN_ACT_RELU = 1, WN_ACT_LEAKY_RELU = 2 };             /* hparams.py:220 */
+enum wn_lr_schedule { WN_LR_EXPONENTIAL = 0, WN_LR_NOAM = 1 };                              /* hparams.py:309 */
+
+#define WN_MAX_UPSAMPLE 8
+
+/* Model + optimiser hyper-parameters: the hparams.py keys read by wavenet.py:89-208 / :522-629. */
+typedef struct wn_config {
+    int32_t abi_version;            /* = WN_ABI_VERSION */
+    /* architecture (hparams.py:187-211) */
+    int32_t layers, stacks;
+    int32_t residual_channels, gate_channels, skip_out_channels, out_channels;
+    int32_t kernel_size;            /* must be 3 */
+    int32_t cin_channels;           /* == num_mels, multiple of 16 */
+    int32_t input_type;             /* wn_input_type */
+    int32_t quantize_channels;
+    int32_t use_bias;
+    int32_t legacy, residual_legacy;
+    float   log_scale_min, log_scale_min_gauss;
+    int32_t cdf_loss;
+    /* upsample net (hparams.py:219-225) */
+    int32_t upsample_type;          /* wn_upsample_type */
+    int32_t upsample_activation;    /* wn_activation */
+    int32_t n_upsample;
+    int32_t upsample_scales[WN_MAX_UPSAMPLE];
+    int32_t freq_axis_kernel_size;
+    float   leaky_alpha;
+    /* training (hparams.py:309-327) */
+    float   dropout;                /* wavenet_dropout */
+    int32_t clip_gradients;
+    float   gradient_max_norm, gradient_max_value;
+    float   adam_beta1, adam_beta2, adam_epsilon, ema_decay;
+    /* capacity: workspace is sized once for these (288 GB HBM: be generous) */
+    int32_t max_batch;              /* utterances per call                       */
+    int32_t max_time;               /* samples per utterance (train or synth)    */
+} wn_config;
+
+typedef struct wn_ctx wn_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int  wn_create(const wn_config* cfg, wn_ctx** out);     /* validates cfg (wavenet.py:94,97; models/__init__.py:6-9) */
+void wn_destroy(wn_ctx* ctx);
+const char* wn_last_error(const wn_ctx* ctx);           /* ctx may be NULL: error of the last failed wn_create */
+int  wn_receptive_field(const wn_ctx* ctx);             /* wavenet.py:54-71 */
+
+/* ---- parameter table (host-side; replaces tf.trainable_variables(), wavenet.py:467) ---------- */
+int64_t wn_param_count(const wn_ctx* ctx);              /* floats in the flat parameter buffer (incl. alignment pad) */
+int     wn_num_tensors(const wn_ctx* ctx);
+/* name: >=128 chars; shape: >=4 ints (TF layout) */
+int     wn_tensor_info(const wn_ctx* ctx, int index, char* name, int32_t* shape, int32_t* ndim, int64_t* offset);
+
+/* Re-pack the flat fp32 parameters into the bf16 MFMA-fragment-ordered copies the kernels read
+ * (ctx-owned).  Call after every change of the parameters (i.e. after wn_optim_step). */
+int wn_pack_weights(wn_ctx* ctx, const float* params, void* stream);
+
+/* ---- training: replaces WaveNet.step + add_loss (wavenet.py:650-721, 476-495) ----------------- */
+/* x        scalar input: float [B,1,T]; mulaw-quantize: int32 class ids [B,T] (== the reference's one-hot
+ *          [B,256,T], feeder.py:295-306, without materialising it)
+ * c        float [B, cin, Tc], Tc*hop == T   (local conditioning, feeder.py:319-340)
+ * y        targets: float [B,T,1] (scalar) or int32 [B,T] (mulaw-quantize)   (wavenet.py:488-495)
+ * lengths  int32 [B]
+ * dropout_seed  counter-based mask key for this step (tf.layers.dropout, modules.py:484); the same
+ *          mask is regenerated in wn_train_bwd.  Dropout is disabled when cfg.dropout == 0.
+ * loss_out float [1] device: masked mean loss of this batch (modules.py:798/817/836)
+ * y_hat_out optional float [B, out_channels, T] (NULL to skip)                                    */
+int wn_train_fwd(wn_ctx* ctx, const void* x, const float* c, const void* y, const int32_t* lengths,
+                 int32_t B, int32_t T, int32_t Tc, uint64_t dropout_seed,
+                 float* loss_out, float* y_hat_out, void* stream);
+
+/* Backward of the last wn_train_fwd: writes d(loss)/d(param) for every tensor into the flat fp32
+ * buffer `grads` (same layout as params; overwritten, not accumulated).
+ * Replaces optimizer.compute_gradients (wavenet.py:557). */
+int wn_train_bwd(wn_ctx* ctx, float* grads, void* stream);
+
+/* Optional access to activations of the last forward (wavenet.py:702 upsampled_local_features):
+ * float [B, cin, T]. */
+int wn_get_upsampled_features(wn_ctx* ctx, float* out, void* stream);
+
+/* Per-tensor clip_by_norm -> clip_by_value -> TF-Adam -> EMA, in place (wavenet.py:586-613).
+ * `step` is the 0-based global step before this update; lr is the already-scheduled rate. */
+int wn_optim_step(wn_ctx* ctx, float* params, const float* grads, float* adam_m, float* adam_v,
+                  float* ema, float lr, int64_t step, void* stream);
+/* wavenet.py:615-629 (host helper). */
+float wn_learning_rate(int32_t schedule, float init_lr, int64_t step, float decay_rate,
+                       int64_t decay_steps, float warmup_steps);
+
+/* ---- synthesis: replaces WaveNet.incremental (wavenet.py:724-911) ----------------------------- */
+/* Fast-WaveNet generation of T = Tc*hop samples for B streams with ring-buffer queues.
+ * c           float [B, cin, Tc]  (already transposed as wavenet.py:427)
+ * noise       float [T, B, noise_per_step]: MoL: M uniforms u1 then 1 uniform u2 (mixture.py:91,104);
+ *             Gaussian: 1 standard-normal draw (gaussian.py:50); softmax: Q uniforms (Gumbel-max form of
+ *             tf.multinomial, wavenet.py:865).  NULL => device Philox stream keyed by `seed`.
+ * test_inputs optional teacher forcing (wavenet.py:877-878): float [B,T] (scalar) / int32 [B,T] ids.
+ * out_samples float [B,T] (scalar types) or int32 [B,T] (class ids)   (wavenet.py:874, 897-911)
+ * out_raw     optional float [B, out_channels, T] raw network outputs  (wavenet.py:847, 904-908)     */
+int wn_synthesize(wn_ctx* ctx, const float* c, int32_t B, int32_t Tc, const float* noise,
+                  uint64_t seed, const void* test_inputs, void* out_samples, float* out_raw,
+                  int32_t steps_per_graph, void* stream);
+int wn_noise_per_step(const wn_ctx* ctx);
+
+/* Stand-alone samplers on [B,O,T] parameters (train-time log path, wavenet.py:302-325). */
+int wn_sample(wn_ctx* ctx, const float* y_hat, int32_t B, int32_t T, const float* noise /*[T,B,nps]*/,
+              void* out /* float [B,T] or int32 [B,T] */, void* stream);
+
+/* ---- mu-law codec (wavenet_vocoder/util.py:30-129; mu fixed to 255 as the reference does) ------ */
+int wn_mulaw(const float* x, float* y, int64_t n, void* stream);
+int wn_inv_mulaw(const float* y, float* x, int64_t n, void* stream);
+int wn_mulaw_quantize(const float* x, int32_t* q, int64_t n, void* stream);        /* bit-exact vs numpy */
+int wn_inv_mulaw_quantize(const int32_t* q, float* x, int64_t n, void* stream);
+/* argmax over channels of [B,Q,T] logits -> int32 [B,T] (first max wins, like tf.argmax) */
+int wn_argmax_channels(const float* logits, int32_t* out, int32_t B, int32_t Q, int32_t T, void* stream);
+
+/* ---- test hook: copy an internal activation buffer of the last step to `out` as fp32 ("X","U","TS","DZ",
+ * "R1","H2","DY","DSKIP","DPRE1","GX0","GX1","cbt" are bf16 [rows][channels]; "YHAT","DC","CUP" fp32). */
+int wn_debug_copy(wn_ctx* ctx, const char* name, int32_t layer, float* out, int64_t n, void* stream);
+
+/* ---- introspection for bench / profiling ----------------------------------------------------- */
+int64_t wn_workspace_bytes(const wn_ctx* ctx);
+/* name of the kernel that dominates training time + its algorithmic bytes/flops per audio sample */
+const char* wn_dominant_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVENET_MI355_H */

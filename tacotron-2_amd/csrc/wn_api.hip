@@ -1,0 +1,296 @@
+// Host side of the C ABI: context, parameter table, workspace, dispatch.
+#include "wn_common.h"
+#include <math.h>
+
+std::string g_create_err;
+
+static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+static void add_tensor(wn_ctx* c, const std::string& name, std::initializer_list<int> shape, int64_t* off_out) {
+    WnTensor t; t.name = name; t.ndim = (int)shape.size(); t.numel = 1;
+    int i = 0; for (int s : shape) { t.shape[i++] = s; t.numel *= s; }
+    for (; i < 4; ++i) t.shape[i] = 1;
+    t.offset = c->n_params;
+    c->n_params = align_up(c->n_params + t.numel, 8);       // 32-B aligned tensors
+    *off_out = t.offset;
+    c->tensors.push_back(t);
+}
+
+// Flat parameter table.  Names mirror the reference's variable scopes (wavenet.py:103-205,
+// modules.py:407-450); layouts are TensorFlow's.  Within a layer the cin kernel directly follows the
+// dilated kernel so that d[W_dil; W_cin] is one contiguous [(3R+C), G] matrix for the wgrad kernel.
+static void build_layout(wn_ctx* c) {
+    char buf[160];
+    add_tensor(c, "input_convolution/kernel", {1, c->Cin, c->R}, &c->first.dil_k);
+    add_tensor(c, "input_convolution/bias", {c->R}, &c->first.dil_b);
+    c->lay.resize(c->L);
+    for (int l = 0; l < c->L; ++l) {
+        WnLayerOffsets& o = c->lay[l];
+        auto nm = [&](const char* s) { snprintf(buf, sizeof buf, "ResidualConv1DGLU_%d/%s", l, s); return std::string(buf); };
+        add_tensor(c, nm("residual_block_causal_conv/kernel"), {3, c->R, c->G}, &o.dil_k);
+        add_tensor(c, nm("residual_block_cin_conv/kernel"), {1, c->C, c->G}, &o.cin_k);
+        add_tensor(c, nm("residual_block_causal_conv/bias"), {c->G}, &o.dil_b);
+        add_tensor(c, nm("residual_block_cin_conv/bias"), {c->G}, &o.cin_b);
+        add_tensor(c, nm("residual_block_skip_conv/kernel"), {1, c->GH, c->S}, &o.skip_k);
+        add_tensor(c, nm("residual_block_out_conv/kernel"), {1, c->GH, c->R}, &o.out_k);
+        add_tensor(c, nm("residual_block_skip_conv/bias"), {c->S}, &o.skip_b);
+        add_tensor(c, nm("residual_block_out_conv/bias"), {c->R}, &o.out_b);
+    }
+    add_tensor(c, "final_convolution_1/kernel", {1, c->S, c->S}, &c->fin1_k);
+    add_tensor(c, "final_convolution_1/bias", {c->S}, &c->fin1_b);
+    add_tensor(c, "final_convolution_2/kernel", {1, c->S, c->O}, &c->fin2_k);
+    add_tensor(c, "final_convolution_2/bias", {c->O}, &c->fin2_b);
+    const wn_config& g = c->cfg;
+    if (g.upsample_type != WN_UP_NEAREST) {
+        for (int i = 0; i < g.n_upsample; ++i) {
+            int s = g.upsample_scales[i], fk = g.freq_axis_kernel_size;
+            int64_t ko, bo;
+            snprintf(buf, sizeof buf, "local_conditioning_upsampling_%d/kernel", i + 1);
+            std::string kn = buf;
+            snprintf(buf, sizeof buf, "local_conditioning_upsampling_%d/bias", i + 1);
+            std::string bn = buf;
+            if (g.upsample_type == WN_UP_2D) { add_tensor(c, kn, {fk, s, 1, 1}, &ko); add_tensor(c, bn, {1}, &bo); }
+            else if (g.upsample_type == WN_UP_SUBPIXEL) { add_tensor(c, kn, {fk, 3, 1, s}, &ko); add_tensor(c, bn, {s}, &bo); }
+            else if (g.upsample_type == WN_UP_RESIZE) { add_tensor(c, kn, {fk, s, 1, 1}, &ko); add_tensor(c, bn, {1}, &bo); }
+            else { add_tensor(c, kn, {1, s, c->C, c->C}, &ko); add_tensor(c, bn, {c->C}, &bo); }
+            c->up_k.push_back(ko); c->up_b.push_back(bo);
+        }
+    }
+}
+
+static char* bump(char*& p, size_t bytes) { char* r = p; p += align_up((int64_t)bytes, 256); return r; }
+
+static int alloc_workspace(wn_ctx* c) {
+    const int64_t NT = c->NT;
+    const int ldDY = (int)align_up(c->O, 16);
+    size_t total = 0;
+    auto sz = [&](size_t b) { total += align_up((int64_t)b, 256); };
+    const int L = c->L;
+    sz(NT * c->C * 2);                     // cbt
+    sz((size_t)(L) * NT * c->R * 2);       // X[0..L-1]
+    sz((size_t)L * NT * c->G * 2);         // TS
+    sz((size_t)L * NT * c->GH * 2);        // U
+    sz(NT * c->S * 2); sz(NT * c->S * 2);  // R1, H2
+    sz(NT * ldDY * 2);                     // DY
+    sz(NT * c->S * 2); sz(NT * c->S * 2);  // DPRE1, DSKIP
+    sz((size_t)L * NT * c->G * 2);         // DZ
+    sz(NT * c->R * 2); sz(NT * c->R * 2);  // GX0, GX1
+    sz(NT * c->O * 4);                     // YHAT
+    sz(NT * c->C * 4);                     // DC
+    for (int i = 0; i <= c->cfg.n_upsample; ++i) sz(NT * c->C * 4);   // CUP (generous: every level sized for full rate)
+    sz(NT * c->C * 4); sz(NT * c->C * 4);  // DCUP ping-pong
+    sz(256);                               // scalars
+    c->ws_bytes = total;
+    hipError_t e = hipMalloc((void**)&c->ws, total);
+    if (e != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMalloc(%zu bytes workspace) failed: %s", total, hipGetErrorString(e));
+    char* p = c->ws;
+    c->cbt = (bf16_t*)bump(p, NT * c->C * 2);
+    c->X = (bf16_t*)bump(p, (size_t)L * NT * c->R * 2);
+    c->TS = (bf16_t*)bump(p, (size_t)L * NT * c->G * 2);
+    c->U = (bf16_t*)bump(p, (size_t)L * NT * c->GH * 2);
+    c->R1 = (bf16_t*)bump(p, NT * c->S * 2); c->H2 = (bf16_t*)bump(p, NT * c->S * 2);
+    c->DY = (bf16_t*)bump(p, NT * ldDY * 2);
+    c->DPRE1 = (bf16_t*)bump(p, NT * c->S * 2); c->DSKIP = (bf16_t*)bump(p, NT * c->S * 2);
+    c->DZ = (bf16_t*)bump(p, (size_t)L * NT * c->G * 2);
+    c->GX0 = (bf16_t*)bump(p, NT * c->R * 2); c->GX1 = (bf16_t*)bump(p, NT * c->R * 2);
+    c->YHAT = (float*)bump(p, NT * c->O * 4);
+    c->DC = (float*)bump(p, NT * c->C * 4);
+    for (int i = 0; i <= c->cfg.n_upsample; ++i) c->CUP[i] = (float*)bump(p, NT * c->C * 4);
+    c->DCUP[0] = (float*)bump(p, NT * c->C * 4); c->DCUP[1] = (float*)bump(p, NT * c->C * 4);
+    c->scal = (float*)bump(p, 256);
+    return WN_OK;
+}
+
+extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
+    wn_ctx* z = nullptr;
+    if (!cfg || !out) WN_FAIL(z, WN_E_ARG, "wn_create: null argument");
+    if (cfg->abi_version != WN_ABI_VERSION) WN_FAIL(z, WN_E_ARG, "wn_create: abi_version %d != %d", cfg->abi_version, WN_ABI_VERSION);
+    // constraints enforced by the reference
+    if (cfg->layers <= 0 || cfg->stacks <= 0 || cfg->layers % cfg->stacks != 0)
+        WN_FAIL(z, WN_E_SHAPE, "layers (%d) must be a positive multiple of stacks (%d) [wavenet.py:97]", cfg->layers, cfg->stacks);
+    if (cfg->kernel_size != 3) WN_FAIL(z, WN_E_UNSUPPORTED, "kernel_size %d: only 3 is built", cfg->kernel_size);
+    if (cfg->input_type < 0 || cfg->input_type > 2) WN_FAIL(z, WN_E_ARG, "bad input_type %d [util.py:10-11]", cfg->input_type);
+    if (cfg->input_type == WN_INPUT_MULAW_QUANTIZE && cfg->out_channels != cfg->quantize_channels)
+        WN_FAIL(z, WN_E_SHAPE, "out_channels must equal to quantize_chennels if input_type is 'mulaw-quantize' [models/__init__.py:6-9]");
+    if (cfg->input_type != WN_INPUT_MULAW_QUANTIZE && cfg->out_channels != 2 && cfg->out_channels % 3 != 0)
+        WN_FAIL(z, WN_E_SHAPE, "out_channels (%d) must be 2 (Gaussian) or a multiple of 3 (MoL) [mixture.py:30]", cfg->out_channels);
+    if (cfg->gate_channels % 2) WN_FAIL(z, WN_E_SHAPE, "gate_channels must be even");
+    if (cfg->residual_channels % 64 || (cfg->gate_channels / 2) % 32 || cfg->skip_out_channels % 64 || cfg->gate_channels % 64)
+        WN_FAIL(z, WN_E_UNSUPPORTED, "channel counts must be multiples of 64 (R=%d G=%d S=%d) for the MFMA tiling",
+                cfg->residual_channels, cfg->gate_channels, cfg->skip_out_channels);
+    if (cfg->cin_channels <= 0 || cfg->cin_channels % 16)
+        WN_FAIL(z, WN_E_UNSUPPORTED, "cin_channels (%d) must be a positive multiple of 16 (local conditioning is required)", cfg->cin_channels);
+    if (!cfg->use_bias) WN_FAIL(z, WN_E_UNSUPPORTED, "use_bias=False is not built");
+    if (cfg->n_upsample < 0 || cfg->n_upsample > WN_MAX_UPSAMPLE) WN_FAIL(z, WN_E_ARG, "bad n_upsample");
+    if (cfg->upsample_type != WN_UP_NEAREST && cfg->upsample_type != WN_UP_2D && cfg->upsample_type != WN_UP_SUBPIXEL &&
+        cfg->upsample_type != WN_UP_1D && cfg->upsample_type != WN_UP_RESIZE)
+        WN_FAIL(z, WN_E_ARG, "bad upsample_type %d", cfg->upsample_type);
+    if (cfg->upsample_type == WN_UP_1D || cfg->upsample_type == WN_UP_RESIZE)
+        WN_FAIL(z, WN_E_UNSUPPORTED, "upsample_type '1D'/'Resize' not built yet (2D, SubPixel, NearestNeighbor are)");
+    if (cfg->freq_axis_kernel_size % 2 == 0 || cfg->freq_axis_kernel_size > 9) WN_FAIL(z, WN_E_UNSUPPORTED, "freq_axis_kernel_size must be odd <= 9");
+    if (cfg->max_batch <= 0 || cfg->max_time <= 0) WN_FAIL(z, WN_E_ARG, "max_batch/max_time must be positive");
+    if (cfg->dropout < 0.f || cfg->dropout >= 1.f) WN_FAIL(z, WN_E_ARG, "dropout must be in [0,1)");
+    int hop = 1; for (int i = 0; i < cfg->n_upsample; ++i) { if (cfg->upsample_scales[i] <= 0) WN_FAIL(z, WN_E_ARG, "bad upsample scale"); hop *= cfg->upsample_scales[i]; }
+
+    wn_ctx* c = new wn_ctx();
+    c->cfg = *cfg;
+    c->L = cfg->layers; c->R = cfg->residual_channels; c->G = cfg->gate_channels; c->GH = c->G / 2;
+    c->S = cfg->skip_out_channels; c->O = cfg->out_channels; c->C = cfg->cin_channels;
+    c->Cin = (cfg->input_type == WN_INPUT_MULAW_QUANTIZE) ? cfg->quantize_channels : 1;
+    c->hop = hop;
+    c->OP = (int)align_up(c->O, 32); c->CP = (int)align_up(c->C, 32);
+    const int per = c->L / cfg->stacks;
+    for (int l = 0; l < c->L; ++l) c->dil.push_back(1 << (l % per));             // wavenet.py:125
+    c->res_scale = cfg->residual_legacy ? WN_SQRT_HALF : 1.0f;
+    c->skip_scale.resize(c->L);
+    for (int l = 0; l < c->L; ++l) {                                             // wavenet.py:706-715 unrolled
+        int e = cfg->legacy ? (l == 0 ? c->L - 1 : c->L - l) : 0;
+        c->skip_scale[l] = (float)pow((double)WN_SQRT_HALF, e);
+    }
+    build_layout(c);
+    c->cup_final_idx = (cfg->upsample_type == WN_UP_NEAREST) ? 0 : cfg->n_upsample - 1;
+    c->maxB = cfg->max_batch; c->maxT = cfg->max_time; c->NT = (int64_t)c->maxB * c->maxT;
+    int rc = alloc_workspace(c);
+    if (rc == WN_OK) rc = wn_build_packs(c);
+    if (rc != WN_OK) { g_create_err = c->err; wn_destroy(c); return rc; }
+    *out = c;
+    return WN_OK;
+}
+
+extern "C" void wn_destroy(wn_ctx* c) {
+    if (!c) return;
+    wn_synth_free(c);
+    auto fr = [](PackedW& w) { if (w.dev) hipFree(w.dev); if (w.dev_segs) hipFree(w.dev_segs); w.dev = nullptr; w.dev_segs = nullptr; };
+    for (auto& p : c->packs) { fr(p.w1); fr(p.wo); fr(p.ws); fr(p.w2T); fr(p.w1T); }
+    fr(c->wskip); fr(c->wh1); fr(c->wh2); fr(c->wh2T); fr(c->wh1T); fr(c->wcT);
+    if (c->b1sum) hipFree(c->b1sum);
+    if (c->skip_bias_total) hipFree(c->skip_bias_total);
+    if (c->tensor_offsets_dev) hipFree(c->tensor_offsets_dev);
+    if (c->norm2_dev) hipFree(c->norm2_dev);
+    if (c->params_dev) hipFree(c->params_dev);
+    if (c->ws) hipFree(c->ws);
+    delete c;
+}
+
+extern "C" const char* wn_last_error(const wn_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+extern "C" int wn_receptive_field(const wn_ctx* c) { int s = 0; for (int d : c->dil) s += d; return 2 * s + 1; }
+extern "C" int64_t wn_param_count(const wn_ctx* c) { return c->n_params; }
+extern "C" int wn_num_tensors(const wn_ctx* c) { return (int)c->tensors.size(); }
+extern "C" int wn_tensor_info(const wn_ctx* c, int i, char* name, int32_t* shape, int32_t* ndim, int64_t* offset) {
+    if (!c || i < 0 || i >= (int)c->tensors.size()) return WN_E_ARG;
+    const WnTensor& t = c->tensors[i];
+    if (name) { strncpy(name, t.name.c_str(), 127); name[127] = 0; }
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = t.shape[k];
+    if (ndim) *ndim = t.ndim;
+    if (offset) *offset = t.offset;
+    return WN_OK;
+}
+extern "C" int64_t wn_workspace_bytes(const wn_ctx* c) { return (int64_t)c->ws_bytes; }
+extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_tile_kernel"; }
+
+extern "C" int wn_pack_weights(wn_ctx* c, const float* params, void* stream) {
+    if (!c || !params) return WN_E_ARG;
+    return wn_launch_pack(c, params, (hipStream_t)stream);
+}
+
+extern "C" float wn_learning_rate(int32_t schedule, float init_lr, int64_t step, float decay_rate,
+                                  int64_t decay_steps, float warmup) {
+    if (schedule == WN_LR_NOAM) {                                   // wavenet.py:615-618
+        double s = (double)(step + 1);
+        double v = init_lr * pow((double)warmup, 0.5) * fmin(s * pow((double)warmup, -1.5), pow(s, -0.5));
+        return (float)fmax(v, 1e-4);
+    }
+    return (float)(init_lr * pow((double)decay_rate, (double)step / (double)decay_steps));   // wavenet.py:620-629
+}
+
+static int check_fwd_args(wn_ctx* c, const void* x, const float* cc, const void* y, const int32_t* len, int B, int T, int Tc) {
+    if (!x || !cc || !y || !len) WN_FAIL(c, WN_E_ARG, "wn_train_fwd: null pointer (Please provide either lengths or mask [modules.py:782-783])");
+    if (B <= 0 || B > c->maxB) WN_FAIL(c, WN_E_SHAPE, "batch %d outside (0, max_batch=%d]", B, c->maxB);
+    if (T <= 1 || T > c->maxT) WN_FAIL(c, WN_E_SHAPE, "time %d outside (1, max_time=%d]", T, c->maxT);
+    if (Tc * c->hop != T) WN_FAIL(c, WN_E_SHAPE, "upsampled conditioning length Tc*hop = %d*%d != T = %d [wavenet.py:699]", Tc, c->hop, T);
+    if (!c->packed) WN_FAIL(c, WN_E_STATE, "wn_pack_weights must be called before wn_train_fwd");
+    return WN_OK;
+}
+
+extern "C" int wn_train_fwd(wn_ctx* c, const void* x, const float* cc, const void* y, const int32_t* lengths,
+                            int32_t B, int32_t T, int32_t Tc, uint64_t seed, float* loss_out, float* y_hat_out, void* stream) {
+    if (!c) return WN_E_ARG;
+    int rc = check_fwd_args(c, x, cc, y, lengths, B, T, Tc);
+    if (rc) return rc;
+    c->fx = x; c->fc = cc; c->fy = y; c->flen = lengths; c->fB = B; c->fT = T; c->fTc = Tc; c->fseed = seed;
+    c->have_fwd = false;
+    rc = wn_fwd_impl(c, (hipStream_t)stream, loss_out, y_hat_out);
+    if (rc == WN_OK) c->have_fwd = true;
+    return rc;
+}
+
+extern "C" int wn_train_bwd(wn_ctx* c, float* grads, void* stream) {
+    if (!c || !grads) return WN_E_ARG;
+    if (!c->have_fwd) WN_FAIL(c, WN_E_STATE, "wn_train_bwd called without a preceding successful wn_train_fwd");
+    return wn_bwd_impl(c, grads, (hipStream_t)stream);
+}
+
+extern "C" int wn_optim_step(wn_ctx* c, float* p, const float* g, float* m, float* v, float* ema, float lr, int64_t step, void* stream) {
+    if (!c || !p || !g || !m || !v || !ema) return WN_E_ARG;
+    return wn_optim_impl(c, p, g, m, v, ema, lr, step, (hipStream_t)stream);
+}
+
+extern "C" int wn_get_upsampled_features(wn_ctx* c, float* out, void* stream) {
+    if (!c || !out) return WN_E_ARG;
+    if (c->fB <= 0) WN_FAIL(c, WN_E_STATE, "no forward/synthesis has run yet");
+    WN_HIP(c, hipMemcpyAsync(out, c->CUP[c->cup_final_idx], (size_t)c->fB * c->C * c->fT * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return WN_OK;
+}
+
+extern "C" int wn_synthesize(wn_ctx* c, const float* cc, int32_t B, int32_t Tc, const float* noise, uint64_t seed,
+                             const void* test_inputs, void* out_samples, float* out_raw, int32_t steps_per_graph, void* stream) {
+    if (!c || !cc || !out_samples) return WN_E_ARG;
+    if (!c->packed) WN_FAIL(c, WN_E_STATE, "wn_pack_weights must be called before wn_synthesize");
+    if (B <= 0 || B > 32) WN_FAIL(c, WN_E_SHAPE, "synthesis batch %d outside (0, 32]", B);
+    if (Tc <= 0) WN_FAIL(c, WN_E_SHAPE, "Tc must be positive");
+    if (!noise) WN_FAIL(c, WN_E_UNSUPPORTED, "device-generated noise not built yet: pass a noise buffer");
+    return wn_synth_impl(c, cc, B, Tc, noise, seed, test_inputs, out_samples, out_raw, steps_per_graph, (hipStream_t)stream);
+}
+
+extern "C" int wn_noise_per_step(const wn_ctx* c) {
+    if (c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE) return c->cfg.quantize_channels;
+    if (c->O == 2) return 1;
+    return c->O / 3 + 1;
+}
+
+extern "C" int wn_sample(wn_ctx* c, const float* y_hat, int32_t B, int32_t T, const float* noise, void* out, void* stream) {
+    if (!c || !y_hat || !noise || !out) return WN_E_ARG;
+    return wn_sample_impl(c, y_hat, B, T, noise, out, (hipStream_t)stream);
+}
+
+// ---- debug access to internal activations (tests only; converts bf16 buffers to fp32) --------
+__global__ void wn_bf16_to_f32(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bf2f(in[i]);
+}
+extern "C" int wn_debug_copy(wn_ctx* c, const char* name, int32_t layer, float* out, int64_t n, void* stream) {
+    if (!c || !name || !out || n <= 0) return WN_E_ARG;
+    const int64_t NT = c->NT;
+    const bf16_t* b = nullptr; const float* f = nullptr;
+    std::string s = name;
+    if (s == "cbt") b = c->cbt;
+    else if (s == "X") b = c->X + (size_t)layer * NT * c->R;
+    else if (s == "TS") b = c->TS + (size_t)layer * NT * c->G;
+    else if (s == "U") b = c->U + (size_t)layer * NT * c->GH;
+    else if (s == "R1") b = c->R1;
+    else if (s == "H2") b = c->H2;
+    else if (s == "DY") b = c->DY;
+    else if (s == "DPRE1") b = c->DPRE1;
+    else if (s == "DSKIP") b = c->DSKIP;
+    else if (s == "DZ") b = c->DZ + (size_t)layer * NT * c->G;
+    else if (s == "GX0") b = c->GX0;
+    else if (s == "GX1") b = c->GX1;
+    else if (s == "YHAT") f = c->YHAT;
+    else if (s == "DC") f = c->DC;
+    else if (s == "CUP") f = c->CUP[layer];
+    else WN_FAIL(c, WN_E_ARG, "wn_debug_copy: unknown buffer '%s'", name);
+    hipStream_t st = (hipStream_t)stream;
+    if (b) { hipLaunchKernelGGL(wn_bf16_to_f32, dim3(cdiv(n, 256)), dim3(256), 0, st, b, out, n); WN_LAUNCH_CHECK(c); }
+    else WN_HIP(c, hipMemcpyAsync(out, f, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    return WN_OK;
+}

@@ -1,0 +1,135 @@
+// Internal definitions shared by the HIP translation units of libwavenet_mi355.so.
+// gfx950 (MI355X / CDNA4) only -- no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/wavenet_mi355.h"
+
+typedef unsigned short bf16_t;                                    // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;      // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;      // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define WN_SQRT_HALF 0.70710678118654752440f
+
+// ------------------------------------------------------------------------------------------------
+// bf16 helpers (round-to-nearest-even, identical to torch's float->bfloat16)
+__host__ __device__ inline bf16_t f2bf(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((v.u >> 16) | 0x40);   // NaN
+    uint32_t r = v.u + 0x7fffu + ((v.u >> 16) & 1u);
+    return (bf16_t)(r >> 16);
+}
+__host__ __device__ inline float bf2f(bf16_t h) {
+    union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16; return v.f;
+}
+__device__ inline uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// ------------------------------------------------------------------------------------------------
+// Dropout mask: counter-based hash, one 32-bit word per PAIR of elements (16 bits each).
+// element e (flat index in the [rows][R] layer input) of layer-key `key` is KEPT iff
+// bits16(e) >= thresh16, thresh16 = round(p * 65536).  Spec mirrored in python (tests) bit for bit.
+__host__ __device__ inline uint32_t wn_mix32(uint32_t x) {          // murmur3 finaliser
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; return x;
+}
+__host__ __device__ inline uint32_t wn_drop_word(uint32_t key_lo, uint32_t key_hi, uint32_t pair_index) {
+    return wn_mix32(wn_mix32(pair_index ^ key_lo) + key_hi);
+}
+__host__ __device__ inline void wn_layer_key(uint64_t seed, int layer, uint32_t* lo, uint32_t* hi) {
+    uint64_t k = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer + 1) * 0xD1B54A32D192ED03ull;
+    k ^= k >> 29;
+    *lo = (uint32_t)k; *hi = (uint32_t)(k >> 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WnTensor {
+    std::string name;
+    int32_t shape[4];
+    int32_t ndim;
+    int64_t offset;       // floats into the flat buffer
+    int64_t numel;
+};
+
+struct WnLayerOffsets {   // offsets (floats) into the flat parameter buffer
+    int64_t dil_k, cin_k, dil_b, cin_b, skip_k, out_k, skip_b, out_b;
+};
+
+// A-operand pack descriptor: Wpk[m][k] = scale * params[base + (k - k0) * stride_k + perm(m) * stride_m]
+struct PackSeg { int64_t base; int32_t k0, nk, stride_k, stride_m; float scale; };
+
+struct PackedW {          // one fragment-ordered bf16 matrix
+    bf16_t* dev = nullptr;
+    int32_t M = 0, K = 0;             // padded: M % 32 == 0, K % 16 == 0
+    int32_t M_valid = 0;
+    int32_t gate_interleave = 0;      // row permutation (see wn_pack.hip)
+    int32_t GH = 0;
+    std::vector<PackSeg> segs;
+    PackSeg* dev_segs = nullptr;
+};
+
+struct WnLayerPacks { PackedW w1, wo, ws, w2T, w1T; };
+
+struct wn_ctx {
+    wn_config cfg;
+    std::string err;
+    int L, R, G, GH, S, O, C, Cin, hop;
+    int OP;                               // out_channels padded to 32
+    int CP;                               // cin padded to 32 (M of the d_c GEMM)
+    std::vector<int> dil;
+    std::vector<float> skip_scale;        // c_l of the legacy skip recursion (wavenet.py:706-715)
+    float res_scale;                      // sqrt(.5) if residual_legacy else 1
+    std::vector<WnTensor> tensors;
+    int64_t n_params = 0;
+    WnLayerOffsets first;                 // dil_k = input kernel, dil_b = input bias
+    std::vector<WnLayerOffsets> lay;
+    int64_t fin1_k, fin1_b, fin2_k, fin2_b;
+    std::vector<int64_t> up_k, up_b;
+    // packed weights
+    float* params_dev = nullptr;          // ctx-owned fp32 copy of the flat parameters taken at wn_pack_weights
+    bool packed = false;
+    int cup_final_idx = 0;                // CUP[cup_final_idx] = upsampled conditioning [B,C,T] fp32
+    std::vector<WnLayerPacks> packs;
+    PackedW wskip, wh1, wh2, wh2T, wh1T, wcT;
+    float* b1sum = nullptr;               // [L][G] dil bias + cin bias
+    float* skip_bias_total = nullptr;     // [S]
+    int32_t* tensor_offsets_dev = nullptr; // [ntensors+1] for the optimiser
+    float* norm2_dev = nullptr;           // [ntensors]
+    // workspace
+    char* ws = nullptr; size_t ws_bytes = 0;
+    int maxB, maxT; int64_t NT;
+    bf16_t *cbt, *X, *TS, *U, *R1, *H2, *DY, *DPRE1, *DSKIP, *DZ, *GX0, *GX1;
+    float *YHAT, *DC, *CUP[WN_MAX_UPSAMPLE + 1], *DCUP[2];
+    float* scal;                          // device scalars: [0]=loss sum [1]=denominator [2]=1/denominator [3]=count
+    // state of the last forward
+    int fB = 0, fT = 0, fTc = 0; uint64_t fseed = 0; bool have_fwd = false; bool have_loss = false;
+    const void* fx = nullptr; const void* fy = nullptr; const int32_t* flen = nullptr; const float* fc = nullptr;
+    // synthesis state (lazy)
+    struct Synth* synth = nullptr;
+};
+
+extern std::string g_create_err;
+
+#define WN_FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); \
+    if (ctx) (ctx)->err = _b; else g_create_err = _b; return (code); } while (0)
+#define WN_HIP(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
+    WN_FAIL(ctx, WN_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+#define WN_LAUNCH_CHECK(ctx) WN_HIP(ctx, hipGetLastError())
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- cross-TU entry points (host) ---------------------------------------------------------------
+int wn_build_packs(wn_ctx* ctx);
+int wn_launch_pack(wn_ctx* ctx, const float* params, hipStream_t st);
+int wn_fwd_impl(wn_ctx* ctx, hipStream_t st, float* loss_out, float* y_hat_out);
+int wn_bwd_impl(wn_ctx* ctx, float* grads, hipStream_t st);
+int wn_optim_impl(wn_ctx* ctx, float* p, const float* g, float* m, float* v, float* ema, float lr, int64_t step, hipStream_t st);
+int wn_synth_impl(wn_ctx* ctx, const float* c, int B, int Tc, const float* noise, uint64_t seed,
+                  const void* test_inputs, void* out_samples, float* out_raw, int steps_per_graph, hipStream_t st);
+void wn_synth_free(wn_ctx* ctx);
+int wn_upsample_fwd(wn_ctx* ctx, const float* params_unused, const float* c, int B, int Tc, hipStream_t st);
+int wn_sample_impl(wn_ctx* ctx, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st);

@@ -1,0 +1,748 @@
+// Element-wise / reduction kernels of the WaveNet hot path (everything that is not an MFMA contraction):
+// weight packing, input convolution, upsample net, losses (+ their gradients), optimiser, mu-law codec,
+// samplers.  All HBM-bound: coalesced along the contiguous axis, 64-wide waves, grid-stride where large.
+#include "wn_common.h"
+#include "wn_mulaw_tables.h"
+#include <math.h>
+
+// =================================================================================== weight packing
+// Fragment order of v_mfma_f32_32x32x16_bf16's A operand:  out[((mtile*KS + ks)*64 + lane)*8 + j]
+//   <-> W[m = mtile*32 + (lane&31)][k = ks*16 + 8*(lane>>5) + j]
+__global__ void wn_pack_kernel(const float* __restrict__ params, bf16_t* __restrict__ out, int M, int K, int M_valid,
+                               int gate_il, int GH, const PackSeg* __restrict__ segs, int nseg) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * K) return;
+    const int KS = K >> 4;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    const int64_t rest = idx >> 9;
+    const int ks = (int)(rest % KS), mtile = (int)(rest / KS);
+    const int m = mtile * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
+    int mm = m;
+    if (gate_il) {          // rows come in 64-row groups [32 tanh rows | their 32 sigmoid partners] (modules.py:494,510)
+        const int blk = m >> 6, w = m & 63;
+        mm = (w < 32) ? blk * 32 + w : GH + blk * 32 + (w - 32);
+    }
+    float v = 0.0f;
+    if (mm < M_valid) {
+        for (int s = 0; s < nseg; ++s) {
+            const PackSeg sg = segs[s];
+            if (k >= sg.k0 && k < sg.k0 + sg.nk) {
+                v = sg.scale * params[sg.base + (int64_t)(k - sg.k0) * sg.stride_k + (int64_t)mm * sg.stride_m];
+                break;
+            }
+        }
+    }
+    out[idx] = f2bf(v);
+}
+
+struct VecSum { int n; int64_t off[32]; float w[32]; };
+__global__ void wn_vecsum_kernel(const float* __restrict__ params, float* __restrict__ out, int len, VecSum vs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    float a = 0.0f;
+    for (int j = 0; j < vs.n; ++j) a += vs.w[j] * params[vs.off[j] + i];
+    out[i] = a;
+}
+
+static void init_pack(wn_ctx* c, PackedW& w, int M_src, int K_src, int gate_il) {
+    w.M = (M_src + 31) / 32 * 32; w.K = (K_src + 15) / 16 * 16; w.M_valid = M_src; w.gate_interleave = gate_il; w.GH = c->GH;
+}
+
+static int finish_pack(wn_ctx* c, PackedW& w) {
+    WN_HIP(c, hipMalloc((void**)&w.dev, (size_t)w.M * w.K * 2));
+    WN_HIP(c, hipMalloc((void**)&w.dev_segs, w.segs.size() * sizeof(PackSeg)));
+    WN_HIP(c, hipMemcpy(w.dev_segs, w.segs.data(), w.segs.size() * sizeof(PackSeg), hipMemcpyHostToDevice));
+    return WN_OK;
+}
+
+int wn_build_packs(wn_ctx* c) {
+    const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, O = c->O, C = c->C;
+    c->packs.resize(L);
+    int rc;
+    for (int l = 0; l < L; ++l) {
+        const WnLayerOffsets& o = c->lay[l];
+        WnLayerPacks& p = c->packs[l];
+        // W1: rows = gate channels (interleaved), K = [tap0 R | tap1 R | tap2 R | cin C]; W[g][j*R+r] = dil[j][r][g]
+        init_pack(c, p.w1, G, 3 * R + C, 1);
+        for (int j = 0; j < 3; ++j) p.w1.segs.push_back({o.dil_k + (int64_t)j * R * G, j * R, R, G, 1, 1.0f});
+        p.w1.segs.push_back({o.cin_k, 3 * R, C, G, 1, 1.0f});
+        if ((rc = finish_pack(c, p.w1))) return rc;
+        // Wo: rows = residual channels, K = GH;  W[r][g'] = out_k[g'][r]
+        init_pack(c, p.wo, R, GH, 0);
+        p.wo.segs.push_back({o.out_k, 0, GH, R, 1, 1.0f});
+        if ((rc = finish_pack(c, p.wo))) return rc;
+        // Ws (synthesis): rows = skip channels, scaled by the legacy factor
+        init_pack(c, p.ws, S, GH, 0);
+        p.ws.segs.push_back({o.skip_k, 0, GH, S, 1, c->skip_scale[l]});
+        if ((rc = finish_pack(c, p.ws))) return rc;
+        // W2T (dgate): rows = g', K = [R | S];  W[g'][r] = out_k[g'][r],  W[g'][R+s] = c_l * skip_k[g'][s]
+        init_pack(c, p.w2T, GH, R + S, 0);
+        p.w2T.segs.push_back({o.out_k, 0, R, 1, R, 1.0f});
+        p.w2T.segs.push_back({o.skip_k, R, S, 1, S, c->skip_scale[l]});
+        if ((rc = finish_pack(c, p.w2T))) return rc;
+        // W1T (dx): rows = r, K = [tap0 G | tap1 G | tap2 G];  W[r][j*G+g] = dil[j][r][g]
+        init_pack(c, p.w1T, R, 3 * G, 0);
+        for (int j = 0; j < 3; ++j) p.w1T.segs.push_back({o.dil_k + (int64_t)j * R * G, j * G, G, 1, G, 1.0f});
+        if ((rc = finish_pack(c, p.w1T))) return rc;
+    }
+    // skip sum as ONE contraction over all layers' gate outputs: rows = s, K = L*GH (wavenet.py:706-715 unrolled)
+    init_pack(c, c->wskip, S, L * GH, 0);
+    for (int l = 0; l < L; ++l) c->wskip.segs.push_back({c->lay[l].skip_k, l * GH, GH, S, 1, c->skip_scale[l]});
+    if ((rc = finish_pack(c, c->wskip))) return rc;
+    init_pack(c, c->wh1, S, S, 0); c->wh1.segs.push_back({c->fin1_k, 0, S, S, 1, 1.0f});
+    if ((rc = finish_pack(c, c->wh1))) return rc;
+    init_pack(c, c->wh2, O, S, 0); c->wh2.segs.push_back({c->fin2_k, 0, S, O, 1, 1.0f});
+    if ((rc = finish_pack(c, c->wh2))) return rc;
+    init_pack(c, c->wh2T, S, O, 0); c->wh2T.segs.push_back({c->fin2_k, 0, O, 1, O, 1.0f});
+    if ((rc = finish_pack(c, c->wh2T))) return rc;
+    init_pack(c, c->wh1T, S, S, 0); c->wh1T.segs.push_back({c->fin1_k, 0, S, 1, S, 1.0f});
+    if ((rc = finish_pack(c, c->wh1T))) return rc;
+    // d_c: rows = cin channel, K = L*G;  W[cc][l*G+g] = cin_k_l[cc][g]
+    init_pack(c, c->wcT, C, L * G, 0);
+    for (int l = 0; l < L; ++l) c->wcT.segs.push_back({c->lay[l].cin_k, l * G, G, 1, G, 1.0f});
+    if ((rc = finish_pack(c, c->wcT))) return rc;
+
+    WN_HIP(c, hipMalloc((void**)&c->b1sum, (size_t)L * G * 4));
+    WN_HIP(c, hipMalloc((void**)&c->skip_bias_total, (size_t)S * 4));
+    WN_HIP(c, hipMalloc((void**)&c->params_dev, (size_t)c->n_params * 4));
+    const int nt = (int)c->tensors.size();
+    std::vector<int32_t> offs(nt + 1);
+    for (int i = 0; i < nt; ++i) offs[i] = (int32_t)c->tensors[i].offset;
+    offs[nt] = (int32_t)c->n_params;
+    WN_HIP(c, hipMalloc((void**)&c->tensor_offsets_dev, (nt + 1) * 4));
+    WN_HIP(c, hipMemcpy(c->tensor_offsets_dev, offs.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
+    WN_HIP(c, hipMalloc((void**)&c->norm2_dev, nt * 4));
+    return WN_OK;
+}
+
+static int launch_one_pack(wn_ctx* c, const PackedW& w, hipStream_t st) {
+    const int64_t n = (int64_t)w.M * w.K;
+    hipLaunchKernelGGL(wn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, c->params_dev, w.dev, w.M, w.K,
+                       w.gate_interleave ? c->G : w.M_valid, w.gate_interleave, w.GH, w.dev_segs, (int)w.segs.size());
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
+int wn_launch_pack(wn_ctx* c, const float* params, hipStream_t st) {
+    WN_HIP(c, hipMemcpyAsync(c->params_dev, params, (size_t)c->n_params * 4, hipMemcpyDeviceToDevice, st));
+    int rc;
+    for (int l = 0; l < c->L; ++l) {
+        WnLayerPacks& p = c->packs[l];
+        if ((rc = launch_one_pack(c, p.w1, st))) return rc;
+        if ((rc = launch_one_pack(c, p.wo, st))) return rc;
+        if ((rc = launch_one_pack(c, p.ws, st))) return rc;
+        if ((rc = launch_one_pack(c, p.w2T, st))) return rc;
+        if ((rc = launch_one_pack(c, p.w1T, st))) return rc;
+        VecSum vs; vs.n = 2; vs.off[0] = c->lay[l].dil_b; vs.off[1] = c->lay[l].cin_b; vs.w[0] = vs.w[1] = 1.0f;
+        hipLaunchKernelGGL(wn_vecsum_kernel, dim3(cdiv(c->G, 256)), dim3(256), 0, st, c->params_dev, c->b1sum + (size_t)l * c->G, c->G, vs);
+    }
+    if ((rc = launch_one_pack(c, c->wskip, st))) return rc;
+    if ((rc = launch_one_pack(c, c->wh1, st))) return rc;
+    if ((rc = launch_one_pack(c, c->wh2, st))) return rc;
+    if ((rc = launch_one_pack(c, c->wh2T, st))) return rc;
+    if ((rc = launch_one_pack(c, c->wh1T, st))) return rc;
+    if ((rc = launch_one_pack(c, c->wcT, st))) return rc;
+    if (c->L > 32) WN_FAIL(c, WN_E_UNSUPPORTED, "layers > 32");
+    VecSum vs; vs.n = c->L;
+    for (int l = 0; l < c->L; ++l) { vs.off[l] = c->lay[l].skip_b; vs.w[l] = c->skip_scale[l]; }
+    hipLaunchKernelGGL(wn_vecsum_kernel, dim3(cdiv(c->S, 256)), dim3(256), 0, st, c->params_dev, c->skip_bias_total, c->S, vs);
+    WN_LAUNCH_CHECK(c);
+    c->packed = true;
+    return WN_OK;
+}
+
+// =================================================================================== input convolution
+// wavenet.py:705 / modules.py:336: h0[t][r] = W[cin][r] x[cin][t] + b[r]; Cin = 1 (scalar) or a one-hot row gather.
+__global__ void wn_first_conv_fwd(const void* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                  bf16_t* __restrict__ X0, int64_t rows, int R, int is_ids) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r8 = R >> 3;
+    if (idx >= rows * r8) return;
+    const int64_t row = idx / r8; const int c0 = (int)(idx - row * r8) * 8;
+    float v[8];
+    if (is_ids) {
+        const int id = ((const int32_t*)x)[row];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = W[(int64_t)id * R + c0 + i] + bias[c0 + i];
+    } else {
+        const float xv = ((const float*)x)[row];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = W[c0 + i] * xv + bias[c0 + i];
+    }
+    *reinterpret_cast<uint4*>(X0 + row * R + c0) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
+// dW[cin][r] = sum_t x[cin][t] g0[t][r];  db[r] = sum_t g0[t][r]
+__global__ void wn_first_conv_bwd(const void* __restrict__ x, const bf16_t* __restrict__ g0, float* __restrict__ dW,
+                                  float* __restrict__ db, int64_t rows, int R, int is_ids, int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        float sw = 0.0f, sb = 0.0f;
+        for (int64_t row = r0; row < r1; ++row) {
+            const float g = bf2f(g0[row * R + r]);
+            sb += g;
+            if (is_ids) unsafeAtomicAdd(&dW[(int64_t)((const int32_t*)x)[row] * R + r], g);
+            else sw += ((const float*)x)[row] * g;
+        }
+        unsafeAtomicAdd(&db[r], sb);
+        if (!is_ids) unsafeAtomicAdd(&dW[r], sw);
+    }
+}
+
+int wn_first_conv(wn_ctx* c, hipStream_t st) {
+    const int64_t rows = (int64_t)c->fB * c->fT;
+    const int is_ids = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE;
+    hipLaunchKernelGGL(wn_first_conv_fwd, dim3(cdiv(rows * (c->R / 8), 256)), dim3(256), 0, st, c->fx,
+                       c->params_dev + c->first.dil_k, c->params_dev + c->first.dil_b, c->X, rows, c->R, is_ids);
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+int wn_first_conv_grad(wn_ctx* c, const bf16_t* g0, float* grads, hipStream_t st) {
+    const int64_t rows = (int64_t)c->fB * c->fT;
+    const int is_ids = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE;
+    const int rpb = 128;
+    hipLaunchKernelGGL(wn_first_conv_bwd, dim3(cdiv(rows, rpb)), dim3(256), 0, st, c->fx, g0, grads + c->first.dil_k,
+                       grads + c->first.dil_b, rows, c->R, is_ids, rpb);
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
+// =================================================================================== upsample net
+// modules.py:524-770, wavenet.py:680-702.  Layouts [B][C(freq)][T] fp32; the last layer also emits the bf16
+// time-major copy cbt[b*T+t][C] that the gate GEMM stages.
+__device__ __forceinline__ float act_fwd(float v, int act, float alpha) {
+    if (act == WN_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == WN_ACT_LEAKY_RELU) return v > 0.0f ? v : alpha * v;
+    return v;
+}
+__device__ __forceinline__ float act_grad(float out, int act, float alpha) {   // derivative expressed through the OUTPUT
+    if (act == WN_ACT_RELU) return out > 0.0f ? 1.0f : 0.0f;
+    if (act == WN_ACT_LEAKY_RELU) return out > 0.0f ? 1.0f : alpha;
+    return 1.0f;
+}
+
+// type 0: nearest (s = hop); 1: 2D transposed conv k=(fk,s) stride (1,s); 2: SubPixel conv k=(fk,3) + shuffle
+__global__ void wn_up_fwd(const float* __restrict__ in, float* __restrict__ out, bf16_t* __restrict__ cbt,
+                          const float* __restrict__ K, const float* __restrict__ bias, int B, int C, int Tin, int s,
+                          int fk, int type, int act, float alpha) {
+    const int Tout = Tin * s;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * C * Tout) return;
+    const int to = (int)(idx % Tout); const int64_t bf = idx / Tout;
+    const int f = (int)(bf % C), b = (int)(bf / C);
+    const int t = to / s, j = to - t * s;
+    const float* inb = in + (int64_t)b * C * Tin;
+    float v;
+    if (type == 0) v = inb[(int64_t)f * Tin + t];
+    else if (type == 1) {
+        const int pf = (fk - 1) / 2;
+        v = bias[0];
+        for (int kf = 0; kf < fk; ++kf) { const int fs = f - kf + pf; if (fs >= 0 && fs < C) v += inb[(int64_t)fs * Tin + t] * K[kf * s + j]; }
+        v = act_fwd(v, act, alpha);
+    } else {
+        const int pf = (fk - 1) / 2;
+        v = bias[j];
+        for (int kf = 0; kf < fk; ++kf) {
+            const int fs = f + kf - pf; if (fs < 0 || fs >= C) continue;
+            for (int kt = 0; kt < 3; ++kt) { const int tsrc = t + kt - 1; if (tsrc >= 0 && tsrc < Tin) v += inb[(int64_t)fs * Tin + tsrc] * K[(kf * 3 + kt) * s + j]; }
+        }
+        v = act_fwd(v, act, alpha);
+    }
+    out[idx] = v;
+    if (cbt) cbt[((int64_t)b * Tout + to) * C + f] = f2bf(v);
+}
+
+// dpre = dout * act'(out);  dK, dbias accumulated with atomics;  (one thread per output element)
+__global__ void wn_up_bwd_params(const float* __restrict__ in, const float* __restrict__ out, const float* __restrict__ dout,
+                                 float* __restrict__ dK, float* __restrict__ dbias, int B, int C, int Tin, int s, int fk,
+                                 int type, int act, float alpha) {
+    extern __shared__ float sh[];          // [nk + nb]
+    const int nk = (type == 1) ? fk * s : fk * 3 * s;
+    const int nb = (type == 1) ? 1 : s;
+    for (int i = threadIdx.x; i < nk + nb; i += blockDim.x) sh[i] = 0.0f;
+    __syncthreads();
+    const int Tout = Tin * s;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (int64_t)B * C * Tout) {
+        const int to = (int)(idx % Tout); const int64_t bf = idx / Tout;
+        const int f = (int)(bf % C), b = (int)(bf / C);
+        const int t = to / s, j = to - t * s;
+        const float dp = dout[idx] * act_grad(out[idx], act, alpha);
+        if (dp != 0.0f) {
+            const float* inb = in + (int64_t)b * C * Tin;
+            const int pf = (fk - 1) / 2;
+            if (type == 1) {
+                atomicAdd(&sh[nk], dp);
+                for (int kf = 0; kf < fk; ++kf) { const int fs = f - kf + pf; if (fs >= 0 && fs < C) atomicAdd(&sh[kf * s + j], inb[(int64_t)fs * Tin + t] * dp); }
+            } else {
+                atomicAdd(&sh[nk + j], dp);
+                for (int kf = 0; kf < fk; ++kf) {
+                    const int fs = f + kf - pf; if (fs < 0 || fs >= C) continue;
+                    for (int kt = 0; kt < 3; ++kt) { const int tsrc = t + kt - 1; if (tsrc >= 0 && tsrc < Tin) atomicAdd(&sh[(kf * 3 + kt) * s + j], inb[(int64_t)fs * Tin + tsrc] * dp); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) if (sh[i] != 0.0f) unsafeAtomicAdd(&dK[i], sh[i]);
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) if (sh[nk + i] != 0.0f) unsafeAtomicAdd(&dbias[i], sh[nk + i]);
+}
+
+// din[b][f'][t] (one thread per input element)
+__global__ void wn_up_bwd_input(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ din,
+                                const float* __restrict__ K, int B, int C, int Tin, int s, int fk, int type, int act, float alpha) {
+    const int Tout = Tin * s;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * C * Tin) return;
+    const int t = (int)(idx % Tin); const int64_t bf = idx / Tin;
+    const int f = (int)(bf % C), b = (int)(bf / C);
+    const int pf = (fk - 1) / 2;
+    const float* ob = out + (int64_t)b * C * Tout; const float* db = dout + (int64_t)b * C * Tout;
+    float a = 0.0f;
+    if (type == 0) {
+        for (int j = 0; j < s; ++j) a += db[(int64_t)f * Tout + t * s + j];
+    } else if (type == 1) {
+        for (int kf = 0; kf < fk; ++kf) {
+            const int fo = f + kf - pf; if (fo < 0 || fo >= C) continue;
+            for (int j = 0; j < s; ++j) { const int64_t o = (int64_t)fo * Tout + t * s + j; a += K[kf * s + j] * db[o] * act_grad(ob[o], act, alpha); }
+        }
+    } else {
+        for (int kf = 0; kf < fk; ++kf) {
+            const int fo = f - kf + pf; if (fo < 0 || fo >= C) continue;
+            for (int kt = 0; kt < 3; ++kt) {
+                const int tt = t - kt + 1; if (tt < 0 || tt >= Tin) continue;
+                for (int j = 0; j < s; ++j) { const int64_t o = (int64_t)fo * Tout + tt * s + j; a += K[(kf * 3 + kt) * s + j] * db[o] * act_grad(ob[o], act, alpha); }
+            }
+        }
+    }
+    din[idx] = a;
+}
+
+static int up_type_code(const wn_ctx* c) { return c->cfg.upsample_type == WN_UP_NEAREST ? 0 : c->cfg.upsample_type == WN_UP_2D ? 1 : 2; }
+
+// c_in [B,C,Tc] fp32 -> CUP[i] (fp32 per level), cbt (bf16 time-major)
+int wn_upsample_fwd(wn_ctx* c, const float*, const float* cin, int B, int Tc, hipStream_t st) {
+    const int type = up_type_code(c);
+    const int C = c->C;
+    if (type == 0) {
+        const int64_t n = (int64_t)B * C * Tc * c->hop;
+        hipLaunchKernelGGL(wn_up_fwd, dim3(cdiv(n, 256)), dim3(256), 0, st, cin, c->CUP[0], c->cbt, nullptr, nullptr, B, C, Tc, c->hop, 1, 0, 0, 0.0f);
+        WN_LAUNCH_CHECK(c);
+        return WN_OK;
+    }
+    const float* in = cin; int Tin = Tc;
+    for (int i = 0; i < c->cfg.n_upsample; ++i) {
+        const int s = c->cfg.upsample_scales[i];
+        const bool last = (i == c->cfg.n_upsample - 1);
+        const int64_t n = (int64_t)B * C * Tin * s;
+        hipLaunchKernelGGL(wn_up_fwd, dim3(cdiv(n, 256)), dim3(256), 0, st, in, c->CUP[i], last ? c->cbt : nullptr,
+                           c->params_dev + c->up_k[i], c->params_dev + c->up_b[i], B, C, Tin, s, c->cfg.freq_axis_kernel_size,
+                           type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
+        WN_LAUNCH_CHECK(c);
+        in = c->CUP[i]; Tin *= s;
+    }
+    return WN_OK;
+}
+
+// dc_final [B,C,T] fp32 (d loss / d upsampled conditioning) -> grads of the upsample kernels/biases
+int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t st) {
+    const int type = up_type_code(c);
+    if (type == 0) return WN_OK;               // no parameters
+    const int C = c->C, B = c->fB;
+    const float* dout = dc_final;
+    int Tout = c->fT;
+    for (int i = c->cfg.n_upsample - 1; i >= 0; --i) {
+        const int s = c->cfg.upsample_scales[i];
+        const int Tin = Tout / s;
+        const float* in = (i == 0) ? c->fc : c->CUP[i - 1];
+        const int fk = c->cfg.freq_axis_kernel_size;
+        const int nk = (type == 1) ? fk * s : fk * 3 * s, nb = (type == 1) ? 1 : s;
+        if ((size_t)(nk + nb) * 4 > 60000) WN_FAIL(c, WN_E_UNSUPPORTED, "upsample scale %d too large for the LDS partials", s);
+        const int64_t n = (int64_t)B * C * Tout;
+        hipLaunchKernelGGL(wn_up_bwd_params, dim3(cdiv(n, 256)), dim3(256), (nk + nb) * 4, st, in, c->CUP[i], dout,
+                           grads + c->up_k[i], grads + c->up_b[i], B, C, Tin, s, fk, type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
+        WN_LAUNCH_CHECK(c);
+        if (i > 0) {
+            float* din = c->DCUP[i & 1];
+            const int64_t ni = (int64_t)B * C * Tin;
+            hipLaunchKernelGGL(wn_up_bwd_input, dim3(cdiv(ni, 256)), dim3(256), 0, st, c->CUP[i], dout, din, c->params_dev + c->up_k[i],
+                               B, C, Tin, s, fk, type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
+            WN_LAUNCH_CHECK(c);
+            dout = din;
+        }
+        Tout = Tin;
+    }
+    return WN_OK;
+}
+
+// =================================================================================== losses
+__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.0f) + log1pf(__expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// scal[0] = loss accumulator, [1] = denominator, [2] = 1/denominator, [3] = non-zero count (CE)
+__global__ void wn_loss_prep(const int32_t* __restrict__ lengths, int B, int T, float* scal) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float d = 0.0f;
+        for (int b = 0; b < B; ++b) { int l = min(lengths[b], T); d += (float)max(l - 1, 0); }   // sum(mask[:,1:]) wavenet.py:632-638
+        scal[0] = 0.0f; scal[1] = d; scal[2] = d > 0.0f ? 1.0f / d : 0.0f; scal[3] = 0.0f;
+    }
+}
+
+#define WN_MAX_MIX 16
+// Discretised mixture of logistics, mixture.py:18-74 + modules.py:800-817, with its gradient.
+// one thread per (b, t): prediction at t scored against y[t+1] (wavenet.py:494-495).
+__global__ void wn_mol_loss(const float* __restrict__ yhat, const float* __restrict__ y, const int32_t* __restrict__ lengths,
+                            bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, int B, int T, int M,
+                            float num_classes, float log_scale_min) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float my = 0.0f;
+    if (idx < (int64_t)B * T) {
+        const int b = (int)(idx / T), t = (int)(idx - (int64_t)b * T);
+        const bool valid = (t + 1 < T) && (t + 1 < lengths[b]);
+        bf16_t* drow = dY + idx * ldDY;
+        if (!valid) {
+            for (int o = 0; o < ldDY; ++o) drow[o] = 0;
+        } else {
+            const float inv_den = scal[2];
+            const float yv = y[(int64_t)b * T + t + 1];
+            const float* yh = yhat + ((int64_t)b * 3 * M) * T + t;
+            float logit[WN_MAX_MIX], lp[WN_MAX_MIX], dmu[WN_MAX_MIX], dls[WN_MAX_MIX];
+            const float D = 1.0f / (num_classes - 1.0f);
+            const float logbin = logf((num_classes - 1.0f) * 0.5f);
+            float mx = -INFINITY;
+            for (int i = 0; i < M; ++i) { logit[i] = yh[(int64_t)i * T]; mx = fmaxf(mx, logit[i]); }
+            float se = 0.0f;
+            for (int i = 0; i < M; ++i) se += __expf(logit[i] - mx);
+            const float lse = logf(se);
+            float mlp = -INFINITY;
+            for (int i = 0; i < M; ++i) {
+                const float mu = yh[(int64_t)(M + i) * T];
+                const float lsr = yh[(int64_t)(2 * M + i) * T];
+                const float ls = fmaxf(lsr, log_scale_min);
+                const float cy = yv - mu, inv = __expf(-ls);
+                const float p = inv * (cy + D), m = inv * (cy - D), mid = inv * cy;
+                float l, gm, gs;          // log-prob and its derivatives wrt mu and ls
+                if (yv < -0.999f) { l = p - softplusf(p); const float s = sigmoidf_(-p); gm = -inv * s; gs = -p * s; }
+                else if (yv > 0.999f) { l = -softplusf(m); const float s = sigmoidf_(m); gm = inv * s; gs = m * s; }
+                else {
+                    const float sp = sigmoidf_(p), sm = sigmoidf_(m);
+                    const float cd = sp - sm;
+                    if (cd > 1e-5f) {
+                        l = logf(fmaxf(cd, 1e-12f));
+                        const float dp = sp * (1.0f - sp), dm = sm * (1.0f - sm);
+                        gm = -inv * (dp - dm) / cd; gs = (-p * dp + m * dm) / cd;
+                    } else {
+                        const float q = 1.0f - 2.0f * sigmoidf_(mid);
+                        l = mid - ls - 2.0f * softplusf(mid) - logbin;
+                        gm = -inv * q; gs = -mid * q - 1.0f;
+                    }
+                }
+                if (lsr < log_scale_min) gs = 0.0f;       // tf.maximum passes the gradient only where x >= min
+                lp[i] = l + (logit[i] - mx - lse);
+                dmu[i] = gm; dls[i] = gs;
+                mlp = fmaxf(mlp, lp[i]);
+            }
+            float sw = 0.0f;
+            for (int i = 0; i < M; ++i) sw += __expf(lp[i] - mlp);
+            const float loss = -(mlp + logf(sw));
+            my = loss;
+            for (int i = 0; i < M; ++i) {
+                const float w = __expf(lp[i] - mlp) / sw;              // responsibility
+                const float pi = __expf(logit[i] - mx) / se;           // prior
+                drow[i] = f2bf((pi - w) * inv_den);
+                drow[M + i] = f2bf(-w * dmu[i] * inv_den);
+                drow[2 * M + i] = f2bf(-w * dls[i] * inv_den);
+            }
+            for (int o = 3 * M; o < ldDY; ++o) drow[o] = 0;
+        }
+    }
+    // block reduce
+    for (int o = 32; o > 0; o >>= 1) my += __shfl_down(my, o);
+    __shared__ float part[8];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = my;
+    __syncthreads();
+    if (threadIdx.x == 0) { float s = 0.0f; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += part[i]; unsafeAtomicAdd(&scal[0], s); }
+}
+
+__device__ __forceinline__ float ndtrf_(float x) {      // TF special_math._ndtr, piecewise erf/erfc
+    const float hs2 = 0.70710678118654752440f;
+    const float w = x * hs2, z = fabsf(w);
+    const float y = (z < hs2) ? 1.0f + erff(w) : ((w > 0.0f) ? 2.0f - erfcf(z) : erfcf(z));
+    return 0.5f * y;
+}
+
+// Gaussian MLE, gaussian.py:5-37 + modules.py:819-836, with its gradient.
+__global__ void wn_gauss_loss(const float* __restrict__ yhat, const float* __restrict__ y, const int32_t* __restrict__ lengths,
+                              bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, int B, int T,
+                              float num_classes, float log_scale_min, int use_cdf) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float my = 0.0f;
+    if (idx < (int64_t)B * T) {
+        const int b = (int)(idx / T), t = (int)(idx - (int64_t)b * T);
+        const bool valid = (t + 1 < T) && (t + 1 < lengths[b]);
+        bf16_t* drow = dY + idx * ldDY;
+        float g0 = 0.0f, g1 = 0.0f;
+        if (valid) {
+            const float inv_den = scal[2];
+            const float yv = y[(int64_t)b * T + t + 1];
+            const float mu = yhat[((int64_t)b * 2) * T + t], lsr = yhat[((int64_t)b * 2 + 1) * T + t];
+            const float ls = fmaxf(lsr, log_scale_min);
+            float gm, gs, loss;
+            if (use_cdf) {
+                const float D = 1.0f / (num_classes - 1.0f);
+                const float sc = __expf(ls);
+                const float zp = (yv + D - mu) / sc, zm = (yv - D - mu) / sc;
+                const float diff = ndtrf_(zp) - ndtrf_(zm);
+                loss = -logf(fmaxf(diff, 1e-12f));
+                if (diff >= 1e-12f) {
+                    const float c0 = 0.3989422804014327f;
+                    const float pp = c0 * __expf(-0.5f * zp * zp), pm = c0 * __expf(-0.5f * zm * zm);
+                    gm = (pp - pm) / (sc * diff);            // d(-lp)/dmu
+                    gs = (zp * pp - zm * pm) / diff;         // d(-lp)/dls
+                } else { gm = 0.0f; gs = 0.0f; }
+            } else {
+                const float e2 = __expf(-2.0f * ls), dlt = yv - mu;
+                loss = 0.5f * (1.8378770664093453f + 2.0f * ls + dlt * dlt * e2);
+                gm = -dlt * e2; gs = 1.0f - dlt * dlt * e2;
+            }
+            if (lsr < log_scale_min) gs = 0.0f;
+            my = loss; g0 = gm * inv_den; g1 = gs * inv_den;
+        }
+        drow[0] = f2bf(g0); drow[1] = f2bf(g1);
+        for (int o = 2; o < ldDY; ++o) drow[o] = 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) my += __shfl_down(my, o);
+    __shared__ float part[8];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = my;
+    __syncthreads();
+    if (threadIdx.x == 0) { float s = 0.0f; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += part[i]; unsafeAtomicAdd(&scal[0], s); }
+}
+
+// Masked softmax cross-entropy, modules.py:781-798 (denominator = count_nonzero(masked loss)).
+// pass 0: per-element loss into `tmp`, sum and non-zero count; pass 1: gradients (needs the count).
+__global__ void wn_ce_loss(const float* __restrict__ yhat, const int32_t* __restrict__ y, const int32_t* __restrict__ lengths,
+                           bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, float* __restrict__ tmp,
+                           int B, int T, int Q, int pass) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float my = 0.0f, cnt = 0.0f;
+    if (idx < (int64_t)B * T) {
+        const int b = (int)(idx / T), t = (int)(idx - (int64_t)b * T);
+        const bool valid = (t + 1 < T) && (t + 1 < lengths[b]);
+        const float* yh = yhat + ((int64_t)b * Q) * T + t;
+        if (pass == 0) {
+            float l = 0.0f;
+            if (valid) {
+                float mx = -INFINITY;
+                for (int q = 0; q < Q; ++q) mx = fmaxf(mx, yh[(int64_t)q * T]);
+                float se = 0.0f;
+                for (int q = 0; q < Q; ++q) se += __expf(yh[(int64_t)q * T] - mx);
+                const int tgt = y[(int64_t)b * T + t + 1];
+                l = mx + logf(se) - yh[(int64_t)tgt * T];
+            }
+            tmp[idx] = l; my = l; cnt = (l != 0.0f) ? 1.0f : 0.0f;
+        } else {
+            bf16_t* drow = dY + idx * ldDY;
+            if (!valid) { for (int q = 0; q < ldDY; ++q) drow[q] = 0; }
+            else {
+                const float inv = 1.0f / scal[3];
+                float mx = -INFINITY;
+                for (int q = 0; q < Q; ++q) mx = fmaxf(mx, yh[(int64_t)q * T]);
+                float se = 0.0f;
+                for (int q = 0; q < Q; ++q) se += __expf(yh[(int64_t)q * T] - mx);
+                const int tgt = y[(int64_t)b * T + t + 1];
+                for (int q = 0; q < Q; ++q) drow[q] = f2bf((__expf(yh[(int64_t)q * T] - mx) / se - (q == tgt ? 1.0f : 0.0f)) * inv);
+                for (int q = Q; q < ldDY; ++q) drow[q] = 0;
+            }
+        }
+    }
+    if (pass == 0) {
+        for (int o = 32; o > 0; o >>= 1) { my += __shfl_down(my, o); cnt += __shfl_down(cnt, o); }
+        __shared__ float part[16];
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = my; part[8 + (threadIdx.x >> 6)] = cnt; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.0f, n = 0.0f;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { s += part[i]; n += part[8 + i]; }
+            unsafeAtomicAdd(&scal[0], s); unsafeAtomicAdd(&scal[3], n);
+        }
+    }
+}
+
+__global__ void wn_loss_finalize(float* scal, float* loss_out, int use_count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float den = use_count ? scal[3] : scal[1];
+        *loss_out = scal[0] / den;
+    }
+}
+
+int wn_loss_fwd_bwd(wn_ctx* c, float* loss_out, hipStream_t st) {
+    const int B = c->fB, T = c->fT;
+    const int64_t n = (int64_t)B * T;
+    const int ldDY = (c->O + 15) / 16 * 16;
+    hipLaunchKernelGGL(wn_loss_prep, dim3(1), dim3(64), 0, st, c->flen, B, T, c->scal);
+    if (c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE) {
+        float* tmp = c->DC;      // scratch, free at this point of the step
+        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, c->YHAT, (const int32_t*)c->fy, c->flen, c->DY, ldDY, c->scal, tmp, B, T, c->O, 0);
+        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, c->YHAT, (const int32_t*)c->fy, c->flen, c->DY, ldDY, c->scal, tmp, B, T, c->O, 1);
+        hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 1);
+    } else if (c->O == 2) {
+        hipLaunchKernelGGL(wn_gauss_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, c->YHAT, (const float*)c->fy, c->flen, c->DY, ldDY, c->scal, B, T,
+                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min_gauss, c->cfg.cdf_loss);
+        hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 0);
+    } else {
+        if (c->O / 3 > WN_MAX_MIX) WN_FAIL(c, WN_E_UNSUPPORTED, "more than %d mixture components", WN_MAX_MIX);
+        hipLaunchKernelGGL(wn_mol_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, c->YHAT, (const float*)c->fy, c->flen, c->DY, ldDY, c->scal, B, T, c->O / 3,
+                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min);
+        hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 0);
+    }
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
+// =================================================================================== optimiser
+// wavenet.py:586-613: per-tensor tf.clip_by_norm -> tf.clip_by_value -> tf.train.AdamOptimizer (epsilon-hat) -> EMA
+__device__ __forceinline__ int find_tensor(const int32_t* __restrict__ offs, int nt, int64_t i) {
+    int lo = 0, hi = nt - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (offs[mid] <= i) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ void wn_norm2_kernel(const float* __restrict__ g, const int32_t* __restrict__ offs, int nt, int64_t n, float* __restrict__ norm2) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    float s = 0.0f; int id = -1;
+    if (i < n) {
+        const float4 v = *reinterpret_cast<const float4*>(g + i);
+        s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        id = find_tensor(offs, nt, i);
+    }
+    const int id0 = __shfl(id, 0);
+    if (__all(id == id0) && id0 >= 0) {
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&norm2[id0], s);
+    } else if (id >= 0 && s != 0.0f) unsafeAtomicAdd(&norm2[id], s);
+}
+__global__ void wn_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                               float* __restrict__ ema, const int32_t* __restrict__ offs, int nt, int64_t n,
+                               const float* __restrict__ norm2, int clip, float max_norm, float max_value,
+                               float lr_t, float b1, float b2, float eps, float ema_decay) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    if (clip) {
+        const float nrm = sqrtf(norm2[find_tensor(offs, nt, i)]);
+        gi = gi * max_norm / fmaxf(nrm, max_norm);
+        gi = fminf(fmaxf(gi, -max_value), max_value);
+    }
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    const float pi = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    m[i] = mi; v[i] = vi; p[i] = pi;
+    ema[i] = ema[i] - (1.0f - ema_decay) * (ema[i] - pi);
+}
+
+int wn_optim_impl(wn_ctx* c, float* p, const float* g, float* m, float* v, float* ema, float lr, int64_t step, hipStream_t st) {
+    const wn_config& h = c->cfg;
+    const int nt = (int)c->tensors.size();
+    const int64_t n = c->n_params;
+    if (h.clip_gradients) {
+        WN_HIP(c, hipMemsetAsync(c->norm2_dev, 0, nt * 4, st));
+        hipLaunchKernelGGL(wn_norm2_kernel, dim3(cdiv(n / 4 + 1, 256)), dim3(256), 0, st, g, c->tensor_offsets_dev, nt, n, c->norm2_dev);
+    }
+    const double t = (double)(step + 1);
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)h.adam_beta2, t)) / (1.0 - pow((double)h.adam_beta1, t)));
+    hipLaunchKernelGGL(wn_adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, p, g, m, v, ema, c->tensor_offsets_dev, nt, n, c->norm2_dev,
+                       h.clip_gradients, h.gradient_max_norm, h.gradient_max_value, lr_t, h.adam_beta1, h.adam_beta2, h.adam_epsilon, h.ema_decay);
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
+// =================================================================================== mu-law codec
+// util.py:30-129.  The quantiser is evaluated through the exact float32 decision thresholds of the
+// reference's numpy float32 path (wn_mulaw_tables.h, generated by oracle/gen_mulaw_tables.py from the
+// reference's own util.py): bit-exact indices for every float32 input, independent of device log1p ULPs.
+__global__ void wn_mulaw_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float s = (v > 0.0f) ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+    y[i] = (float)((double)s * log1p(255.0 * fabs((double)v)) / 5.545177444479562);
+}
+__global__ void wn_inv_mulaw_kernel(const float* __restrict__ y, float* __restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = y[i];
+    const float s = (v > 0.0f) ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+    x[i] = (float)((double)s * (1.0 / 255.0) * (pow(256.0, fabs((double)v)) - 1.0));
+}
+__device__ __forceinline__ int mulaw_q(float v) {
+    // number of thresholds <= v  (thresholds ascending; NaN -> 0)
+    int lo = 0, hi = 255;               // answer in [0,255]
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (v >= WN_MULAW_THRESH[mid - 1]) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ void wn_mulaw_quantize_kernel(const float* __restrict__ x, int32_t* __restrict__ q, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) q[i] = mulaw_q(x[i]);
+}
+__global__ void wn_inv_mulaw_quantize_kernel(const int32_t* __restrict__ q, float* __restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int v = min(max(q[i], 0), 255); x[i] = WN_MULAW_DECODE[v]; }
+}
+__global__ void wn_argmax_kernel(const float* __restrict__ logits, int32_t* __restrict__ out, int B, int Q, int T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T) return;
+    const int b = (int)(i / T), t = (int)(i - (int64_t)b * T);
+    const float* p = logits + ((int64_t)b * Q) * T + t;
+    float best = p[0]; int bi = 0;
+    for (int q = 1; q < Q; ++q) { const float v = p[(int64_t)q * T]; if (v > best) { best = v; bi = q; } }   // first max wins (tf.argmax)
+    out[i] = bi;
+}
+
+#define EW_LAUNCH(kern, n, st, ...) do { if ((n) > 0) hipLaunchKernelGGL(kern, dim3(cdiv((n), 256)), dim3(256), 0, (hipStream_t)(st), __VA_ARGS__); \
+    hipError_t _e = hipGetLastError(); if (_e != hipSuccess) { g_create_err = hipGetErrorString(_e); return WN_E_HIP; } return WN_OK; } while (0)
+
+extern "C" int wn_mulaw(const float* x, float* y, int64_t n, void* st) { if (!x || !y || n < 0) return WN_E_ARG; EW_LAUNCH(wn_mulaw_kernel, n, st, x, y, n); }
+extern "C" int wn_inv_mulaw(const float* y, float* x, int64_t n, void* st) { if (!x || !y || n < 0) return WN_E_ARG; EW_LAUNCH(wn_inv_mulaw_kernel, n, st, y, x, n); }
+extern "C" int wn_mulaw_quantize(const float* x, int32_t* q, int64_t n, void* st) { if (!x || !q || n < 0) return WN_E_ARG; EW_LAUNCH(wn_mulaw_quantize_kernel, n, st, x, q, n); }
+extern "C" int wn_inv_mulaw_quantize(const int32_t* q, float* x, int64_t n, void* st) { if (!x || !q || n < 0) return WN_E_ARG; EW_LAUNCH(wn_inv_mulaw_quantize_kernel, n, st, q, x, n); }
+extern "C" int wn_argmax_channels(const float* l, int32_t* o, int32_t B, int32_t Q, int32_t T, void* st) {
+    if (!l || !o || B <= 0 || Q <= 0 || T <= 0) return WN_E_ARG; EW_LAUNCH(wn_argmax_kernel, (int64_t)B * T, st, l, o, B, Q, T); }
+
+// =================================================================================== samplers
+// mixture.py:76-107, gaussian.py:39-52, wavenet.py:861-867; noise [T][B][nps] supplied by the caller.
+__device__ __forceinline__ float sample_mol(const float* p, int64_t stride, int M, const float* nz, float log_scale_min) {
+    float best = -INFINITY; int bi = 0;
+    for (int i = 0; i < M; ++i) { const float v = p[(int64_t)i * stride] - logf(-logf(nz[i])); if (v > best) { best = v; bi = i; } }
+    const float mu = p[(int64_t)(M + bi) * stride];
+    const float ls = fmaxf(p[(int64_t)(2 * M + bi) * stride], log_scale_min);
+    const float u = nz[M];
+    const float x = mu + expf(ls) * (logf(u) - logf(1.0f - u));
+    return fminf(fmaxf(x, -1.0f), 1.0f);
+}
+__device__ __forceinline__ float sample_gauss(const float* p, int64_t stride, const float* nz, float lsmin) {
+    const float x = p[0] + expf(fmaxf(p[stride], lsmin)) * nz[0];
+    return fminf(fmaxf(x, -1.0f), 1.0f);
+}
+__device__ __forceinline__ int sample_cat(const float* p, int64_t stride, int Q, const float* nz) {
+    float best = -INFINITY; int bi = 0;
+    for (int q = 0; q < Q; ++q) { const float v = p[(int64_t)q * stride] - logf(-logf(nz[q])); if (v > best) { best = v; bi = q; } }
+    return bi;
+}
+__global__ void wn_sample_kernel(const float* __restrict__ yhat, const float* __restrict__ noise, void* __restrict__ out,
+                                 int B, int T, int O, int mode, int nps, float lsmin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T) return;
+    const int b = (int)(i / T), t = (int)(i - (int64_t)b * T);
+    const float* p = yhat + ((int64_t)b * O) * T + t;
+    const float* nz = noise + ((int64_t)t * B + b) * nps;
+    if (mode == 0) ((float*)out)[i] = sample_mol(p, T, O / 3, nz, lsmin);
+    else if (mode == 1) ((float*)out)[i] = sample_gauss(p, T, nz, lsmin);
+    else ((int32_t*)out)[i] = sample_cat(p, T, O, nz);
+}
+int wn_sample_impl(wn_ctx* c, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st) {
+    const int mode = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE ? 2 : (c->O == 2 ? 1 : 0);
+    const float lsmin = mode == 1 ? c->cfg.log_scale_min_gauss : c->cfg.log_scale_min;
+    hipLaunchKernelGGL(wn_sample_kernel, dim3(cdiv((int64_t)B * T, 256)), dim3(256), 0, st, y_hat, noise, out, B, T, c->O, mode, wn_noise_per_step(c), lsmin);
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}

@@ -1,0 +1,90 @@
+"""Shared helpers of the GPU parity tests: hparams builders, oracle <-> engine parameter transfer, and the
+numpy mirror of the device dropout-mask hash (csrc/wn_common.h: wn_mix32 / wn_drop_word / wn_layer_key)."""
+import numpy as np
+import torch
+
+import hparams as hparams_mod
+from oracle import wavenet_oracle as O
+
+
+def make_hp(**kw):
+    hp = hparams_mod._build()
+    for k, v in kw.items():
+        hp.set_hparam(k, v)
+    return hp
+
+
+SMALL = dict(layers=4, stacks=2, residual_channels=64, gate_channels=128, skip_out_channels=64, cin_channels=16,
+             num_mels=16, upsample_type='2D', upsample_scales=[4, 4], hop_size=16, out_channels=30,
+             input_type='raw', quantize_channels=65536, legacy=False, residual_legacy=False, wavenet_dropout=0.0,
+             log_scale_min=float(np.log(1e-14)), NN_scaler=0.3)
+
+
+def oracle_cfg(hp):
+    return O.OracleConfig.from_hparams(hp)
+
+
+def upload_params(engine, params):
+    """oracle name->tensor dict -> flat fp32 CUDA buffer in the engine's layout."""
+    flat = torch.zeros(engine.n_params, dtype=torch.float32)
+    for name, (shape, off) in engine.layout.items():
+        t = params[name]
+        assert tuple(t.shape) == tuple(shape), (name, t.shape, shape)
+        flat[off:off + t.numel()] = t.reshape(-1)
+    return flat.cuda()
+
+
+def download_grads(engine, flat):
+    flat = flat.cpu()
+    return {name: flat[off:off + int(np.prod(shape))].view(*shape).clone() for name, (shape, off) in engine.layout.items()}
+
+
+# ---- dropout mask mirror ---------------------------------------------------------------------
+def _mix32(x):
+    x = x.astype(np.uint64) & 0xffffffff
+    x ^= x >> 16; x = (x * 0x85ebca6b) & 0xffffffff
+    x ^= x >> 13; x = (x * 0xc2b2ae35) & 0xffffffff
+    x ^= x >> 16
+    return x
+
+
+def layer_key(seed, layer):
+    k = (seed * 0x9E3779B97F4A7C15 + (layer + 1) * 0xD1B54A32D192ED03) & 0xffffffffffffffff
+    k ^= k >> 29
+    return k & 0xffffffff, (k >> 32) & 0xffffffff
+
+
+def dropout_mask(seed, layer, rows, R, p):
+    """{0,1} float mask [rows, R] identical to the device's (element e = row*R + r)."""
+    lo, hi = layer_key(seed, layer)
+    e = np.arange(rows * R, dtype=np.uint64)
+    w = _mix32((_mix32((e >> 1) ^ lo) + hi) & 0xffffffff)
+    bits = np.where((e & 1) == 1, w >> 16, w & 0xffff)
+    thresh = int(np.rint(np.float32(p) * np.float32(65536.0)))
+    return (bits >= thresh).astype(np.float32).reshape(rows, R)
+
+
+def oracle_masks(seed, cfg, B, T):
+    """per-layer masks in the oracle's [B, R, T] layout."""
+    out = []
+    for l in range(cfg.layers):
+        m = dropout_mask(seed, l, B * T, cfg.residual_channels, cfg.wavenet_dropout)
+        out.append(torch.from_numpy(m).view(B, T, cfg.residual_channels).permute(0, 2, 1).contiguous())
+    return out
+
+
+def rel_err(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def synth_batch(cfg, B, T, seed=0):
+    """LJSpeech-shaped synthetic tensors as the feeder emits them (feeder.py:266-340)."""
+    g = torch.Generator().manual_seed(seed)
+    Tc = T // cfg.hop
+    t = torch.arange(T).float()
+    f = torch.rand(B, 1, generator=g) * 320 + 80
+    wav = 0.3 * torch.sin(2 * np.pi * f * t[None] / 22050.0) + 0.1 * torch.randn(B, T, generator=g)
+    wav = wav.clamp(-0.999, 0.999)
+    c = torch.rand(B, cfg.cin_channels, Tc, generator=g)
+    return wav, c

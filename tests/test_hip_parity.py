@@ -1,0 +1,256 @@
+"""HIP path vs oracle on identical seeded inputs (run on the GPU box: pytest -m gpu).
+
+Tolerances (stated per SURVEY.md 8c):
+  * vs the bf16-emulating oracle (same rounding points, fp32 contraction): activations rel-L2 <= 2e-2,
+    loss rtol 5e-3  -- checks kernel LOGIC tightly;
+  * vs the pure fp32 oracle (the reference arithmetic): loss rtol 2e-2, y_hat rel-L2 <= 5e-2 -- the
+    documented price of bf16 MFMA operands;
+  * gradients vs autograd of the emulating oracle: per-tensor rel-L2 <= 6e-2 (bf16 backward signals);
+  * integer outputs (mu-law indices, argmax, categorical samples given identical logits+noise): bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hip_util import (SMALL, download_grads, make_hp, oracle_cfg, oracle_masks, rel_err, synth_batch, upload_params)
+from oracle import mulaw as M
+from oracle import wavenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(hp, B, T):
+    from wavenet_vocoder import _ext
+    return _ext.Engine(hp, B, T)
+
+
+def _inputs(cfg, hp, B, T, seed=0):
+    wav, c = synth_batch(cfg, B, T, seed)
+    if hp.input_type == 'mulaw-quantize':
+        ids = torch.from_numpy(M.mulaw_quantize(wav.numpy())).int()
+        x_dev, y_dev = ids.cuda(), ids.cuda()
+        x_or = torch.nn.functional.one_hot(ids.long(), 256).float().permute(0, 2, 1).contiguous()
+        y_or = ids.long()
+    else:
+        if hp.input_type == 'mulaw':
+            wav = torch.from_numpy(M.mulaw(wav.numpy())).float()
+        x_dev, y_dev = wav.view(B, 1, T).contiguous().cuda(), wav.view(B, T, 1).contiguous().cuda()
+        x_or, y_or = wav.view(B, 1, T), wav.view(B, T, 1)
+    return x_dev, y_dev, x_or, y_or, c
+
+
+CONFIGS = {
+    'mol_2d': dict(),
+    'mol_2d_legacy_drop': dict(legacy=True, residual_legacy=True, wavenet_dropout=0.05),
+    'gauss_subpixel': dict(out_channels=2, upsample_type='SubPixel', legacy=True, residual_legacy=True,
+                           log_scale_min_gauss=float(np.log(1e-7))),
+    'gauss_cdf_nn': dict(out_channels=2, upsample_type='NearestNeighbor', cdf_loss=True,
+                         log_scale_min_gauss=float(np.log(9.1188196e-4))),
+    'softmax_c1': dict(input_type='mulaw-quantize', out_channels=256, quantize_channels=256, layers=8, stacks=1,
+                       upsample_activation='LeakyRelu'),
+    'wide': dict(residual_channels=128, gate_channels=256, skip_out_channels=128, cin_channels=80, num_mels=80,
+                 layers=6, stacks=2),
+}
+
+
+def _run_fwd(name, B=2, T=400, lengths=None, with_bwd=False):
+    kw = dict(SMALL); kw.update(CONFIGS[name])
+    hp = make_hp(**kw)
+    cfg = oracle_cfg(hp)
+    T = (T // cfg.hop) * cfg.hop
+    eng = _engine(hp, B, T)
+    params = O.init_params(cfg, seed=5339, bias_scale=0.05)
+    # non-NN-init upsample kernels so that the frequency taps are exercised
+    g = torch.Generator().manual_seed(7)
+    for k in params:
+        if k.startswith('local_conditioning') and k.endswith('kernel'):
+            params[k] = params[k] + 0.05 * torch.randn(params[k].shape, generator=g)
+    flat = upload_params(eng, params)
+    eng.pack_weights(flat)
+    x_dev, y_dev, x_or, y_or, c = _inputs(cfg, hp, B, T)
+    lengths = lengths or [T] * B
+    len_dev = torch.tensor(lengths, dtype=torch.int32).cuda()
+    loss_dev = torch.zeros(1, device='cuda')
+    yhat_dev = torch.empty(B, cfg.out_channels, T, device='cuda')
+    seed = 1234
+    eng.train_fwd(x_dev, c.cuda(), y_dev, len_dev, seed, loss_dev, yhat_dev)
+    torch.cuda.synchronize()
+    masks = oracle_masks(seed, cfg, B, T) if cfg.wavenet_dropout > 0 else None
+    return dict(hp=hp, cfg=cfg, eng=eng, params=params, flat=flat, x_or=x_or, y_or=y_or, c=c, lengths=lengths,
+                loss_dev=loss_dev, yhat_dev=yhat_dev, masks=masks, B=B, T=T, seed=seed)
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_train_forward(name):
+    r = _run_fwd(name)
+    cfg, eng, B, T = r['cfg'], r['eng'], r['B'], r['T']
+    y_em, aux = O.step(r['params'], cfg, r['x_or'], r['c'], dropout_masks=r['masks'], emulate_bf16=True, return_aux=True)
+    y_fp = O.step(r['params'], cfg, r['x_or'], r['c'], dropout_masks=r['masks'])
+    rows = B * T
+    rep = []
+    cup = eng.debug_copy('CUP', eng.cfg.n_upsample - 1 if cfg.upsample_type != 'NearestNeighbor' else 0, B * cfg.cin_channels, T).cpu()
+    rep.append(('c_up', rel_err(cup.view(B, cfg.cin_channels, T), aux['c_up'])))
+    for l in range(cfg.layers):
+        X = eng.debug_copy('X', l, rows, cfg.residual_channels).cpu().view(B, T, -1).permute(0, 2, 1)
+        rep.append(('X%d' % l, rel_err(X, aux['layer_in'][l])))
+        U = eng.debug_copy('U', l, rows, cfg.gate_channels // 2).cpu().view(B, T, -1).permute(0, 2, 1)
+        rep.append(('U%d' % l, rel_err(U, aux['u'][l])))
+    yh = r['yhat_dev'].cpu()
+    rep.append(('y_hat(emul)', rel_err(yh, y_em)))
+    rep.append(('y_hat(fp32)', rel_err(yh, y_fp)))
+    loss_em = float(O.training_loss(cfg, y_em, r['y_or'], r['lengths']))
+    loss_fp = float(O.training_loss(cfg, y_fp, r['y_or'], r['lengths']))
+    loss_same = float(O.training_loss(cfg, yh, r['y_or'], r['lengths']))      # oracle loss on the device's own y_hat
+    ld = float(r['loss_dev'].item())
+    print('\n[%s] ' % name + '  '.join('%s=%.2e' % kv for kv in rep))
+    print('[%s] loss dev=%.6f oracle(dev y_hat)=%.6f emul=%.6f fp32=%.6f' % (name, ld, loss_same, loss_em, loss_fp))
+    assert np.isfinite(ld)
+    for k, v in rep[:-1]:
+        assert v < 2e-2, (k, v)
+    assert rep[-1][1] < 5e-2
+    assert abs(ld - loss_same) <= 2e-4 * max(1.0, abs(loss_same)), 'loss kernel vs oracle on identical y_hat'
+    assert abs(ld - loss_em) <= 5e-3 * max(1.0, abs(loss_em))
+    assert abs(ld - loss_fp) <= 2e-2 * max(1.0, abs(loss_fp))
+
+
+def test_ragged_lengths_and_tail_tile():
+    # T not a multiple of the 128-row tile, lengths shorter than T (mask), B=3
+    r = _run_fwd('mol_2d', B=3, T=336, lengths=[336, 200, 17])
+    cfg = r['cfg']
+    y_em = O.step(r['params'], cfg, r['x_or'], r['c'], emulate_bf16=True)
+    assert rel_err(r['yhat_dev'].cpu(), y_em) < 2e-2
+    loss_same = float(O.training_loss(cfg, r['yhat_dev'].cpu(), r['y_or'], r['lengths']))
+    assert abs(float(r['loss_dev'].item()) - loss_same) <= 2e-4 * max(1.0, abs(loss_same))
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_train_backward(name):
+    r = _run_fwd(name)
+    cfg, eng, B, T = r['cfg'], r['eng'], r['B'], r['T']
+    grads_dev = torch.empty(eng.n_params, device='cuda')
+    eng.train_bwd(grads_dev)
+    torch.cuda.synchronize()
+    g_dev = download_grads(eng, grads_dev)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in r['params'].items()}
+    y = O.step(leaf, cfg, r['x_or'], r['c'], dropout_masks=r['masks'], emulate_bf16=True)
+    loss = O.training_loss(cfg, y, r['y_or'], r['lengths'])
+    gs = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
+    g_or = {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(leaf, gs)}
+    worst = []
+    for k in g_or:
+        n_or = float(g_or[k].norm())
+        err = float((g_dev[k] - g_or[k]).norm())
+        worst.append((err / (n_or + 1e-12) if n_or > 1e-9 else err, k, n_or))
+    worst.sort(reverse=True)
+    print('\n[%s] worst gradient errors:' % name)
+    for e, k, n in worst[:12]:
+        print('   %-70s rel=%.3e |g|=%.3e' % (k, e, n))
+    total = torch.cat([g_dev[k].flatten() for k in g_or]), torch.cat([g_or[k].flatten() for k in g_or])
+    print('[%s] global grad rel err %.3e' % (name, rel_err(*total)))
+    assert rel_err(*total) < 4e-2
+    for e, k, n in worst:
+        assert e < 8e-2, (k, e, n)
+
+
+def test_optimizer_step_matches_tf_adam():
+    r = _run_fwd('mol_2d')
+    eng = r['eng']
+    n = eng.n_params
+    g = torch.Generator().manual_seed(3)
+    grads = (torch.randn(n, generator=g) * 0.5)
+    # one tensor with a huge norm (norm clip) and some huge values (value clip)
+    k0, (sh0, off0) = list(eng.layout.items())[2]
+    grads[off0:off0 + int(np.prod(sh0))] *= 400.0
+    p0 = r['flat'].cpu().clone()
+    m0, v0 = torch.rand(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.01
+    e0 = p0.clone()
+    p, m, v, e, gd = p0.cuda(), m0.cuda(), v0.cuda(), e0.cuda(), grads.cuda()
+    step, lr = 41, 7.5e-4
+    eng.optim_step(p, gd, m, v, e, lr, step)
+    torch.cuda.synchronize()
+    for name, (shape, off) in eng.layout.items():
+        sl = slice(off, off + int(np.prod(shape)))
+        gc = O.clip_gradient(grads[sl])
+        pn, mn, vn, en = O.adam_ema_update(p0[sl], gc, m0[sl], v0[sl], e0[sl], step + 1, lr)
+        assert torch.allclose(p.cpu()[sl], pn, rtol=1e-5, atol=1e-7), name
+        assert torch.allclose(m.cpu()[sl], mn, rtol=1e-5, atol=1e-8), name
+        assert torch.allclose(v.cpu()[sl], vn, rtol=1e-5, atol=1e-9), name
+        assert torch.allclose(e.cpu()[sl], en, rtol=1e-5, atol=1e-7), name
+
+
+def test_mulaw_codec_bit_exact(golden_dir):
+    from wavenet_vocoder import _ext
+    g = np.load(os.path.join(golden_dir, 'mulaw_golden.npz'))
+    x = torch.from_numpy(g['x']).cuda()
+    q = _ext.mulaw_quantize(x).cpu().numpy()
+    assert np.array_equal(q, g['quantized'])                                       # bit-exact indices
+    dec = _ext.inv_mulaw_quantize(torch.arange(256, dtype=torch.int32).cuda()).cpu().numpy()
+    assert np.array_equal(dec, g['inv_q_all'].astype(np.float32))
+    np.testing.assert_allclose(_ext.mulaw(x).cpu().numpy(), g['mulaw'], rtol=0, atol=2e-7)
+    yy = torch.linspace(-1, 1, 4097).cuda()
+    np.testing.assert_allclose(_ext.inv_mulaw(yy).cpu().numpy(), g['inv_mulaw'], rtol=1e-6, atol=1e-7)
+    # 16M random + full-size property: quantiser is monotone and matches the numpy oracle exactly
+    xr = (torch.rand(1 << 24, generator=torch.Generator().manual_seed(1)) * 2 - 1)
+    qr = _ext.mulaw_quantize(xr.cuda()).cpu().numpy()
+    assert np.array_equal(qr, M.mulaw_quantize(xr.numpy()))
+
+
+def test_argmax_and_samplers_match_oracle(golden_dir):
+    from wavenet_vocoder import _ext
+    # argmax decode: bit-exact indices
+    logits = torch.randn(3, 256, 500, generator=torch.Generator().manual_seed(0))
+    idx = _ext.argmax_channels(logits.cuda()).cpu()
+    assert torch.equal(idx.long(), logits.argmax(dim=1))
+    # MoL sampler vs the reference-generated golden sample (same params + same uniforms)
+    g = np.load(os.path.join(golden_dir, 'mol_golden.npz'))
+    y_hat = torch.from_numpy(g['y_hat'])
+    B, O3, T = y_hat.shape
+    hp = make_hp(**SMALL)
+    eng = _engine(hp, B, 16 * 32)
+    noise = torch.cat([torch.from_numpy(g['u1']), torch.from_numpy(g['u2']).unsqueeze(-1)], dim=-1)   # [B,T,M+1]
+    noise = noise.permute(1, 0, 2).contiguous()                                                          # [T,B,M+1]
+    out = torch.empty(B, T, device='cuda')
+    eng.sample(y_hat.cuda(), noise.cuda(), out)
+    np.testing.assert_allclose(out.cpu().numpy(), g['sample'], rtol=0, atol=2e-5)
+    # Gaussian
+    gg = np.load(os.path.join(golden_dir, 'gaussian_golden.npz'))
+    kw = dict(SMALL); kw.update(out_channels=2, log_scale_min_gauss=float(np.log(1e-7)))
+    eng2 = _engine(make_hp(**kw), B, 16 * 32)
+    out2 = torch.empty(B, T, device='cuda')
+    eng2.sample(torch.from_numpy(gg['y_hat']).cuda(), torch.from_numpy(gg['eps']).permute(1, 0).contiguous().unsqueeze(-1).contiguous().cuda(), out2)
+    np.testing.assert_allclose(out2.cpu().numpy(), gg['sample'], rtol=0, atol=2e-5)
+    # categorical: identical logits + identical Gumbel uniforms -> identical indices
+    kw = dict(SMALL); kw.update(input_type='mulaw-quantize', out_channels=256, quantize_channels=256)
+    eng3 = _engine(make_hp(**kw), B, 16 * 32)
+    lg = torch.randn(2, 256, 64, generator=torch.Generator().manual_seed(5))
+    u = torch.rand(64, 2, 256, generator=torch.Generator().manual_seed(6)) * 0.98 + 0.01
+    out3 = torch.empty(2, 64, dtype=torch.int32, device='cuda')
+    eng3.sample(lg.cuda(), u.cuda(), out3)
+    exp = torch.stack([O.sample_categorical(lg[:, :, t], u[t]) for t in range(64)], dim=1)
+    assert torch.equal(out3.cpu().long(), exp)
+
+
+def test_error_paths():
+    from wavenet_vocoder import _ext
+    with pytest.raises(_ext.WnError) as ei:
+        _engine(make_hp(**dict(SMALL, layers=5, stacks=2)), 1, 64)
+    assert ei.value.code == -2
+    with pytest.raises(_ext.WnError):
+        _engine(make_hp(**dict(SMALL, input_type='mulaw-quantize', out_channels=30)), 1, 64)   # models/__init__.py:6-9
+    hp = make_hp(**SMALL)
+    eng = _engine(hp, 2, 64)
+    flat = upload_params(eng, O.init_params(oracle_cfg(hp)))
+    x = torch.zeros(2, 1, 64, device='cuda'); c = torch.zeros(2, 16, 4, device='cuda'); y = torch.zeros(2, 64, 1, device='cuda')
+    ln = torch.tensor([64, 64], dtype=torch.int32, device='cuda'); loss = torch.zeros(1, device='cuda')
+    with pytest.raises(_ext.WnError) as ei:          # pack first
+        eng.train_fwd(x, c, y, ln, 0, loss)
+    assert ei.value.code == -5
+    eng.pack_weights(flat)
+    with pytest.raises(_ext.WnError) as ei:          # bwd before fwd
+        eng.train_bwd(torch.zeros(eng.n_params, device='cuda'))
+    assert ei.value.code == -5
+    with pytest.raises(_ext.WnError) as ei:          # Tc*hop != T  (wavenet.py:699)
+        eng.train_fwd(x, torch.zeros(2, 16, 3, device='cuda'), y, ln, 0, loss)
+    assert ei.value.code == -2
