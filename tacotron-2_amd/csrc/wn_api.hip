@@ -79,6 +79,7 @@ static int alloc_workspace(wn_ctx* c) {
     sz(NT * c->C * 4);                     // DC
     for (int i = 0; i <= c->cfg.n_upsample; ++i) sz(NT * c->C * 4);   // CUP (generous: every level sized for full rate)
     sz(NT * c->C * 4); sz(NT * c->C * 4);  // DCUP ping-pong
+    sz(NT * 4); sz(NT * c->C * 4);          // XIN, CIN
     sz(256);                               // scalars
     c->ws_bytes = total;
     hipError_t e = hipMalloc((void**)&c->ws, total);
@@ -97,6 +98,7 @@ static int alloc_workspace(wn_ctx* c) {
     c->DC = (float*)bump(p, NT * c->C * 4);
     for (int i = 0; i <= c->cfg.n_upsample; ++i) c->CUP[i] = (float*)bump(p, NT * c->C * 4);
     c->DCUP[0] = (float*)bump(p, NT * c->C * 4); c->DCUP[1] = (float*)bump(p, NT * c->C * 4);
+    c->XIN = (void*)bump(p, NT * 4); c->CIN = (float*)bump(p, NT * c->C * 4);
     c->scal = (float*)bump(p, 256);
     return WN_OK;
 }
@@ -217,7 +219,10 @@ extern "C" int wn_train_fwd(wn_ctx* c, const void* x, const float* cc, const voi
     if (!c) return WN_E_ARG;
     int rc = check_fwd_args(c, x, cc, y, lengths, B, T, Tc);
     if (rc) return rc;
-    c->fx = x; c->fc = cc; c->fy = y; c->flen = lengths; c->fB = B; c->fT = T; c->fTc = Tc; c->fseed = seed;
+    // x and c are needed again by wn_train_bwd: keep ctx-owned copies (caller pointers are borrowed for this call only)
+    WN_HIP(c, hipMemcpyAsync(c->XIN, x, (size_t)B * T * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    WN_HIP(c, hipMemcpyAsync(c->CIN, cc, (size_t)B * c->C * Tc * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    c->fx = c->XIN; c->fc = c->CIN; c->fy = y; c->flen = lengths; c->fB = B; c->fT = T; c->fTc = Tc; c->fseed = seed;
     c->have_fwd = false;
     rc = wn_fwd_impl(c, (hipStream_t)stream, loss_out, y_hat_out);
     if (rc == WN_OK) c->have_fwd = true;

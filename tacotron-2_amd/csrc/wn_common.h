@@ -104,6 +104,7 @@ struct wn_ctx {
     int maxB, maxT; int64_t NT;
     bf16_t *cbt, *X, *TS, *U, *R1, *H2, *DY, *DPRE1, *DSKIP, *DZ, *GX0, *GX1;
     float *YHAT, *DC, *CUP[WN_MAX_UPSAMPLE + 1], *DCUP[2];
+    void* XIN; float* CIN;                // ctx-owned copies of the step's x and c (pointers are borrowed per call)
     float* scal;                          // device scalars: [0]=loss sum [1]=denominator [2]=1/denominator [3]=count
     // state of the last forward
     int fB = 0, fT = 0, fTc = 0; uint64_t fseed = 0; bool have_fwd = false; bool have_loss = false;
