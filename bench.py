@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Headline benchmark: WaveNet-vocoder TRAINING throughput (audio samples / s, whole job) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run)
+
+One "step" = the full training step of the reference (wavenet_vocoder/train.py:303) on one batch per GPU:
+pack weights -> forward (upsample net, 24 gated residual layers, head) -> masked MoL loss -> backward ->
+[RCCL all-reduce(mean) of the flat fp32 gradient over ranks, wavenet.py:560-575] -> per-tensor clip +
+TF-Adam + EMA.  Inputs are LJSpeech-shaped synthetic tensors already resident in HBM; weights are
+random-init (Glorot) of the named architecture.
+
+Workload (BASELINE.json configs[1], "C2"): paper_hparams WaveNet -- 24 layers / 2 stacks (BASELINE's
+shape; --workload c2_4stack gives paper_hparams.py's 4-stack variant), R=256 G=512 S=256, 10-component
+MoL, raw 16-bit scalar input, 80-mel local conditioning through the '2D' upsample net [5,5,11] (hop 275),
+dropout 0.05, batch 8 x 11 000 samples per GPU, bf16 MFMA operands with fp32 accumulation.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (gate GEMM `wn_gemm_tile_kernel<2,2,2,2,EPI_GATE>`, one launch per
+                  layer and step) timed live with HIP events on its launch stream inside the timed region;
+  cpu_baseline -- the oracle (CPU restatement of the reference arithmetic, torch-CPU fp32 on all host
+                  cores) running the same training step on a bounded sample of the same workload.
+A short autoregressive-synthesis measurement (RTF at 22.05 kHz) is appended under "synthesis".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tacotron-2_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (hparams overrides on top of paper_hparams, B per GPU, T)
+    'c2': (dict(stacks=2), 8, 11000),
+    'c2_4stack': (dict(), 8, 11000),
+    'default_hparams': (None, 8, 11000),          # hparams.py defaults (Gaussian, R=128, SubPixel)
+    'c5_stress': (dict(out_channels=2, residual_channels=512, gate_channels=1024, skip_out_channels=512, layers=30, stacks=3,
+                       legacy=True, residual_legacy=True, upsample_type='SubPixel', upsample_scales=[15, 20], hop_size=300,
+                       sample_rate=24000, cdf_loss=False), 8, 12000),
+}
+
+
+def build_hparams(workload):
+    import hparams as base
+    import paper_hparams as paper
+    over, B, T = WORKLOADS[workload]
+    if over is None:
+        hp = base._build()
+    else:
+        o = dict(paper.PAPER_OVERRIDES); o.update(over)
+        hp = base._build(o)
+    return hp, B, T
+
+
+def mac_per_sample(hp):
+    """MAC_fwd = Cin*R + L(k R G + C G + G/2 S + G/2 R) + S S + S O."""
+    R, G, S, O, C, L = hp.residual_channels, hp.gate_channels, hp.skip_out_channels, hp.out_channels, hp.cin_channels, hp.layers
+    cin = 1 if hp.input_type != 'mulaw-quantize' else hp.quantize_channels
+    return cin * R + L * (3 * R * G + C * G + (G // 2) * S + (G // 2) * R) + S * S + S * O
+
+
+def synthetic_batch(hp, B, T, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    hop = int(np.prod(hp.upsample_scales))
+    t = torch.arange(T).float()
+    f = torch.rand(B, 1, generator=g) * 320 + 80
+    wav = (0.3 * torch.sin(2 * np.pi * f * t[None] / hp.sample_rate) + 0.1 * torch.randn(B, T, generator=g)).clamp(-0.999, 0.999)
+    c = torch.rand(B, hp.cin_channels, T // hop, generator=g)
+    x = wav.view(B, 1, T).contiguous().to(device)
+    y = wav.view(B, T, 1).contiguous().to(device)
+    lengths = torch.full((B,), T, dtype=torch.int32, device=device)
+    return x, c.to(device), y, lengths, wav, c
+
+
+def cpu_baseline(hp, seconds_budget=20.0):
+    """Oracle training step (fwd + loss + autograd bwd + clip + TF-Adam + EMA) on a bounded sample:
+    the same architecture, batch 1 x (8 frames = 2200 samples), repeated until ~budget seconds."""
+    from oracle import wavenet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig.from_hparams(hp)
+    params = O.init_params(cfg, seed=5339)
+    state = O.init_opt_state(params)
+    B, Tc = 1, 8
+    T = Tc * cfg.hop
+    g = torch.Generator().manual_seed(0)
+    wav = (torch.rand(B, T, generator=g) * 1.6 - 0.8)
+    c = torch.rand(B, cfg.cin_channels, Tc, generator=g)
+    masks = [(torch.rand(B, cfg.residual_channels, T, generator=g) >= cfg.wavenet_dropout).float() for _ in range(cfg.layers)]
+    O.train_step(params, state, cfg, wav.view(B, 1, T), c, wav.view(B, T, 1), [T], 0, dropout_masks=masks)   # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        _, _, params, state = O.train_step(params, state, cfg, wav.view(B, 1, T), c, wav.view(B, T, 1), [T], n, dropout_masks=masks)
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 50:
+            break
+    dt = time.time() - t0
+    return {'value': B * T * n / dt, 'unit': 'audio_samples/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle train step (fwd+loss+autograd bwd+clip+TF-Adam+EMA), same architecture, batch %dx%d samples, %d steps in %.1f s, torch-CPU fp32 %d threads'
+                      % (B, T, n, dt, cores)}
+
+
+def measure_synthesis(hp, eng_params_flat, device, seconds=0.25, batches=(1, 8)):
+    """Autoregressive synthesis RTF at hp.sample_rate for `seconds` of audio per stream."""
+    from wavenet_vocoder import _ext
+    hop = int(np.prod(hp.upsample_scales))
+    Tc = max(2, int(round(seconds * hp.sample_rate / hop)))
+    T = Tc * hop
+    out = {}
+    for B in batches:
+        eng = _ext.Engine(hp, B, T)
+        eng.pack_weights(eng_params_flat)
+        nps = eng.noise_per_step
+        c = torch.rand(B, hp.cin_channels, Tc, device=device)
+        noise = (torch.rand(T, B, nps, device=device) * 0.98 + 0.01) if hp.out_channels != 2 else torch.randn(T, B, nps, device=device)
+        samples = torch.empty(B, T, device=device)
+        eng.synthesize(c, noise, samples, None, None, steps_per_graph=hp.mi355_steps_per_graph)      # warm-up + graph build
+        torch.cuda.synchronize()
+        t0 = time.time()
+        eng.synthesize(c, noise, samples, None, None, steps_per_graph=hp.mi355_steps_per_graph)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        out['B%d' % B] = {'seconds_of_audio_per_stream': T / hp.sample_rate, 'wall_s': dt,
+                          'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt,
+                          'us_per_step': dt / T * 1e6}
+        eng.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-synth', action='store_true')
+    ap.add_argument('--batch', type=int, default=None, help='override per-GPU batch (debug)')
+    ap.add_argument('--time', type=int, default=None, help='override T (debug)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=device)
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    from wavenet_vocoder import _ext
+    from wavenet_vocoder.models.modules import initialize_parameters
+    hp, B, T = build_hparams(args.workload)
+    B = args.batch or B
+    T = args.time or T
+    hop = int(np.prod(hp.upsample_scales))
+    T = T // hop * hop
+    eng = _ext.Engine(hp, B, T)
+    flat = initialize_parameters(hp, eng.layout).to(device)
+    assert flat.numel() == eng.n_params
+    if world > 1:
+        dist.broadcast(flat, 0)
+    grads = torch.zeros_like(flat)
+    m, v, ema = torch.zeros_like(flat), torch.zeros_like(flat), flat.clone()
+    loss = torch.zeros(1, device=device)
+    x, c, y, lengths, _, _ = synthetic_batch(hp, B, T, seed=5339 + rank, device=device)   # disjoint utterances per rank
+
+    def one_step(i):
+        eng.pack_weights(flat)
+        eng.train_fwd(x, c, y, lengths, 1000 + i, loss)
+        eng.train_bwd(grads)
+        if world > 1:
+            dist.all_reduce(grads, op=dist.ReduceOp.SUM)
+            grads.mul_(1.0 / world)
+        lr = _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, i, hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
+        eng.optim_step(flat, grads, m, v, ema, lr, i)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.profile(True)
+    t0 = time.time()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    prof_ms, prof_n = eng.profile_result()
+    eng.profile(False)
+    final_loss = float(loss.item())
+    if world > 1:
+        tmax = torch.tensor([dt], device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        samples = world * B * T * args.steps
+        value = samples / dt
+        mac = mac_per_sample(hp)
+        # dominant kernel: gate GEMM.  Algorithmic flops per launch = 2 * G * (3R + C) * B*T  (SURVEY 8d per-sample x units/launch)
+        R, G, C = hp.residual_channels, hp.gate_channels, hp.cin_channels
+        flops_launch = 2.0 * G * (3 * R + C) * B * T
+        avg_s = (prof_ms / max(prof_n, 1)) * 1e-3
+        achieved = flops_launch / avg_s / 1e12 if prof_n else None
+        peak = 2500.0
+        res = {
+            'metric': 'wavenet_train_audio_samples_per_sec', 'value': value, 'unit': 'audio_samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'C2 paper_hparams WaveNet 24L/%d-stack R256 G512 S256 10-MoL raw16, 2D upsample [5,5,11], B=%d x T=%d per GPU, dropout %.2f'
+                                   % (hp.stacks, B, T, hp.wavenet_dropout) if args.workload.startswith('c2') else args.workload,
+                       'workload_key': args.workload, 'global_batch': world * B, 'seq_len': T, 'parallelism': 'dp%d' % world,
+                       'layers': hp.layers, 'stacks': hp.stacks, 'params': int(eng.n_params)},
+            'samples_per_sec_per_gpu': value / world,
+            'train_tflops_algorithmic': 6.0 * mac * value / 1e12,
+            'final_loss': final_loss,
+            'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_tile_kernel<2,2,2,2,EPI_GATE> (dilated conv + cond GEMM + gate, fwd)',
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
+                         'traffic': None, 'launches_timed': int(prof_n), 'avg_launch_ms': avg_s * 1e3 if prof_n else None,
+                         'alg_flops_per_launch': flops_launch},
+        }
+        if not args.no_synth:
+            try:
+                res['synthesis'] = measure_synthesis(hp, flat, device)
+            except Exception as e:          # never lose the training number to a synthesis problem
+                res['synthesis'] = {'error': str(e)[:300]}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(hp)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -117,6 +117,12 @@ int wn_train_fwd(wn_ctx* ctx, const void* x, const float* c, const void* y, cons
  * Replaces optimizer.compute_gradients (wavenet.py:557). */
 int wn_train_bwd(wn_ctx* ctx, float* grads, void* stream);
 
+/* Stand-alone masked loss on [B,O,T] network outputs.  shift = 1: training alignment (prediction t vs sample
+ * t+1, wavenet.py:488-495); shift = 0: evaluation of the incremental loop's raw outputs (wavenet.py:497-506).
+ * Invalidates the saved backward state of the last wn_train_fwd. */
+int wn_loss(wn_ctx* ctx, const float* y_hat, const void* y, const int32_t* lengths, int32_t B, int32_t T,
+            int32_t shift, float* loss_out, void* stream);
+
 /* Optional access to activations of the last forward (wavenet.py:702 upsampled_local_features):
  * float [B, cin, T]. */
 int wn_get_upsampled_features(wn_ctx* ctx, float* out, void* stream);
@@ -161,6 +167,10 @@ int wn_debug_copy(wn_ctx* ctx, const char* name, int32_t layer, float* out, int6
 
 /* ---- introspection for bench / profiling ----------------------------------------------------- */
 int64_t wn_workspace_bytes(const wn_ctx* ctx);
+/* live HIP-event timing of the dominant training kernel (the gate GEMM, one launch per layer and step),
+ * recorded on the launch stream between wn_profile(ctx,1) and wn_profile_result (which synchronises). */
+int wn_profile(wn_ctx* ctx, int32_t enable);
+int wn_profile_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
 /* name of the kernel that dominates training time + its algorithmic bytes/flops per audio sample */
 const char* wn_dominant_kernel_name(void);
 

@@ -574,11 +574,16 @@ def clip_gradient(g, max_norm=100.0, max_value=5.0):
 def adam_ema_update(p, g, m, v, ema, step, lr, beta1=0.9, beta2=0.999, eps=1e-6, ema_decay=0.9999):
     """TF-1 AdamOptimizer (epsilon-hat form) + ExponentialMovingAverage.apply, wavenet.py:549,
     :601-613.  ``step`` is the 1-based update count t.  Returns new (p, m, v, ema)."""
+    # TF's ApplyAdam / assign_moving_average kernels work on float32 hyper-parameter tensors: the
+    # (1 - beta) factors are float32 subtractions (1 - 0.999f != 0.001)
+    f32 = np.float32
+    b1, b2, dec = f32(beta1), f32(beta2), f32(ema_decay)
+    one_m_b1, one_m_b2, one_m_dec = float(f32(1) - b1), float(f32(1) - b2), float(f32(1) - dec)
     lr_t = lr * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
-    m = beta1 * m + (1 - beta1) * g
-    v = beta2 * v + (1 - beta2) * g * g
+    m = float(b1) * m + one_m_b1 * g
+    v = float(b2) * v + one_m_b2 * g * g
     p = p - lr_t * m / (torch.sqrt(v) + eps)
-    ema = ema - (1 - ema_decay) * (ema - p)
+    ema = ema - one_m_dec * (ema - p)
     return p, m, v, ema
 
 

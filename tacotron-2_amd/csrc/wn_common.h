@@ -109,6 +109,8 @@ struct wn_ctx {
     // state of the last forward
     int fB = 0, fT = 0, fTc = 0; uint64_t fseed = 0; bool have_fwd = false; bool have_loss = false;
     const void* fx = nullptr; const void* fy = nullptr; const int32_t* flen = nullptr; const float* fc = nullptr;
+    // live profiling of the dominant kernel (bench.py roofline): event pairs around every gate-GEMM launch
+    bool prof = false; std::vector<hipEvent_t> pev; size_t pev_used = 0;
     // synthesis state (lazy)
     struct Synth* synth = nullptr;
 };

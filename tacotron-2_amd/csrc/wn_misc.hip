@@ -381,10 +381,10 @@ __device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.0f) + lo
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // scal[0] = loss accumulator, [1] = denominator, [2] = 1/denominator, [3] = non-zero count (CE)
-__global__ void wn_loss_prep(const int32_t* __restrict__ lengths, int B, int T, float* scal) {
+__global__ void wn_loss_prep(const int32_t* __restrict__ lengths, int B, int T, float* scal, int shift) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float d = 0.0f;
-        for (int b = 0; b < B; ++b) { int l = min(lengths[b], T); d += (float)max(l - 1, 0); }   // sum(mask[:,1:]) wavenet.py:632-638
+        for (int b = 0; b < B; ++b) { int l = min(lengths[b], T); d += (float)max(l - shift, 0); }   // sum(mask[:,1:]) wavenet.py:632-638
         scal[0] = 0.0f; scal[1] = d; scal[2] = d > 0.0f ? 1.0f / d : 0.0f; scal[3] = 0.0f;
     }
 }
@@ -394,18 +394,18 @@ __global__ void wn_loss_prep(const int32_t* __restrict__ lengths, int B, int T, 
 // one thread per (b, t): prediction at t scored against y[t+1] (wavenet.py:494-495).
 __global__ void wn_mol_loss(const float* __restrict__ yhat, const float* __restrict__ y, const int32_t* __restrict__ lengths,
                             bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, int B, int T, int M,
-                            float num_classes, float log_scale_min) {
+                            float num_classes, float log_scale_min, int shift) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float my = 0.0f;
     if (idx < (int64_t)B * T) {
         const int b = (int)(idx / T), t = (int)(idx - (int64_t)b * T);
-        const bool valid = (t + 1 < T) && (t + 1 < lengths[b]);
+        const bool valid = (t + shift < T) && (t + shift < lengths[b]);
         bf16_t* drow = dY + idx * ldDY;
         if (!valid) {
             for (int o = 0; o < ldDY; ++o) drow[o] = 0;
         } else {
             const float inv_den = scal[2];
-            const float yv = y[(int64_t)b * T + t + 1];
+            const float yv = y[(int64_t)b * T + t + shift];
             const float* yh = yhat + ((int64_t)b * 3 * M) * T + t;
             float logit[WN_MAX_MIX], lp[WN_MAX_MIX], dmu[WN_MAX_MIX], dls[WN_MAX_MIX];
             const float D = 1.0f / (num_classes - 1.0f);
@@ -475,17 +475,17 @@ __device__ __forceinline__ float ndtrf_(float x) {      // TF special_math._ndtr
 // Gaussian MLE, gaussian.py:5-37 + modules.py:819-836, with its gradient.
 __global__ void wn_gauss_loss(const float* __restrict__ yhat, const float* __restrict__ y, const int32_t* __restrict__ lengths,
                               bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, int B, int T,
-                              float num_classes, float log_scale_min, int use_cdf) {
+                              float num_classes, float log_scale_min, int use_cdf, int shift) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float my = 0.0f;
     if (idx < (int64_t)B * T) {
         const int b = (int)(idx / T), t = (int)(idx - (int64_t)b * T);
-        const bool valid = (t + 1 < T) && (t + 1 < lengths[b]);
+        const bool valid = (t + shift < T) && (t + shift < lengths[b]);
         bf16_t* drow = dY + idx * ldDY;
         float g0 = 0.0f, g1 = 0.0f;
         if (valid) {
             const float inv_den = scal[2];
-            const float yv = y[(int64_t)b * T + t + 1];
+            const float yv = y[(int64_t)b * T + t + shift];
             const float mu = yhat[((int64_t)b * 2) * T + t], lsr = yhat[((int64_t)b * 2 + 1) * T + t];
             const float ls = fmaxf(lsr, log_scale_min);
             float gm, gs, loss;
@@ -523,12 +523,12 @@ __global__ void wn_gauss_loss(const float* __restrict__ yhat, const float* __res
 // pass 0: per-element loss into `tmp`, sum and non-zero count; pass 1: gradients (needs the count).
 __global__ void wn_ce_loss(const float* __restrict__ yhat, const int32_t* __restrict__ y, const int32_t* __restrict__ lengths,
                            bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, float* __restrict__ tmp,
-                           int B, int T, int Q, int pass) {
+                           int B, int T, int Q, int pass, int shift) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float my = 0.0f, cnt = 0.0f;
     if (idx < (int64_t)B * T) {
         const int b = (int)(idx / T), t = (int)(idx - (int64_t)b * T);
-        const bool valid = (t + 1 < T) && (t + 1 < lengths[b]);
+        const bool valid = (t + shift < T) && (t + shift < lengths[b]);
         const float* yh = yhat + ((int64_t)b * Q) * T + t;
         if (pass == 0) {
             float l = 0.0f;
@@ -537,7 +537,7 @@ __global__ void wn_ce_loss(const float* __restrict__ yhat, const int32_t* __rest
                 for (int q = 0; q < Q; ++q) mx = fmaxf(mx, yh[(int64_t)q * T]);
                 float se = 0.0f;
                 for (int q = 0; q < Q; ++q) se += __expf(yh[(int64_t)q * T] - mx);
-                const int tgt = y[(int64_t)b * T + t + 1];
+                const int tgt = y[(int64_t)b * T + t + shift];
                 l = mx + logf(se) - yh[(int64_t)tgt * T];
             }
             tmp[idx] = l; my = l; cnt = (l != 0.0f) ? 1.0f : 0.0f;
@@ -550,7 +550,7 @@ __global__ void wn_ce_loss(const float* __restrict__ yhat, const int32_t* __rest
                 for (int q = 0; q < Q; ++q) mx = fmaxf(mx, yh[(int64_t)q * T]);
                 float se = 0.0f;
                 for (int q = 0; q < Q; ++q) se += __expf(yh[(int64_t)q * T] - mx);
-                const int tgt = y[(int64_t)b * T + t + 1];
+                const int tgt = y[(int64_t)b * T + t + shift];
                 for (int q = 0; q < Q; ++q) drow[q] = f2bf((__expf(yh[(int64_t)q * T] - mx) / se - (q == tgt ? 1.0f : 0.0f)) * inv);
                 for (int q = Q; q < ldDY; ++q) drow[q] = 0;
             }
@@ -576,28 +576,39 @@ __global__ void wn_loss_finalize(float* scal, float* loss_out, int use_count) {
     }
 }
 
-int wn_loss_fwd_bwd(wn_ctx* c, float* loss_out, hipStream_t st) {
-    const int B = c->fB, T = c->fT;
+// shift = 1: training (prediction at t scored against sample t+1, wavenet.py:488-495);
+// shift = 0: evaluation of the incremental loop's raw outputs (wavenet.py:497-506).
+int wn_loss_run(wn_ctx* c, const float* yhat, const void* y, const int32_t* lengths, int B, int T, int shift, float* loss_out, hipStream_t st) {
     const int64_t n = (int64_t)B * T;
+    if (n > c->NT) WN_FAIL(c, WN_E_SHAPE, "loss: B*T exceeds the workspace");
     const int ldDY = (c->O + 15) / 16 * 16;
-    hipLaunchKernelGGL(wn_loss_prep, dim3(1), dim3(64), 0, st, c->flen, B, T, c->scal);
+    hipLaunchKernelGGL(wn_loss_prep, dim3(1), dim3(64), 0, st, lengths, B, T, c->scal, shift);
     if (c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE) {
         float* tmp = c->DC;      // scratch, free at this point of the step
-        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, c->YHAT, (const int32_t*)c->fy, c->flen, c->DY, ldDY, c->scal, tmp, B, T, c->O, 0);
-        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, c->YHAT, (const int32_t*)c->fy, c->flen, c->DY, ldDY, c->scal, tmp, B, T, c->O, 1);
+        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const int32_t*)y, lengths, c->DY, ldDY, c->scal, tmp, B, T, c->O, 0, shift);
+        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const int32_t*)y, lengths, c->DY, ldDY, c->scal, tmp, B, T, c->O, 1, shift);
         hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 1);
     } else if (c->O == 2) {
-        hipLaunchKernelGGL(wn_gauss_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, c->YHAT, (const float*)c->fy, c->flen, c->DY, ldDY, c->scal, B, T,
-                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min_gauss, c->cfg.cdf_loss);
+        hipLaunchKernelGGL(wn_gauss_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const float*)y, lengths, c->DY, ldDY, c->scal, B, T,
+                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min_gauss, c->cfg.cdf_loss, shift);
         hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 0);
     } else {
         if (c->O / 3 > WN_MAX_MIX) WN_FAIL(c, WN_E_UNSUPPORTED, "more than %d mixture components", WN_MAX_MIX);
-        hipLaunchKernelGGL(wn_mol_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, c->YHAT, (const float*)c->fy, c->flen, c->DY, ldDY, c->scal, B, T, c->O / 3,
-                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min);
+        hipLaunchKernelGGL(wn_mol_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const float*)y, lengths, c->DY, ldDY, c->scal, B, T, c->O / 3,
+                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min, shift);
         hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 0);
     }
     WN_LAUNCH_CHECK(c);
     return WN_OK;
+}
+int wn_loss_fwd_bwd(wn_ctx* c, float* loss_out, hipStream_t st) {
+    return wn_loss_run(c, c->YHAT, c->fy, c->flen, c->fB, c->fT, 1, loss_out, st);
+}
+extern "C" int wn_loss(wn_ctx* c, const float* y_hat, const void* y, const int32_t* lengths, int32_t B, int32_t T, int32_t shift, float* loss_out, void* stream) {
+    if (!c || !y_hat || !y || !lengths || !loss_out) return WN_E_ARG;
+    if (shift != 0 && shift != 1) WN_FAIL(c, WN_E_ARG, "shift must be 0 or 1");
+    c->have_loss = false;      // DY is overwritten
+    return wn_loss_run(c, y_hat, y, lengths, B, T, shift, loss_out, (hipStream_t)stream);
 }
 
 // =================================================================================== optimiser

@@ -20,6 +20,8 @@ struct Synth {
     bf16_t* h2 = nullptr;          // [32][S]
     float* yraw = nullptr;         // [32][OP]
     int32_t* t_dev = nullptr;
+    hipStream_t priv = nullptr;    // capture / replay happens on a ctx-owned stream (the caller's may be the legacy
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // NULL stream, which cannot be captured); ordered by events
     bf16_t** ring_tab = nullptr;   // device table of ring pointers
     hipGraphExec_t gexec = nullptr; int g_steps = 0; int g_B = 0; const void* g_key[5] = {0, 0, 0, 0, 0}; int g_T = 0;
 };
@@ -250,6 +252,7 @@ void wn_synth_free(wn_ctx* c) {
     if (s->ucur) hipFree(s->ucur); if (s->skip_acc) hipFree(s->skip_acc); if (s->h2) hipFree(s->h2);
     if (s->yraw) hipFree(s->yraw); if (s->t_dev) hipFree(s->t_dev);
     if (s->gexec) hipGraphExecDestroy(s->gexec);
+    if (s->ev0) hipEventDestroy(s->ev0); if (s->ev1) hipEventDestroy(s->ev1); if (s->priv) hipStreamDestroy(s->priv);
     delete s; c->synth = nullptr;
 }
 
@@ -274,7 +277,7 @@ static int enqueue_step(wn_ctx* c, Synth* s, const float* noise, const void* tes
 }
 
 int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise, uint64_t, const void* test_inputs,
-                  void* out_samples, float* out_raw, int steps_per_graph, hipStream_t st) {
+                  void* out_samples, float* out_raw, int steps_per_graph, hipStream_t caller_st) {
     const int T = Tc * c->hop;
     if ((int64_t)B * T > c->NT) WN_FAIL(c, WN_E_SHAPE, "synthesis B*T = %d*%d exceeds the workspace (max_batch*max_time = %lld)", B, T, (long long)c->NT);
     const int L = c->L, R = c->R;
@@ -292,7 +295,14 @@ int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise
         WN_HIP(c, hipMalloc((void**)&s->h2, 32 * c->S * 2));
         WN_HIP(c, hipMalloc((void**)&s->yraw, 32 * c->OP * 4));
         WN_HIP(c, hipMalloc((void**)&s->t_dev, 4));
+        WN_HIP(c, hipStreamCreateWithFlags(&s->priv, hipStreamNonBlocking));
+        WN_HIP(c, hipEventCreateWithFlags(&s->ev0, hipEventDisableTiming));
+        WN_HIP(c, hipEventCreateWithFlags(&s->ev1, hipEventDisableTiming));
     }
+    // everything below runs on the ctx-owned stream, ordered after the caller's stream and before its next op
+    hipStream_t st = s->priv;
+    WN_HIP(c, hipEventRecord(s->ev0, caller_st));
+    WN_HIP(c, hipStreamWaitEvent(st, s->ev0, 0));
     s->B = B; s->T = T;
     c->fB = B; c->fT = T; c->fTc = Tc;
     // upsample the conditioning once for the whole utterance (wavenet.py:781-803); cbt[b*T+t][C]
@@ -324,5 +334,7 @@ int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise
         for (; done + steps_per_graph <= T; done += steps_per_graph) WN_HIP(c, hipGraphLaunch(s->gexec, st));
     }
     for (; done < T; ++done) { rc = enqueue_step(c, s, noise, test_inputs, out_samples, out_raw, st); if (rc) return rc; }
+    WN_HIP(c, hipEventRecord(s->ev1, st));
+    WN_HIP(c, hipStreamWaitEvent(caller_st, s->ev1, 0));
     return WN_OK;
 }

@@ -195,6 +195,25 @@ static SrcSeg seg(const bf16_t* base, int ld, int col0, int nk, int shift, int d
     SrcSeg s; s.base = base; s.ld = ld; s.col0 = col0; s.nk = nk; s.shift = shift; s.dropout = drop; return s;
 }
 
+static void prof_mark(wn_ctx* c, hipStream_t st) {
+    if (c->pev_used == c->pev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->pev.push_back(e); }
+    (void)hipEventRecord(c->pev[c->pev_used++], st);
+}
+extern "C" int wn_profile(wn_ctx* c, int32_t enable) { if (!c) return WN_E_ARG; c->prof = enable != 0; c->pev_used = 0; return WN_OK; }
+// total milliseconds and number of launches of the dominant kernel (gate GEMM) since wn_profile(ctx, 1); synchronises.
+extern "C" int wn_profile_result(wn_ctx* c, double* total_ms, int64_t* launches) {
+    if (!c || !total_ms || !launches) return WN_E_ARG;
+    double tot = 0.0; int64_t n = 0;
+    for (size_t i = 0; i + 1 < c->pev_used; i += 2) {
+        float ms = 0.0f;
+        WN_HIP(c, hipEventSynchronize(c->pev[i + 1]));
+        WN_HIP(c, hipEventElapsedTime(&ms, c->pev[i], c->pev[i + 1]));
+        tot += ms; ++n;
+    }
+    *total_ms = tot; *launches = n;
+    return WN_OK;
+}
+
 int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
     const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C;
     const int64_t NT = c->NT;
@@ -215,7 +234,9 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
         a.e.bias = c->b1sum + (size_t)l * G;
         a.e.out0 = c->TS + (size_t)l * NT * G; a.e.ld_out0 = G;
         a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
+        if (c->prof) prof_mark(c, st);
         if ((rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st))) return rc;
+        if (c->prof) prof_mark(c, st);
         if (l + 1 < L) {      // the residual output of the last layer is never consumed (wavenet.py:716)
             GemmArgs o; base_args(c, o, c->packs[l].wo);
             o.nseg = 1; o.seg[0] = seg(c->U + (size_t)l * NT * GH, GH, 0, GH, 0, 0);

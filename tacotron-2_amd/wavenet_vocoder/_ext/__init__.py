@@ -85,6 +85,9 @@ def load_library():
         'wn_mulaw_quantize': (ctypes.c_int, [vp, vp, i64, vp]),
         'wn_inv_mulaw_quantize': (ctypes.c_int, [vp, vp, i64, vp]),
         'wn_argmax_channels': (ctypes.c_int, [vp, vp, i32, i32, i32, vp]),
+        'wn_loss': (ctypes.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+        'wn_profile': (ctypes.c_int, [vp, i32]),
+        'wn_profile_result': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]),
         'wn_debug_copy': (ctypes.c_int, [vp, ctypes.c_char_p, i32, vp, i64, vp]),
         'wn_workspace_bytes': (i64, [vp]),
         'wn_dominant_kernel_name': (ctypes.c_char_p, []),
@@ -246,6 +249,18 @@ class Engine:
         B, Tc = int(c.shape[0]), int(c.shape[-1])
         self._ok(self.lib.wn_synthesize(self.h, _ptr(c), B, Tc, _ptr(noise), ctypes.c_uint64(seed), _ptr(test_inputs),
                                         _ptr(out_samples), _ptr(out_raw), int(steps_per_graph), _stream()))
+
+    def loss(self, y_hat, y, lengths, shift, loss_out):
+        B, T = int(y_hat.shape[0]), int(y_hat.shape[-1])
+        self._ok(self.lib.wn_loss(self.h, _ptr(y_hat), _ptr(y), _ptr(lengths), B, T, int(shift), _ptr(loss_out), _stream()))
+
+    def profile(self, enable):
+        self._ok(self.lib.wn_profile(self.h, int(bool(enable))))
+
+    def profile_result(self):
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        self._ok(self.lib.wn_profile_result(self.h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def debug_copy(self, name, layer, rows, cols):
         import torch

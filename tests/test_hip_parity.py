@@ -176,7 +176,7 @@ def test_optimizer_step_matches_tf_adam():
         pn, mn, vn, en = O.adam_ema_update(p0[sl], gc, m0[sl], v0[sl], e0[sl], step + 1, lr)
         assert torch.allclose(p.cpu()[sl], pn, rtol=1e-5, atol=1e-7), name
         assert torch.allclose(m.cpu()[sl], mn, rtol=1e-5, atol=1e-8), name
-        assert torch.allclose(v.cpu()[sl], vn, rtol=1e-5, atol=1e-9), name
+        assert torch.allclose(v.cpu()[sl], vn, rtol=2e-5, atol=1e-9), name
         assert torch.allclose(e.cpu()[sl], en, rtol=1e-5, atol=1e-7), name
 
 
