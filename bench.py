@@ -161,6 +161,7 @@ def main():
 
     from wavenet_vocoder import _ext
     from wavenet_vocoder.models.modules import initialize_parameters
+    from wavenet_vocoder.parallel import allreduce_mean_
     hp, B, T = build_hparams(args.workload)
     B = args.batch or B
     T = args.time or T
@@ -180,9 +181,7 @@ def main():
         eng.pack_weights(flat)
         eng.train_fwd(x, c, y, lengths, 1000 + i, loss)
         eng.train_bwd(grads)
-        if world > 1:
-            dist.all_reduce(grads, op=dist.ReduceOp.SUM)
-            grads.mul_(1.0 / world)
+        allreduce_mean_(grads)
         lr = _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, i, hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
         eng.optim_step(flat, grads, m, v, ema, lr, i)
 

@@ -1,0 +1,244 @@
+"""Training-data feeder of the WaveNet vocoder.
+
+Same on-disk contract and batch tensors as the reference's ``wavenet_vocoder/feeder.py``:
+  * ``map.txt`` lines ``audio_path|mel_path|gta_mel_path|speaker_id|...`` (columns 0..3 are read; the GTA column
+    is used when ``hparams.train_with_GTA``), ``audio-*.npy`` float32 [T] (int16 class ids for mulaw-quantize),
+    ``mel-*.npy`` float32 [Tc, num_mels] in [-max_abs_value, max_abs_value], with T == Tc * hop_size;
+  * train/test split with sklearn (``random_state = wavenet_data_random_state``), 64-batch groups sorted by
+    length, hop-aligned random crops to ``max_time_steps``, mel padding with the silence value followed by
+    the [0,1] normalisation.
+Differences (by design): batches are produced as device tensors by a background thread instead of a
+tf.FIFOQueue; with torch.distributed every rank reads a disjoint shard of each shuffled group (the reference
+had one feeder for all towers); mulaw-quantize inputs stay class ids instead of materialising one-hot.
+
+``SyntheticFeeder`` emits LJSpeech-shaped random tensors of the same layout (no dataset needed).
+"""
+import os
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from datasets import audio
+from infolog import log
+from wavenet_vocoder.util import is_mulaw_quantize, is_scalar_input
+
+_batches_per_group = 64
+
+
+def _interp(feats, in_range):
+    """Rescale from in_range to [0, 1] (reference feeder.py:426-428)."""
+    return (feats - in_range[0]) / (in_range[1] - in_range[0])
+
+
+def _ranks():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+class Feeder(object):
+    def __init__(self, coordinator, metadata_filename, base_dir, hparams, device=None):
+        self._coord = coordinator
+        self._hparams = hparams
+        self._train_offset = 0
+        self._test_offset = 0
+        self._device = device
+        self._rank, self._world = _ranks()
+        self._rng = np.random.RandomState(hparams.wavenet_random_seed + 7919 * self._rank)
+        if hparams.symmetric_mels:
+            self._spec_pad = -hparams.max_abs_value
+        else:
+            self._spec_pad = 0.
+        self._base_dir = base_dir
+        self._data_dir = os.path.dirname(metadata_filename)
+        with open(metadata_filename, 'r', encoding='utf-8') as f:
+            self._metadata = [line.strip().split('|') for line in f if line.strip()]
+        if hparams.gin_channels > 0:
+            raise NotImplementedError('global conditioning is not built')
+        from sklearn.model_selection import train_test_split
+        indices = np.arange(len(self._metadata))
+        test_size = hparams.wavenet_test_size if hparams.wavenet_test_size is not None else hparams.wavenet_test_batches * hparams.wavenet_batch_size
+        train_indices, test_indices = train_test_split(indices, test_size=test_size, random_state=hparams.wavenet_data_random_state)
+        # make the test set a multiple of the batch size
+        len_test = (len(test_indices) // hparams.wavenet_batch_size) * hparams.wavenet_batch_size
+        extra = test_indices[len_test:]
+        test_indices = test_indices[:len_test]
+        train_indices = np.concatenate([train_indices, extra])
+        self._train_meta = [self._metadata[i] for i in train_indices]
+        self._test_meta = [self._metadata[i] for i in test_indices]
+        self.test_steps = len(self._test_meta) // hparams.wavenet_batch_size
+        if hparams.wavenet_test_size is None:
+            assert hparams.wavenet_test_batches == self.test_steps
+        self.local_condition = hparams.cin_channels > 0
+        self.global_condition = False
+        self._train_q = queue.Queue(maxsize=8)
+        self._eval_q = queue.Queue(maxsize=1)
+        self._threads = []
+
+    # ------------------------------------------------------------------ threads
+    def start_threads(self, session=None):
+        for target in (self._enqueue_next_train_group, self._enqueue_next_test_group):
+            t = threading.Thread(name='background', target=target, daemon=True)
+            t.start()
+            self._threads.append(t)
+
+    def _should_stop(self):
+        return self._coord is not None and self._coord.should_stop()
+
+    def _enqueue_next_train_group(self):
+        while not self._should_stop():
+            for batch in self._next_group(train=True):
+                self._train_q.put(self._prepare_batch(batch))
+
+    def _enqueue_next_test_group(self):
+        while not self._should_stop():
+            for batch in self._next_group(train=False):
+                self._eval_q.put(self._prepare_batch(batch))
+
+    def next_train_batch(self):
+        return self._to_device(self._train_q.get())
+
+    def next_eval_batch(self):
+        return self._to_device(self._eval_q.get())
+
+    def _to_device(self, batch):
+        dev = self._device or torch.device('cuda', torch.cuda.current_device())
+        return tuple(None if b is None else torch.from_numpy(b).to(dev, non_blocking=True) for b in batch)
+
+    # ------------------------------------------------------------------ examples
+    def _next_group(self, train):
+        hp = self._hparams
+        n = hp.wavenet_batch_size               # GLOBAL batch, divisible by the number of ranks (feeder.py:267-268)
+        assert n % self._world == 0, 'wavenet_batch_size must be divisible by the number of GPUs'
+        if train:
+            examples = [self._get_example(self._train_meta, True) for _ in range(n * _batches_per_group)]
+            examples.sort(key=lambda e: len(e[0]))                 # bucket by length
+            batches = [examples[i:i + n] for i in range(0, len(examples), n)]
+            self._rng.shuffle(batches)
+        else:
+            examples = [self._get_example(self._test_meta, False) for _ in range(len(self._test_meta))]
+            batches = [examples[i:i + n] for i in range(0, len(examples), n)]
+        per = n // self._world
+        return [b[self._rank * per:(self._rank + 1) * per] for b in batches]
+
+    def _get_example(self, meta_list, train):
+        hp = self._hparams
+        if train:
+            if self._train_offset >= len(meta_list):
+                self._train_offset = 0
+                self._rng_shared_shuffle(meta_list)
+            meta = meta_list[self._train_offset]; self._train_offset += 1
+        else:
+            if self._test_offset >= len(meta_list):
+                self._test_offset = 0
+            meta = meta_list[self._test_offset]; self._test_offset += 1
+        mel_file = meta[2] if hp.train_with_GTA else meta[1]
+        audio_file = meta[0]
+        input_data = np.load(self._resolve(audio_file))
+        local_feats = np.load(self._resolve(mel_file)) if self.local_condition else None
+        assert len(input_data) == len(local_feats) * audio.get_hop_size(hp), 'audio / mel length mismatch in %s' % audio_file
+        return input_data, local_feats, None, len(input_data)
+
+    def _rng_shared_shuffle(self, meta_list):
+        # every rank shuffles identically so that the per-rank slices of a batch stay disjoint
+        np.random.RandomState(self._hparams.wavenet_data_random_state + len(meta_list)).shuffle(meta_list)
+
+    def _resolve(self, path):
+        if os.path.isabs(path) or os.path.exists(path):
+            return path
+        for root in (self._base_dir, self._data_dir):
+            cand = os.path.join(root, path)
+            if os.path.exists(cand):
+                return cand
+        return path
+
+    # ------------------------------------------------------------------ batch assembly
+    def _prepare_batch(self, batch):
+        hp = self._hparams
+        batch = list(batch)
+        self._rng.shuffle(batch)
+        batch = _limit_time(batch, hp, self._rng)
+        input_lengths = np.asarray([len(x[0]) for x in batch], dtype=np.int32)
+        max_t = int(input_lengths.max())
+        hop = audio.get_hop_size(hp)
+        if is_mulaw_quantize(hp.input_type):
+            pad_v = 127
+            x = np.stack([np.pad(b[0].astype(np.int32), (0, max_t - len(b[0])), constant_values=pad_v) for b in batch])
+            inputs, targets = x, x                                     # class ids [B,T] (one-hot never materialised)
+        else:
+            x = np.stack([np.pad(b[0].astype(np.float32), (0, max_t - len(b[0]))) for b in batch])
+            inputs = x[:, None, :]                                      # [B,1,T]
+            targets = x[:, :, None]                                     # [B,T,1]
+        max_c = max_t // hop
+        T2 = (-hp.max_abs_value, hp.max_abs_value) if hp.symmetric_mels else (0., hp.max_abs_value)
+        c = np.stack([np.pad(b[1].astype(np.float32), [(0, max_c - len(b[1])), (0, 0)], constant_values=self._spec_pad) for b in batch])
+        if hp.clip_for_wavenet:
+            c = np.clip(c, T2[0], T2[1])
+        if hp.normalize_for_wavenet:
+            c = _interp(c, T2)
+        c = np.ascontiguousarray(c.transpose(0, 2, 1)).astype(np.float32)   # [B, num_mels, Tc]
+        return (np.ascontiguousarray(inputs), np.ascontiguousarray(targets), input_lengths, c, None)
+
+
+def _limit_time(batch, hparams, rng):
+    """Hop-aligned random crop to max_time_steps (reference feeder.py:356-398)."""
+    if hparams.max_time_sec is not None:
+        max_time_steps = int(hparams.max_time_sec * hparams.sample_rate)
+    elif hparams.max_time_steps is not None:
+        max_time_steps = hparams.max_time_steps
+    else:
+        return batch
+    hop = audio.get_hop_size(hparams)
+    out = []
+    for x, c, g, l in batch:
+        max_steps = max_time_steps - max_time_steps % hop
+        if len(x) > max_steps:
+            max_frames = max_steps // hop
+            s = int(rng.randint(0, len(c) - max_frames + 1))
+            c = c[s:s + max_frames]
+            x = x[s * hop:(s + max_frames) * hop]
+        assert len(x) == len(c) * hop
+        out.append((x, c, g, len(x)))
+    return out
+
+
+class SyntheticFeeder(object):
+    """LJSpeech-shaped synthetic batches resident in HBM: smooth bounded waveform + U[0,1] mels."""
+
+    def __init__(self, hparams, batch_size_per_rank, time_steps, device=None, n_distinct=4):
+        self._hparams = hparams
+        self._rank, self._world = _ranks()
+        hop = audio.get_hop_size(hparams)
+        self.T = int(time_steps) // hop * hop
+        self.B = int(batch_size_per_rank)
+        self.test_steps = 1
+        dev = device or torch.device('cuda', torch.cuda.current_device())
+        g = torch.Generator().manual_seed(hparams.wavenet_random_seed + 104729 * self._rank)
+        self._batches = []
+        for _ in range(n_distinct):
+            t = torch.arange(self.T).float()
+            f = torch.rand(self.B, 1, generator=g) * 320 + 80
+            wav = (0.3 * torch.sin(2 * np.pi * f * t[None] / hparams.sample_rate) + 0.1 * torch.randn(self.B, self.T, generator=g)).clamp(-0.999, 0.999)
+            c = torch.rand(self.B, hparams.cin_channels, self.T // hop, generator=g)
+            lengths = torch.full((self.B,), self.T, dtype=torch.int32)
+            if is_mulaw_quantize(hparams.input_type):
+                from wavenet_vocoder.util import mulaw_quantize
+                ids = torch.from_numpy(mulaw_quantize(wav.numpy())).int()
+                x, y = ids, ids
+            else:
+                x, y = wav.view(self.B, 1, self.T), wav.view(self.B, self.T, 1)
+            self._batches.append(tuple(v.contiguous().to(dev) for v in (x, y, lengths, c)) + (None,))
+        self._i = 0
+
+    def start_threads(self, session=None):
+        pass
+
+    def next_train_batch(self):
+        b = self._batches[self._i % len(self._batches)]
+        self._i += 1
+        return b
+
+    def next_eval_batch(self):
+        return self._batches[0]

@@ -1,0 +1,259 @@
+"""WaveNet vocoder model -- host façade over the HIP engine.
+
+Mirrors the public surface of the reference's ``wavenet_vocoder/models/wavenet.py:WaveNet`` (``initialize``,
+``add_loss``, ``add_optimizer``, ``step``, ``incremental``, ``receptive_field``, ``variables``, the ``tower_*``
+result lists) but is EAGER: where the reference builds TF graph nodes that ``session.run`` evaluates later,
+these methods enqueue the HIP kernels immediately on the current stream and return device tensors.
+
+Data-parallel training is one process per GPU (torch.distributed, backend "nccl" == RCCL): every rank owns
+an identical replica, ``add_optimizer`` all-reduces the flat fp32 gradient (mean over ranks == the tower
+average of wavenet.py:560-575) and every rank applies the same clip / Adam / EMA update.
+"""
+import numpy as np
+import torch
+
+from datasets import audio
+from infolog import log
+from wavenet_vocoder import _ext, util
+from wavenet_vocoder.parallel import allreduce_mean_
+from wavenet_vocoder.util import is_mulaw, is_mulaw_quantize, is_scalar_input
+
+from .modules import initialize_parameters, receptive_field_size
+
+
+class WaveNet(object):
+    def __init__(self, hparams, init=False):
+        self._hparams = hparams
+        if self.local_conditioning_enabled():
+            assert hparams.num_mels == hparams.cin_channels
+        assert hparams.layers % hparams.stacks == 0
+        if hparams.gin_channels > 0:
+            raise NotImplementedError('global conditioning (gin_channels > 0) is not built in this tree yet')
+        if hparams.wavenet_weight_normalization:
+            raise NotImplementedError('wavenet_weight_normalization=True is not built in this tree yet')
+        self.scalar_input = is_scalar_input(hparams.input_type)
+        self.receptive_field = receptive_field_size(hparams.layers, hparams.stacks, hparams.kernel_size)
+        self.embed_speakers = None
+        self.engine = None
+        self.is_training = False
+        self.is_evaluating = False
+        self.global_step = 0
+        self._world = 1
+        self._dist = None
+
+    # ------------------------------------------------------------------ construction
+    def build(self, max_batch, max_time, device=None, params=None):
+        """Allocate the engine (packed weights + workspace) and the flat fp32 parameter / optimiser buffers."""
+        hp = self._hparams
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = device
+        hop = audio.get_hop_size(hp)
+        max_time = (int(max_time) + hop - 1) // hop * hop
+        self.engine = _ext.Engine(hp, max_batch, max_time)
+        self.max_batch, self.max_time = max_batch, max_time
+        if params is None:
+            params = initialize_parameters(hp, self.engine.layout)
+        self.params = params.to(device).contiguous()
+        assert self.params.numel() == self.engine.n_params
+        self.grads = torch.zeros_like(self.params)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.ema_params = self.params.clone()                # tf.train.ExponentialMovingAverage shadow (wavenet.py:473)
+        self.variables = self.engine.views(self.params)      # name -> tensor view (TF layouts)
+        self.gradients = self.engine.views(self.grads)
+        self._loss_dev = torch.zeros(1, device=device)
+        self._dirty = True
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self._dist = torch.distributed
+            self._world = self._dist.get_world_size()
+            self._dist.broadcast(self.params, 0)
+            self.ema_params.copy_(self.params)
+        log('Initializing Wavenet model.  Dimensions: ')
+        log('  Receptive Field:           ({} samples / {:.1f} ms)'.format(self.receptive_field, self.receptive_field / hp.sample_rate * 1000.))
+        n = sum(int(np.prod(s)) for s, _ in self.engine.layout.values())
+        log('  WaveNet Parameters:        {:.3f} Million.'.format(n / 1000000))
+        return self
+
+    def _ensure_packed(self):
+        if self._dirty:
+            self.engine.pack_weights(self.params)
+            self._dirty = False
+
+    def use_ema_weights(self):
+        """Synthesis with the averaged weights (what the reference intended with its shadow saver)."""
+        self.engine.pack_weights(self.ema_params)
+        self._dirty = True
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def initialize(self, y, c, g, input_lengths, x=None, synthesis_length=None, test_inputs=None, split_infos=None):
+        """Train (x given), eval (y given, x None) or synthesis (neither) -- wavenet.py:218-473."""
+        hp = self._hparams
+        self.is_training = x is not None
+        self.is_evaluating = not self.is_training and y is not None
+        self.tower_y_hat, self.tower_y_target, self.tower_synth_upsampled_local_features = [], [], []
+        if self.is_training:
+            B, T = int(x.shape[0]), int(x.shape[-1])
+            if self.engine is None:
+                self.build(B, T)
+            self._ensure_packed()
+            self._seed = int(hp.wavenet_random_seed) * 1000003 + self.global_step
+            self.tower_y, self.tower_input_lengths, self.tower_c = [y], [input_lengths], [c]
+            self._y_hat_train = None
+            self.engine.train_fwd(x.contiguous(), c.contiguous(), y.contiguous(), input_lengths, self._seed, self._loss_dev)
+            self._have_fwd = True
+            return
+        if self.is_evaluating:
+            # item 0 of the batch, teacher forced unless wavenet_natural_eval (wavenet.py:342-405)
+            idx = 0
+            length = int(input_lengths[idx])
+            hop = audio.get_hop_size(hp)
+            length = length // hop * hop
+            y0 = y[idx].reshape(-1)[:length]
+            c0 = c[idx:idx + 1, :, :length // hop].contiguous()
+            ti = None if hp.wavenet_natural_eval else y0.reshape(1, -1).contiguous()
+            out, raw = self.incremental(None, c=c0, time_length=length, test_inputs=ti, return_raw=True)
+            tgt = y0.reshape(1, -1)
+            ln = torch.tensor([length], dtype=torch.int32, device=raw.device)
+            self.engine.loss(raw, tgt.contiguous(), ln, 0, self._loss_dev)          # no shift: wavenet.py:497-506
+            self.eval_loss = self._loss_dev.clone()
+            y_hat = out.reshape(-1)
+            y_target = y0
+            if is_mulaw_quantize(hp.input_type):
+                y_hat = util.inv_mulaw_quantize(y_hat); y_target = util.inv_mulaw_quantize(y_target)
+            elif is_mulaw(hp.input_type):
+                y_hat = util.inv_mulaw(y_hat); y_target = util.inv_mulaw(y_target.float())
+            self.tower_y_hat.append(y_hat)
+            self.tower_y_target.append(y_target)
+            self.tower_eval_c = [c0[0]]
+            self.tower_eval_upsampled_local_features = [self.upsampled_local_features[0]]
+            return
+        # synthesis: c arrives [B, Tc, num_mels] like the reference's placeholder (wavenet.py:408-465)
+        assert c is not None, 'local conditioning is required'
+        if c.dim() != 3:
+            raise ValueError('Expected 3 dimension shape [batch_size(1), time_length, {}] for local condition features but found {}'.format(
+                hp.cin_channels, tuple(c.shape)))
+        cT = c.transpose(1, 2).contiguous()
+        out = self.incremental(None, c=cT, time_length=None, test_inputs=test_inputs)
+        if is_mulaw_quantize(hp.input_type):
+            y_hat = util.inv_mulaw_quantize(out)
+        elif is_mulaw(hp.input_type):
+            y_hat = util.inv_mulaw(out)
+        else:
+            y_hat = out
+        self.tower_y_hat.append(y_hat)
+        self.tower_synth_upsampled_local_features.append(self.upsampled_local_features)
+
+    def add_loss(self):
+        """wavenet.py:476-519.  The masked loss is fused into the forward call; this exposes it."""
+        if self.is_training:
+            self.loss = self._loss_dev
+            if self._dist is not None and self._world > 1:
+                # reported loss = mean of the per-tower losses (wavenet.py:515-516); logging only
+                self._loss_avg = self._loss_dev.clone()
+                self._dist.all_reduce(self._loss_avg, op=self._dist.ReduceOp.SUM)
+                self._loss_avg.mul_(1.0 / self._world)
+                self.loss = self._loss_avg
+            self.tower_loss = [self._loss_dev]
+            return self.loss
+        if self.is_evaluating:
+            return self.eval_loss
+        raise RuntimeError('Model not in train/eval mode but computing loss: Where did this go wrong?')
+
+    def learning_rate_at(self, global_step):
+        hp = self._hparams
+        return _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, global_step,
+                                  hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
+
+    def add_optimizer(self, global_step=None):
+        """Backward + tower-gradient mean (RCCL all-reduce) + clip + Adam + EMA -- wavenet.py:522-613."""
+        if not getattr(self, '_have_fwd', False):
+            raise RuntimeError('add_optimizer needs a training-mode initialize() first')
+        step = self.global_step if global_step is None else int(global_step)
+        self.engine.train_bwd(self.grads)
+        allreduce_mean_(self.grads)
+        self.learning_rate = self.learning_rate_at(step)
+        self.engine.optim_step(self.params, self.grads, self.adam_m, self.adam_v, self.ema_params, self.learning_rate, step)
+        self._dirty = True
+        self._have_fwd = False
+        self.global_step = step + 1
+        self.optimize = True
+        return self.global_step
+
+    def get_mask(self, input_lengths, maxlen=None):
+        expand = not is_mulaw_quantize(self._hparams.input_type)
+        mask = util.sequence_mask(input_lengths, max_len=maxlen, expand=expand)
+        return mask[:, 1:] if not expand else mask[:, 1:, :]
+
+    def has_speaker_embedding(self):
+        return self.embed_speakers is not None
+
+    def local_conditioning_enabled(self):
+        return self._hparams.cin_channels > 0
+
+    def global_conditioning_enabled(self):
+        return self._hparams.gin_channels > 0
+
+    def step(self, x, c=None, g=None, softmax=False):
+        """Teacher-forced parallel forward: x [B,Cin,T] (or ids [B,T]), c [B,cin,Tc] -> [B,O,T] (wavenet.py:650-721)."""
+        B, T = int(x.shape[0]), int(x.shape[-1])
+        if self.engine is None:
+            self.build(B, T)
+        self._ensure_packed()
+        y_hat = torch.empty(B, self._hparams.out_channels, T, device=x.device)
+        lengths = torch.full((B,), T, dtype=torch.int32, device=x.device)
+        dummy_y = x.reshape(B, T).contiguous() if not self.scalar_input else x.reshape(B, T, 1).contiguous()
+        self.engine.train_fwd(x.contiguous(), c.contiguous(), dummy_y, lengths, 0, None, y_hat)
+        self._have_fwd = False
+        return torch.softmax(y_hat, dim=1) if softmax else y_hat
+
+    def incremental(self, initial_input, c=None, g=None, time_length=100, test_inputs=None, softmax=True, quantize=True,
+                    log_scale_min=-7.0, log_scale_min_gauss=-7.0, noise=None, return_raw=False):
+        """Fast-WaveNet generation with ring-buffer queues: c [B,cin,Tc] -> samples [B,T] (wavenet.py:724-911).
+        ``initial_input`` is accepted for signature parity; generation always starts from the reference's silence
+        frame (wavenet.py:433-445).  ``noise`` [T,B,noise_per_step] may be supplied for reproducible draws."""
+        hp = self._hparams
+        B, Tc = int(c.shape[0]), int(c.shape[-1])
+        hop = audio.get_hop_size(hp)
+        T = Tc * hop
+        if self.engine is None:
+            self.build(B, T)
+        self._ensure_packed()
+        dev = c.device
+        nps = self.engine.noise_per_step
+        if noise is None:
+            gen = getattr(self, '_noise_gen', None)
+            if gen is None:
+                gen = torch.Generator(device=dev); gen.manual_seed(int(hp.wavenet_random_seed)); self._noise_gen = gen
+            if hp.out_channels == 2 and self.scalar_input:
+                noise = torch.randn(T, B, nps, device=dev, generator=gen)
+            else:
+                noise = torch.rand(T, B, nps, device=dev, generator=gen) * (1. - 2e-5) + 1e-5        # U(1e-5, 1-1e-5): mixture.py:91,104
+        out = torch.empty(B, T, device=dev, dtype=torch.float32 if self.scalar_input else torch.int32)
+        raw = torch.empty(B, hp.out_channels, T, device=dev) if return_raw else None
+        ti = None
+        if test_inputs is not None:
+            ti = test_inputs.reshape(B, -1)[:, :T]
+            ti = (ti.float() if self.scalar_input else ti.to(torch.int32)).contiguous()
+            assert ti.shape[1] == T, 'teacher-forcing inputs must cover the whole synthesis length'
+        self.engine.synthesize(c.contiguous().float(), noise.contiguous(), out, raw, ti,
+                               steps_per_graph=int(getattr(hp, 'mi355_steps_per_graph', 16)))
+        feats = torch.empty(B, hp.cin_channels, T, device=dev)
+        self.engine.upsampled_features(feats)
+        self.upsampled_local_features = feats
+        return (out, raw) if return_raw else out
+
+    # ------------------------------------------------------------------ checkpoint state
+    def state_dict(self):
+        return {'params': self.params.detach().cpu(), 'ema': self.ema_params.detach().cpu(), 'adam_m': self.adam_m.detach().cpu(),
+                'adam_v': self.adam_v.detach().cpu(), 'global_step': self.global_step,
+                'layout': {k: (tuple(s), int(o)) for k, (s, o) in self.engine.layout.items()}}
+
+    def load_state_dict(self, sd):
+        for name, dst in (('params', self.params), ('ema', self.ema_params), ('adam_m', self.adam_m), ('adam_v', self.adam_v)):
+            src = sd[name]
+            if src.numel() != dst.numel():
+                raise ValueError('checkpoint tensor %s has %d elements, model expects %d' % (name, src.numel(), dst.numel()))
+            dst.copy_(src.to(dst.device))
+        self.global_step = int(sd.get('global_step', 0))
+        self._dirty = True

