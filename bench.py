@@ -78,11 +78,19 @@ def synthetic_batch(hp, B, T, seed, device):
     return x, c.to(device), y, lengths, wav, c
 
 
+def _log(msg):
+    print('[bench %7.1fs] %s' % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
+
+
 def cpu_baseline(hp, seconds_budget=20.0):
     """Oracle training step (fwd + loss + autograd bwd + clip + TF-Adam + EMA) on a bounded sample:
-    the same architecture, batch 1 x (8 frames = 2200 samples), repeated until ~budget seconds."""
+    the same architecture, batch 1 x (8 frames = 2200 samples), repeated until ~budget seconds.
+    Threads: all host cores up to 64 (the bounded sample is too small to feed more)."""
     from oracle import wavenet_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     cfg = O.OracleConfig.from_hparams(hp)
     params = O.init_params(cfg, seed=5339)
@@ -106,6 +114,22 @@ def cpu_baseline(hp, seconds_budget=20.0):
                       % (B, T, n, dt, cores)}
 
 
+def cpu_baseline_subprocess(workload, hard_timeout=150):
+    """Run the CPU leg in a child process so that a pathological host (thread oversubscription) can never
+    take the GPU number down with it."""
+    import subprocess
+    code = ('import sys, json; sys.path.insert(0, %r); import bench; hp, _, _ = bench.build_hparams(%r); '
+            'print("CPUBASE" + json.dumps(bench.cpu_baseline(hp)))' % (ROOT, workload))
+    try:
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=hard_timeout)
+        for line in r.stdout.splitlines():
+            if line.startswith('CPUBASE'):
+                return json.loads(line[len('CPUBASE'):])
+        return {'value': None, 'unit': 'audio_samples/s', 'cores': None, 'kind': 'port', 'sample': 'failed: ' + r.stderr[-200:]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'audio_samples/s', 'cores': None, 'kind': 'port', 'sample': 'timed out after %d s' % hard_timeout}
+
+
 def measure_synthesis(hp, eng_params_flat, device, seconds=0.25, batches=(1, 8)):
     """Autoregressive synthesis RTF at hp.sample_rate for `seconds` of audio per stream."""
     from wavenet_vocoder import _ext
@@ -114,6 +138,7 @@ def measure_synthesis(hp, eng_params_flat, device, seconds=0.25, batches=(1, 8))
     T = Tc * hop
     out = {}
     for B in batches:
+        _log('synthesis B=%d T=%d' % (B, T))
         eng = _ext.Engine(hp, B, T)
         eng.pack_weights(eng_params_flat)
         nps = eng.noise_per_step
@@ -185,8 +210,10 @@ def main():
         lr = _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, i, hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
         eng.optim_step(flat, grads, m, v, ema, lr, i)
 
+    _log('engine + buffers ready; warm-up')
     for i in range(args.warmup):
         one_step(i)
+        torch.cuda.synchronize(); _log('warm-up step %d done' % i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -200,6 +227,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.time() - t0
+    _log('timed region done: %.1f ms/step' % (dt / args.steps * 1e3))
     prof_ms, prof_n = eng.profile_result()
     eng.profile(False)
     final_loss = float(loss.item())
@@ -235,12 +263,14 @@ def main():
                          'alg_flops_per_launch': flops_launch},
         }
         if not args.no_synth:
+            _log('synthesis measurement ...')
             try:
                 res['synthesis'] = measure_synthesis(hp, flat, device)
             except Exception as e:          # never lose the training number to a synthesis problem
                 res['synthesis'] = {'error': str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(hp)
+            _log('cpu baseline (oracle) ...')
+            res['cpu_baseline'] = cpu_baseline_subprocess(args.workload)
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))
