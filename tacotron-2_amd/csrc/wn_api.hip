@@ -68,6 +68,7 @@ static int alloc_workspace(wn_ctx* c) {
     const int L = c->L;
     sz(NT * c->C * 2);                     // cbt
     sz((size_t)(L) * NT * c->R * 2);       // X[0..L-1]
+    if (c->cfg.dropout > 0.0f) sz((size_t)(L) * NT * c->R * 2);   // XD
     sz((size_t)L * NT * c->G * 2);         // TS
     sz((size_t)L * NT * c->GH * 2);        // U
     sz(NT * c->S * 2); sz(NT * c->S * 2);  // R1, H2
@@ -87,6 +88,7 @@ static int alloc_workspace(wn_ctx* c) {
     char* p = c->ws;
     c->cbt = (bf16_t*)bump(p, NT * c->C * 2);
     c->X = (bf16_t*)bump(p, (size_t)L * NT * c->R * 2);
+    c->XD = (c->cfg.dropout > 0.0f) ? (bf16_t*)bump(p, (size_t)L * NT * c->R * 2) : c->X;
     c->TS = (bf16_t*)bump(p, (size_t)L * NT * c->G * 2);
     c->U = (bf16_t*)bump(p, (size_t)L * NT * c->GH * 2);
     c->R1 = (bf16_t*)bump(p, NT * c->S * 2); c->H2 = (bf16_t*)bump(p, NT * c->S * 2);

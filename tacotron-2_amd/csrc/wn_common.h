@@ -102,6 +102,7 @@ struct wn_ctx {
     // workspace
     char* ws = nullptr; size_t ws_bytes = 0;
     int maxB, maxT; int64_t NT;
+    bf16_t* XD;                           // [L][NT][R] dropout-applied layer inputs (aliases X when dropout == 0)
     bf16_t *cbt, *X, *TS, *U, *R1, *H2, *DY, *DPRE1, *DSKIP, *DZ, *GX0, *GX1;
     float *YHAT, *DC, *CUP[WN_MAX_UPSAMPLE + 1], *DCUP[2];
     void* XIN; float* CIN;                // ctx-owned copies of the step's x and c (pointers are borrowed per call)

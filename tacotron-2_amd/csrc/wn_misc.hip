@@ -154,7 +154,8 @@ int wn_launch_pack(wn_ctx* c, const float* params, hipStream_t st) {
 // =================================================================================== input convolution
 // wavenet.py:705 / modules.py:336: h0[t][r] = W[cin][r] x[cin][t] + b[r]; Cin = 1 (scalar) or a one-hot row gather.
 __global__ void wn_first_conv_fwd(const void* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                                  bf16_t* __restrict__ X0, int64_t rows, int R, int is_ids) {
+                                  bf16_t* __restrict__ X0, bf16_t* __restrict__ XD0, int64_t rows, int R, int is_ids,
+                                  uint32_t key_lo, uint32_t key_hi, uint32_t thresh16, float keep_scale) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int r8 = R >> 3;
     if (idx >= rows * r8) return;
@@ -169,7 +170,23 @@ __global__ void wn_first_conv_fwd(const void* __restrict__ x, const float* __res
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = W[c0 + i] * xv + bias[c0 + i];
     }
-    *reinterpret_cast<uint4*>(X0 + row * R + c0) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    bf16_t hb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hb[i] = f2bf(v[i]);
+    *reinterpret_cast<uint4*>(X0 + row * R + c0) = make_uint4(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16),
+                                                               hb[4] | ((uint32_t)hb[5] << 16), hb[6] | ((uint32_t)hb[7] << 16));
+    if (XD0) {      // layer-0 conv input with its dropout mask applied once (modules.py:484)
+        const uint32_t e0 = (uint32_t)(row * R + c0);
+        uint32_t o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t w = wn_drop_word(key_lo, key_hi, (e0 >> 1) + p);
+            const float lo = ((w & 0xffffu) >= thresh16) ? bf2f(hb[2 * p]) * keep_scale : 0.0f;
+            const float hi = ((w >> 16) >= thresh16) ? bf2f(hb[2 * p + 1]) * keep_scale : 0.0f;
+            o[p] = pack_bf2(lo, hi);
+        }
+        *reinterpret_cast<uint4*>(XD0 + row * R + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 // dW[cin][r] = sum_t x[cin][t] g0[t][r];  db[r] = sum_t g0[t][r]
@@ -193,8 +210,11 @@ __global__ void wn_first_conv_bwd(const void* __restrict__ x, const bf16_t* __re
 int wn_first_conv(wn_ctx* c, hipStream_t st) {
     const int64_t rows = (int64_t)c->fB * c->fT;
     const int is_ids = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE;
+    uint32_t klo = 0, khi = 0; wn_layer_key(c->fseed, 0, &klo, &khi);
+    const bool drop = c->cfg.dropout > 0.0f;
     hipLaunchKernelGGL(wn_first_conv_fwd, dim3(cdiv(rows * (c->R / 8), 256)), dim3(256), 0, st, c->fx,
-                       c->params_dev + c->first.dil_k, c->params_dev + c->first.dil_b, c->X, rows, c->R, is_ids);
+                       c->params_dev + c->first.dil_k, c->params_dev + c->first.dil_b, c->X, drop ? c->XD : nullptr, rows, c->R, is_ids,
+                       klo, khi, (uint32_t)lrintf(c->cfg.dropout * 65536.0f), 1.0f / (1.0f - c->cfg.dropout));
     WN_LAUNCH_CHECK(c);
     return WN_OK;
 }

@@ -245,8 +245,21 @@ __global__ __launch_bounds__(WM * WN * 64) void wn_gemm_tile_kernel(const GemmAr
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v[r] *= e.scale; if (e.relu) v[r] = fmaxf(v[r], 0.0f); }
-                        *reinterpret_cast<uint2*>((bf16_t*)e.out0 + row * e.ld_out0 + m) =
-                            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        const uint2 pk = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        *reinterpret_cast<uint2*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pk;
+                        if (e.out1) {
+                            // dropout of the NEXT layer's conv input applied once, here (tf.layers.dropout,
+                            // modules.py:484): x~ = bf16(bf16(x) * 1/(1-p)) or 0; the residual path keeps out0.
+                            const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);
+                            const uint32_t w0 = wn_drop_word(a.key_lo, a.key_hi, e0 >> 1), w1 = wn_drop_word(a.key_lo, a.key_hi, (e0 >> 1) + 1);
+                            const float x0 = bf2f((bf16_t)(pk.x & 0xffff)), x1 = bf2f((bf16_t)(pk.x >> 16));
+                            const float x2 = bf2f((bf16_t)(pk.y & 0xffff)), x3 = bf2f((bf16_t)(pk.y >> 16));
+                            const float d0 = ((w0 & 0xffffu) >= a.thresh16) ? x0 * a.keep_scale : 0.0f;
+                            const float d1 = ((w0 >> 16) >= a.thresh16) ? x1 * a.keep_scale : 0.0f;
+                            const float d2 = ((w1 & 0xffffu) >= a.thresh16) ? x2 * a.keep_scale : 0.0f;
+                            const float d3 = ((w1 >> 16) >= a.thresh16) ? x3 * a.keep_scale : 0.0f;
+                            *reinterpret_cast<uint2*>((bf16_t*)e.out1 + row * e.ld_out1 + m) = make_uint2(pack_bf2(d0, d1), pack_bf2(d2, d3));
+                        }
                     } else if constexpr (EPI == EPI_STORE_F32_BOT) {
                         float* out = (float*)e.out0;
 #pragma unroll

@@ -224,13 +224,13 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
     for (int l = 0; l < L; ++l) {                                                    // wavenet.py:706-715 / modules.py:471-521
         const int d = c->dil[l];
         const bf16_t* Xl = c->X + (size_t)l * NT * R;
+        const bf16_t* XDl = c->XD + (size_t)l * NT * R;      // dropout already applied by the producer
         GemmArgs a; base_args(c, a, c->packs[l].w1);
         a.nseg = 4;
-        a.seg[0] = seg(Xl, R, 0, R, -2 * d, drop);
-        a.seg[1] = seg(Xl, R, 0, R, -d, drop);
-        a.seg[2] = seg(Xl, R, 0, R, 0, drop);
+        a.seg[0] = seg(XDl, R, 0, R, -2 * d, 0);
+        a.seg[1] = seg(XDl, R, 0, R, -d, 0);
+        a.seg[2] = seg(XDl, R, 0, R, 0, 0);
         a.seg[3] = seg(c->cbt, C, 0, C, 0, 0);
-        set_dropout(c, l, a.key_lo, a.key_hi, a.thresh16, a.keep_scale, a.drop_ld);
         a.e.bias = c->b1sum + (size_t)l * G;
         a.e.out0 = c->TS + (size_t)l * NT * G; a.e.ld_out0 = G;
         a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
@@ -244,6 +244,10 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
             o.e.in0 = Xl; o.e.ld_in0 = R;
             o.e.scale = c->res_scale;
             o.e.out0 = c->X + (size_t)(l + 1) * NT * R; o.e.ld_out0 = R;
+            if (drop) {
+                o.e.out1 = c->XD + (size_t)(l + 1) * NT * R; o.e.ld_out1 = R;
+                set_dropout(c, l + 1, o.key_lo, o.key_hi, o.thresh16, o.keep_scale, o.drop_ld);
+            }
             if ((rc = wn_launch_gemm<EPI_STORE_BF16>(c, o, c->packs[l].wo.M, st))) return rc;
         }
     }
@@ -328,13 +332,13 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
         {   // d [W_dil; W_cin], d bias
             WgArgs w; memset(&w, 0, sizeof w);
             w.nseg = 4;
-            w.seg[0] = seg(Xl, R, 0, R, -2 * d, drop); w.seg[1] = seg(Xl, R, 0, R, -d, drop); w.seg[2] = seg(Xl, R, 0, R, 0, drop);
+            const bf16_t* XDl = c->XD + (size_t)l * NT * R;
+            w.seg[0] = seg(XDl, R, 0, R, -2 * d, 0); w.seg[1] = seg(XDl, R, 0, R, -d, 0); w.seg[2] = seg(XDl, R, 0, R, 0, 0);
             w.seg[3] = seg(c->cbt, C, 0, C, 0, 0);
             w.ones_row = 1;
             w.Bm = DZl; w.ldb = G; w.N = G;
             w.out = grads + c->lay[l].dil_k; w.ldw = G; w.bias_out = grads + c->lay[l].dil_b; w.bias_out2 = grads + c->lay[l].cin_b;
             w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-            set_dropout(c, l, w.key_lo, w.key_hi, w.thresh16, w.keep_scale, w.drop_ld);
             if ((rc = launch_wgrad(c, w, st))) return rc;
         }
         {   // d W_skip (scaled by the legacy factor c_l), d skip bias
