@@ -75,13 +75,14 @@ static int alloc_workspace(wn_ctx* c) {
     sz(NT * ldDY * 2);                     // DY
     sz(NT * c->S * 2); sz(NT * c->S * 2);  // DPRE1, DSKIP
     sz((size_t)L * NT * c->G * 2);         // DZ
-    sz(NT * c->R * 2); sz(NT * c->R * 2);  // GX0, GX1
+    sz((size_t)(L + 1) * NT * c->R * 2);   // GXall
     sz(NT * c->O * 4);                     // YHAT
     sz(NT * c->C * 4);                     // DC
     for (int i = 0; i <= c->cfg.n_upsample; ++i) sz(NT * c->C * 4);   // CUP (generous: every level sized for full rate)
     sz(NT * c->C * 4); sz(NT * c->C * 4);  // DCUP ping-pong
     sz(NT * 4); sz(NT * c->C * 4);          // XIN, CIN
     sz(256);                               // scalars
+    sz(256);                               // zero page
     c->ws_bytes = total;
     hipError_t e = hipMalloc((void**)&c->ws, total);
     if (e != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMalloc(%zu bytes workspace) failed: %s", total, hipGetErrorString(e));
@@ -95,13 +96,16 @@ static int alloc_workspace(wn_ctx* c) {
     c->DY = (bf16_t*)bump(p, NT * ldDY * 2);
     c->DPRE1 = (bf16_t*)bump(p, NT * c->S * 2); c->DSKIP = (bf16_t*)bump(p, NT * c->S * 2);
     c->DZ = (bf16_t*)bump(p, (size_t)L * NT * c->G * 2);
-    c->GX0 = (bf16_t*)bump(p, NT * c->R * 2); c->GX1 = (bf16_t*)bump(p, NT * c->R * 2);
+    c->GXall = (bf16_t*)bump(p, (size_t)(L + 1) * NT * c->R * 2);
+    c->GX0 = c->GXall; c->GX1 = c->GXall + (size_t)NT * c->R;     // (debug names: gradients wrt the inputs of layers 0 and 1)
     c->YHAT = (float*)bump(p, NT * c->O * 4);
     c->DC = (float*)bump(p, NT * c->C * 4);
     for (int i = 0; i <= c->cfg.n_upsample; ++i) c->CUP[i] = (float*)bump(p, NT * c->C * 4);
     c->DCUP[0] = (float*)bump(p, NT * c->C * 4); c->DCUP[1] = (float*)bump(p, NT * c->C * 4);
     c->XIN = (void*)bump(p, NT * 4); c->CIN = (float*)bump(p, NT * c->C * 4);
     c->scal = (float*)bump(p, 256);
+    c->zero_page = (bf16_t*)bump(p, 256);
+    if (hipMemset(c->zero_page, 0, 256) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
     return WN_OK;
 }
 
@@ -156,6 +160,12 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     c->maxB = cfg->max_batch; c->maxT = cfg->max_time; c->NT = (int64_t)c->maxB * c->maxT;
     int rc = alloc_workspace(c);
     if (rc == WN_OK) rc = wn_build_packs(c);
+    if (rc == WN_OK) {
+        c->wg_partial_bytes = wn_wgrad_partial_need(c);
+        if (hipMalloc((void**)&c->wg_partial, c->wg_partial_bytes) != hipSuccess) {
+            c->err = "hipMalloc(wgrad partial buffer) failed"; rc = WN_E_HIP;
+        }
+    }
     if (rc != WN_OK) { g_create_err = c->err; wn_destroy(c); return rc; }
     *out = c;
     return WN_OK;
@@ -173,6 +183,7 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->norm2_dev) hipFree(c->norm2_dev);
     if (c->params_dev) hipFree(c->params_dev);
     if (c->ws) hipFree(c->ws);
+    if (c->wg_partial) hipFree(c->wg_partial);
     delete c;
 }
 
@@ -189,7 +200,7 @@ extern "C" int wn_tensor_info(const wn_ctx* c, int i, char* name, int32_t* shape
     if (offset) *offset = t.offset;
     return WN_OK;
 }
-extern "C" int64_t wn_workspace_bytes(const wn_ctx* c) { return (int64_t)c->ws_bytes; }
+extern "C" int64_t wn_workspace_bytes(const wn_ctx* c) { return (int64_t)(c->ws_bytes + c->wg_partial_bytes); }
 extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_tile_kernel"; }
 
 extern "C" int wn_pack_weights(wn_ctx* c, const float* params, void* stream) {

@@ -106,6 +106,9 @@ struct wn_ctx {
     bf16_t *cbt, *X, *TS, *U, *R1, *H2, *DY, *DPRE1, *DSKIP, *DZ, *GX0, *GX1;
     float *YHAT, *DC, *CUP[WN_MAX_UPSAMPLE + 1], *DCUP[2];
     void* XIN; float* CIN;                // ctx-owned copies of the step's x and c (pointers are borrowed per call)
+    float* wg_partial = nullptr; size_t wg_partial_bytes = 0;   // split-K partial tiles of the grouped wgrad (wn_wgrad.h)
+    bf16_t* GXall = nullptr;              // [L+1][NT][R] gradient wrt every layer input (kept for the grouped W_out wgrad)
+    bf16_t* zero_page = nullptr;          // 256 B of zeros: DMA source for out-of-range rows (wn_gemm_lds_kernel)
     float* scal;                          // device scalars: [0]=loss sum [1]=denominator [2]=1/denominator [3]=count
     // state of the last forward
     int fB = 0, fT = 0, fTc = 0; uint64_t fseed = 0; bool have_fwd = false; bool have_loss = false;
@@ -136,4 +139,5 @@ int wn_synth_impl(wn_ctx* ctx, const float* c, int B, int Tc, const float* noise
                   const void* test_inputs, void* out_samples, float* out_raw, int steps_per_graph, hipStream_t st);
 void wn_synth_free(wn_ctx* ctx);
 int wn_upsample_fwd(wn_ctx* ctx, const float* params_unused, const float* c, int B, int Tc, hipStream_t st);
+size_t wn_wgrad_partial_need(wn_ctx* ctx);
 int wn_sample_impl(wn_ctx* ctx, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st);

@@ -17,6 +17,7 @@
 // 64-wide wavefronts, 4 waves per workgroup, 2 workgroups per CU (36 KiB LDS each).
 #pragma once
 #include "wn_common.h"
+#include <type_traits>
 
 struct SrcSeg {
     const bf16_t* base;   // [rows][ld] bf16, row = b*T + t
@@ -47,6 +48,7 @@ struct GemmArgs {
     int32_t B, T;
     int32_t tiles_per_utt, ntiles;
     uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;   // dropout mask spec (row pitch of the dropped tensor)
+    const bf16_t* zero;         // >= 16 B of zeros in device memory (source of out-of-range rows for the LDS-DMA kernel)
     EpiArgs e;
 };
 
@@ -80,6 +82,138 @@ __device__ __forceinline__ uint4 drop8(uint4 v, uint32_t key_lo, uint32_t key_hi
         out[p] = pack_bf2(lo, hi);
     }
     return make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// Fused epilogues, shared by both main loops.  acc[i][j][r]: time t = t0w + j*32 + (lane&31);
+// channel m = (mtile0+i)*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void wn_tile_epilogue(const GemmArgs& a, f32x16_t (&acc)[MT][NT], const int mtile0, const int t0w,
+                                                 const int b, const int T, const int64_t rowbase, const int lane) {
+#ifdef WN_EPI_ABLATE      // harness-only: measure the main loop alone (accumulators kept live, nothing stored)
+    if (a.e.scale != -7777.0f) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        return;
+    }
+#endif
+    const EpiArgs& e = a.e;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = t0w + j * 32 + (lane & 31);
+        if (t >= T) continue;
+        const int64_t row = rowbase + t;
+        if constexpr (EPI == EPI_GATE) {
+            static_assert(EPI != EPI_GATE || MT == 2, "gate epilogue pairs m-tiles");
+            const int gblk = (mtile0 >> 1) * 32;
+            bf16_t* TS = (bf16_t*)e.out0; bf16_t* U = (bf16_t*)e.out1;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int g = gblk + qd * 8 + h * 4;
+                float ta[4], sgm[4], u[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float za = acc[0][j][qd * 4 + r] + e.bias[g + r];
+                    float zb = acc[MT - 1][j][qd * 4 + r] + e.bias[e.GH + g + r];
+                    ta[r] = fast_tanh(za); sgm[r] = fast_sigmoid(zb); u[r] = ta[r] * sgm[r];
+                }
+                *reinterpret_cast<uint2*>(TS + row * e.ld_out0 + g) = make_uint2(pack_bf2(ta[0], ta[1]), pack_bf2(ta[2], ta[3]));
+                *reinterpret_cast<uint2*>(TS + row * e.ld_out0 + e.GH + g) = make_uint2(pack_bf2(sgm[0], sgm[1]), pack_bf2(sgm[2], sgm[3]));
+                *reinterpret_cast<uint2*>(U + row * e.ld_out1 + g) = make_uint2(pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int m = (mtile0 + i) * 32 + qd * 8 + h * 4;
+                    if (m >= e.M_valid) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][qd * 4 + r];
+                    if constexpr (EPI == EPI_STORE_BF16) {
+                        if (e.bias) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += e.bias[m + r];
+                        }
+                        if (e.in0) {
+                            uint2 x = *reinterpret_cast<const uint2*>((const bf16_t*)e.in0 + row * e.ld_in0 + m);
+                            v[0] += bf2f((bf16_t)(x.x & 0xffff)); v[1] += bf2f((bf16_t)(x.x >> 16));
+                            v[2] += bf2f((bf16_t)(x.y & 0xffff)); v[3] += bf2f((bf16_t)(x.y >> 16));
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] *= e.scale; if (e.relu) v[r] = fmaxf(v[r], 0.0f); }
+                        const uint2 pk = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        *reinterpret_cast<uint2*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pk;
+                        if (e.out1) {
+                            // dropout of the NEXT layer's conv input applied once, here (tf.layers.dropout,
+                            // modules.py:484): x~ = bf16(bf16(x) * 1/(1-p)) or 0; the residual path keeps out0.
+                            const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);
+                            const uint32_t w0 = wn_drop_word(a.key_lo, a.key_hi, e0 >> 1), w1 = wn_drop_word(a.key_lo, a.key_hi, (e0 >> 1) + 1);
+                            const float x0 = bf2f((bf16_t)(pk.x & 0xffff)), x1 = bf2f((bf16_t)(pk.x >> 16));
+                            const float x2 = bf2f((bf16_t)(pk.y & 0xffff)), x3 = bf2f((bf16_t)(pk.y >> 16));
+                            const float d0 = ((w0 & 0xffffu) >= a.thresh16) ? x0 * a.keep_scale : 0.0f;
+                            const float d1 = ((w0 >> 16) >= a.thresh16) ? x1 * a.keep_scale : 0.0f;
+                            const float d2 = ((w1 & 0xffffu) >= a.thresh16) ? x2 * a.keep_scale : 0.0f;
+                            const float d3 = ((w1 >> 16) >= a.thresh16) ? x3 * a.keep_scale : 0.0f;
+                            *reinterpret_cast<uint2*>((bf16_t*)e.out1 + row * e.ld_out1 + m) = make_uint2(pack_bf2(d0, d1), pack_bf2(d2, d3));
+                        }
+                    } else if constexpr (EPI == EPI_STORE_F32_BOT) {
+                        float* out = (float*)e.out0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (m + r < e.M_valid) {
+                                float y = v[r] * e.scale + (e.bias ? e.bias[m + r] : 0.0f);
+                                out[((int64_t)b * e.M_valid + (m + r)) * T + t] = y;
+                            }
+                        }
+                    } else if constexpr (EPI == EPI_DGATE) {
+                        const bf16_t* TS = (const bf16_t*)e.in0;
+                        uint2 xa = *reinterpret_cast<const uint2*>(TS + row * e.ld_in0 + m);
+                        uint2 xb = *reinterpret_cast<const uint2*>(TS + row * e.ld_in0 + e.GH + m);
+                        float ta[4] = {bf2f((bf16_t)(xa.x & 0xffff)), bf2f((bf16_t)(xa.x >> 16)), bf2f((bf16_t)(xa.y & 0xffff)), bf2f((bf16_t)(xa.y >> 16))};
+                        float sg[4] = {bf2f((bf16_t)(xb.x & 0xffff)), bf2f((bf16_t)(xb.x >> 16)), bf2f((bf16_t)(xb.y & 0xffff)), bf2f((bf16_t)(xb.y >> 16))};
+                        float da[4], db[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            da[r] = v[r] * sg[r] * (1.0f - ta[r] * ta[r]);
+                            db[r] = v[r] * ta[r] * sg[r] * (1.0f - sg[r]);
+                        }
+                        bf16_t* DZ = (bf16_t*)e.out0;
+                        *reinterpret_cast<uint2*>(DZ + row * e.ld_out0 + m) = make_uint2(pack_bf2(da[0], da[1]), pack_bf2(da[2], da[3]));
+                        *reinterpret_cast<uint2*>(DZ + row * e.ld_out0 + e.GH + m) = make_uint2(pack_bf2(db[0], db[1]), pack_bf2(db[2], db[3]));
+                    } else if constexpr (EPI == EPI_MASK_STORE) {
+                        uint2 x = *reinterpret_cast<const uint2*>((const bf16_t*)e.in0 + row * e.ld_in0 + m);
+                        float ref[4] = {bf2f((bf16_t)(x.x & 0xffff)), bf2f((bf16_t)(x.x >> 16)), bf2f((bf16_t)(x.y & 0xffff)), bf2f((bf16_t)(x.y >> 16))};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (ref[r] > 0.0f) ? v[r] * e.scale : 0.0f;
+                        *reinterpret_cast<uint2*>((bf16_t*)e.out0 + row * e.ld_out0 + m) =
+                            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    } else if constexpr (EPI == EPI_DX) {
+                        if (a.thresh16 != 0) {
+                            const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                v[r] = drop_keep(a.key_lo, a.key_hi, a.thresh16, e0 + r) ? v[r] * a.keep_scale : 0.0f;
+                        }
+                        if (e.in0) {
+                            uint2 x = *reinterpret_cast<const uint2*>((const bf16_t*)e.in0 + row * e.ld_in0 + m);
+                            v[0] += bf2f((bf16_t)(x.x & 0xffff)); v[1] += bf2f((bf16_t)(x.x >> 16));
+                            v[2] += bf2f((bf16_t)(x.y & 0xffff)); v[3] += bf2f((bf16_t)(x.y >> 16));
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= e.scale;
+                        *reinterpret_cast<uint2*>((bf16_t*)e.out0 + row * e.ld_out0 + m) =
+                            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int MT, int NT, int WM, int WN, int EPI>
@@ -197,116 +331,308 @@ __global__ __launch_bounds__(WM * WN * 64) void wn_gemm_tile_kernel(const GemmAr
         __syncthreads();
     }
 
-    // ---- epilogue.  acc[i][j][r]: time t = tbase + j*32 + (lane&31); channel m = (mtile0+i)*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
-    const EpiArgs& e = a.e;
-    const int h = lane >> 5;
+    wn_tile_epilogue<MT, NT, EPI>(a, acc, mtile0, t0 + wn * NT * 32, b, T, rowbase, lane);
+}
+
+// ================================================================================================
+// Main loop v2: BOTH operands through LDS, filled by LDS-DMA (global_load_lds_dwordx4), NBUF-deep ring
+// with counted vmcnt + raw s_barrier, 8 waves per workgroup (1 workgroup per CU).
+//   * workgroup tile  MTILE = WM*MT*32 output channels  x  TTILE = WN*NT*32 time rows, K-chunk BK channels;
+//     at 256 x 128 x 64 the L2->CU traffic is 48 B/clk/CU at full MFMA rate (a 128x128 tile needs 64 B/clk,
+//     which is the L1/TA limit -- the reason v1, which also re-read every A fragment per wave, stalls);
+//   * A: the packed weights are already in MFMA fragment order, one fragment (32 rows x 16 k) = 1 KiB = one
+//     wave-wide LDS-DMA; LDS image [mtile][kstep][lane][8], read back lane-linear (conflict free);
+//   * B: activation rows [t][BK channels] (BK*2 bytes per row), lane-linear LDS image with the 16-B slot
+//     index XOR-swizzled by the row (applied on the per-lane SOURCE address, and again on the ds_read_b128),
+//     so the 16-lane groups of a fragment read hit 16 different 16-B slots of the 256-B bank line;
+//     out-of-range taps (causal zero padding, utterance boundaries, rows >= T, channels >= nk) read a
+//     device zero page instead, so the number of DMAs per chunk is constant (counted vmcnt);
+//   * ring buffers are indexed at compile time (loop unrolled by NBUF): with a runtime index hipcc cannot
+//     prove the DMA destination and the ds_reads disjoint and drains vmcnt(0) before every read.
+constexpr int lds_gemm_bytes(int MT, int NT, int WM, int WN, int BK, int NBUF) {
+    const int ring = NBUF * (WM * MT * 32 + WN * NT * 32) * BK * 2, epi = WN * 32 * (WM * MT * 32 * 4 + 16);
+    return ring > epi ? ring : epi;
+}
+// minimum waves per SIMD for __launch_bounds__: two 8-wave workgroups per CU when LDS allows it
+constexpr int lds_gemm_min_waves(int MT, int NT, int WM, int WN, int BK, int NBUF) {
+    return ((160 * 1024 / lds_gemm_bytes(MT, NT, WM, WN, BK, NBUF) >= 2 && WM * WN <= 8) ? 2 : 1) * WM * WN / 4;
+}
+template <int MT, int NT, int WM, int WN, int BK, int NBUF>
+struct LdsGemmCfg {
+    static constexpr int NW = WM * WN;
+    static constexpr int MTILE = WM * MT * 32, TTILE = WN * NT * 32;
+    static constexpr int KS = BK / 16;
+    static constexpr int A_BYTES = MTILE * BK * 2, B_BYTES = TTILE * BK * 2, BUF_BYTES = A_BYTES + B_BYTES;
+    static constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;
+    static constexpr int A_PW = A_INSTR / NW, B_PW = B_INSTR / NW, LPC = A_PW + B_PW;   // DMAs per wave per chunk
+    static constexpr int RB = BK * 2, SPR = RB / 16, RPL = 256 / RB;                      // row bytes, 16-B slots per row, rows per bank line
+    static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0, "DMA pieces must divide over the waves");
+    static_assert(BK == 32 || BK == 64, "BK");
+    static constexpr int EPI_PITCH = MTILE * 4 + 16;            // fp32 staging row of the epilogue (+16: conflict-free ds_write_b128)
+    static constexpr int EPI_ROWS = WN * 32;
+    static constexpr int LDS_BYTES = lds_gemm_bytes(MT, NT, WM, WN, BK, NBUF);
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, (lds_gemm_min_waves(MT, NT, WM, WN, BK, NBUF)))
+void wn_gemm_lds_kernel(const GemmArgs a) {
+    using Cfg = LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>;
+    __shared__ __attribute__((aligned(1024))) char lds[Cfg::LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, q = id >> 3;
+    const int mblk = q % a.mblocks;
+    const int tile = (q / a.mblocks) * 8 + xcd;
+    if (tile >= a.ntiles) return;
+    const int b = tile / a.tiles_per_utt;
+    const int t0 = (tile - b * a.tiles_per_utt) * Cfg::TTILE;
+    const int T = a.T;
+    const int64_t rowbase = (int64_t)b * T;
+
+    f32x16_t acc[MT][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int t = t0 + (wn * NT + j) * 32 + (lane & 31);
-        if (t >= T) continue;
-        const int64_t row = rowbase + t;
-        if constexpr (EPI == EPI_GATE) {
-            static_assert(EPI != EPI_GATE || MT == 2, "gate epilogue pairs m-tiles");
-            const int gblk = (mtile0 >> 1) * 32;
-            bf16_t* TS = (bf16_t*)e.out0; bf16_t* U = (bf16_t*)e.out1;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int g = gblk + qd * 8 + h * 4;
-                float ta[4], sgm[4], u[4];
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float za = acc[0][j][qd * 4 + r] + e.bias[g + r];
-                    float zb = acc[MT - 1][j][qd * 4 + r] + e.bias[e.GH + g + r];
-                    ta[r] = fast_tanh(za); sgm[r] = fast_sigmoid(zb); u[r] = ta[r] * sgm[r];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int mtile_wg = mblk * (WM * MT);           // first 32-row m-tile of this workgroup
+    const int mtile0 = mtile_wg + wm * MT;            // first m-tile of this wave
+
+    const int chunks_per_rep = [&] { int n = 0; for (int s = 0; s < a.nseg; ++s) n += (a.seg[s].nk + BK - 1) / BK; return n; }();
+    const int nchunks = chunks_per_rep * a.nrep;
+
+    // ---- staging iterator (chunk being DMA'd) and compute iterator (k-step base of the chunk being multiplied)
+    int s_rep = 0, s_sg = 0, s_cc = 0, s_kstep = 0;
+    int c_sg = 0, c_cc = 0, c_kstep = 0;
+
+    // per-lane constants of the B image: LDS byte offset lane*16 inside a 1-KiB piece -> (row, slot)
+    const int b_row_in = (lane * 16) / Cfg::RB, b_slot = lane % Cfg::SPR;
+
+    auto stage = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        char* const abuf = lds + BUF * Cfg::BUF_BYTES;
+        char* const bbuf = abuf + Cfg::A_BYTES;
+        const SrcSeg& s = a.seg[s_sg];
+        const int kc = min(BK, s.nk - s_cc * BK);
+        // A: fragment f = mt*KS + ks  <-  Apk[(mtile_wg + mt)][s_kstep + ks]
+#pragma unroll
+        for (int p = 0; p < Cfg::A_PW; ++p) {
+            const int f = wave + p * Cfg::NW;
+            const int mt = f / Cfg::KS, ks = f % Cfg::KS;
+            const bf16_t* src = (ks * 16 < kc) ? a.Apk + (((int64_t)(mtile_wg + mt) * a.ksteps_total + s_kstep + ks) * 64 + lane) * 8 : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(abuf + f * 1024), 16, 0, 0);
+        }
+        // B: piece g covers rows g*(1024/RB) ...
+        const bf16_t* base = s.base + (int64_t)s_rep * a.rep_stride + s.col0 + s_cc * BK;
+#pragma unroll
+        for (int p = 0; p < Cfg::B_PW; ++p) {
+            const int g = wave + p * Cfg::NW;
+            const int row = g * (1024 / Cfg::RB) + b_row_in;
+            const int c = b_slot ^ ((row / Cfg::RPL) % Cfg::SPR);
+            const int t = t0 + row, ts = t + s.shift;
+            const bool ok = (c * 8 < kc) && (t < T) && (ts >= 0) && (ts < T);
+            const bf16_t* src = ok ? base + (rowbase + ts) * s.ld + c * 8 : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(bbuf + g * 1024), 16, 0, 0);
+        }
+        s_kstep += kc >> 4;
+        ++s_cc;
+        if (s_cc * BK >= s.nk) { s_cc = 0; ++s_sg; if (s_sg == a.nseg) { s_sg = 0; ++s_rep; } }
+    };
+
+    auto compute = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        const char* const abuf = lds + BUF * Cfg::BUF_BYTES;
+        const char* const bbuf = abuf + Cfg::A_BYTES;
+        const int kc = min(BK, a.seg[c_sg].nk - c_cc * BK);
+#pragma unroll
+        for (int ks = 0; ks < Cfg::KS; ++ks) {
+            if (ks * 16 < kc) {
+                bf16x8_t af[MT], bfr[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(abuf + (((wm * MT + i) * Cfg::KS + ks) * 64 + lane) * 16));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int row = (wn * NT + j) * 32 + (lane & 31);
+                    const int c = (ks * 2 + (lane >> 5)) ^ ((row / Cfg::RPL) % Cfg::SPR);
+                    bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bbuf + row * Cfg::RB + c * 16));
                 }
-                *reinterpret_cast<uint2*>(TS + row * e.ld_out0 + g) = make_uint2(pack_bf2(ta[0], ta[1]), pack_bf2(ta[2], ta[3]));
-                *reinterpret_cast<uint2*>(TS + row * e.ld_out0 + e.GH + g) = make_uint2(pack_bf2(sgm[0], sgm[1]), pack_bf2(sgm[2], sgm[3]));
-                *reinterpret_cast<uint2*>(U + row * e.ld_out1 + g) = make_uint2(pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3]));
-            }
-        } else {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        c_kstep += kc >> 4;
+        ++c_cc;
+        if (c_cc * BK >= a.seg[c_sg].nk) { c_cc = 0; ++c_sg; if (c_sg == a.nseg) c_sg = 0; }
+    };
+
+    // one ring step: chunk `ch` lives in buffer BUF; chunk ch+NBUF-1 is DMA'd into the buffer freed by chunk ch-1
+    auto ring_step = [&](auto bufc, int ch) {
+        constexpr int BUF = decltype(bufc)::value;
+        // all DMAs except those of the (NBUF-2) youngest chunks have landed
+        const int younger = min(NBUF - 2, nchunks - 1 - ch);
+        if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+        compute(bufc);
+    };
+    static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+
+    // prologue: fill NBUF-1 buffers
+    stage(std::integral_constant<int, 0>{});
+    if constexpr (NBUF == 3) { if (nchunks > 1) stage(std::integral_constant<int, 1>{}); }
+    for (int ch = 0; ch < nchunks; ch += NBUF) {
+        ring_step(std::integral_constant<int, 0>{}, ch);
+        if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1);
+        if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2); }
+    }
+
+#ifdef WN_EPI_ABLATE
+    if (a.e.scale != -7777.0f) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        return;
+    }
+#endif
+    if constexpr (EPI == EPI_STORE_F32_BOT) {
+        // [B][M][T] fp32 output: lanes are consecutive time steps, already coalesced
+        wn_tile_epilogue<MT, NT, EPI>(a, acc, mtile0, t0 + wn * NT * 32, b, T, rowbase, lane);
+    } else {
+        // ---- epilogue v2: accumulators -> LDS (fp32, [time][channel]) -> one (row, 8 channels) item per thread, so that
+        // every global access of the fused epilogue is a 16-B piece of a fully covered row segment.
+        constexpr int PITCH = Cfg::EPI_PITCH;                // bytes; +16 keeps the ds_write_b128 of 8-lane groups conflict free
+        constexpr int PROWS = Cfg::EPI_ROWS;                 // rows per pass (one 32-row tile of every wave column)
+        const EpiArgs& e = a.e;
+        const int h = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
-                    const int m = (mtile0 + i) * 32 + qd * 8 + h * 4;
-                    if (m >= e.M_valid) continue;
-                    float v[4];
+                    const int rl = wn * 32 + (lane & 31), ml = (wm * MT + i) * 32 + qd * 8 + h * 4;
+                    *reinterpret_cast<float4*>(lds + rl * PITCH + ml * 4) =
+                        make_float4(acc[i][j][qd * 4], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]);
+                }
+            __syncthreads();
+            if constexpr (EPI == EPI_GATE) {
+                constexpr int GT = Cfg::MTILE / 2, C8 = GT / 8, ITEMS = PROWS * C8;
+                bf16_t* TS = (bf16_t*)e.out0; bf16_t* U = (bf16_t*)e.out1;
+                for (int it = tid; it < ITEMS; it += Cfg::NW * 64) {
+                    const int rl = it / C8, c8 = it % C8;
+                    const int t = t0 + ((rl >> 5) * NT + j) * 32 + (rl & 31);
+                    if (t >= T) continue;
+                    const int gl = c8 * 8, ml = (gl >> 5) * 64 + (gl & 31);
+                    const int g = mblk * GT + gl;
+                    const float4 a0 = *reinterpret_cast<const float4*>(lds + rl * PITCH + ml * 4), a1 = *reinterpret_cast<const float4*>(lds + rl * PITCH + ml * 4 + 16);
+                    const float4 b0 = *reinterpret_cast<const float4*>(lds + rl * PITCH + (ml + 32) * 4), b1 = *reinterpret_cast<const float4*>(lds + rl * PITCH + (ml + 32) * 4 + 16);
+                    const float za[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, zb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    uint32_t pt[4], ps[4], pu[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][qd * 4 + r];
+                    for (int p = 0; p < 4; ++p) {
+                        const float t0_ = fast_tanh(za[2 * p] + e.bias[g + 2 * p]), t1_ = fast_tanh(za[2 * p + 1] + e.bias[g + 2 * p + 1]);
+                        const float s0_ = fast_sigmoid(zb[2 * p] + e.bias[e.GH + g + 2 * p]), s1_ = fast_sigmoid(zb[2 * p + 1] + e.bias[e.GH + g + 2 * p + 1]);
+                        pt[p] = pack_bf2(t0_, t1_); ps[p] = pack_bf2(s0_, s1_); pu[p] = pack_bf2(t0_ * s0_, t1_ * s1_);
+                    }
+                    const int64_t row = rowbase + t;
+                    *reinterpret_cast<uint4*>(TS + row * e.ld_out0 + g) = make_uint4(pt[0], pt[1], pt[2], pt[3]);
+                    *reinterpret_cast<uint4*>(TS + row * e.ld_out0 + e.GH + g) = make_uint4(ps[0], ps[1], ps[2], ps[3]);
+                    *reinterpret_cast<uint4*>(U + row * e.ld_out1 + g) = make_uint4(pu[0], pu[1], pu[2], pu[3]);
+                }
+            } else {
+                constexpr int C8 = Cfg::MTILE / 8, ITEMS = PROWS * C8;
+                for (int it = tid; it < ITEMS; it += Cfg::NW * 64) {
+                    const int rl = it / C8, c8 = it % C8;
+                    const int t = t0 + ((rl >> 5) * NT + j) * 32 + (rl & 31);
+                    if (t >= T) continue;
+                    const int m = mblk * Cfg::MTILE + c8 * 8;
+                    const int64_t row = rowbase + t;
+                    const float4 a0 = *reinterpret_cast<const float4*>(lds + rl * PITCH + c8 * 32), a1 = *reinterpret_cast<const float4*>(lds + rl * PITCH + c8 * 32 + 16);
+                    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    auto unpack8 = [](const uint4 x, float* f) {
+                        f[0] = bf2f((bf16_t)(x.x & 0xffff)); f[1] = bf2f((bf16_t)(x.x >> 16)); f[2] = bf2f((bf16_t)(x.y & 0xffff)); f[3] = bf2f((bf16_t)(x.y >> 16));
+                        f[4] = bf2f((bf16_t)(x.z & 0xffff)); f[5] = bf2f((bf16_t)(x.z >> 16)); f[6] = bf2f((bf16_t)(x.w & 0xffff)); f[7] = bf2f((bf16_t)(x.w >> 16));
+                    };
+                    auto pack8 = [](const float* f) { return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7])); };
                     if constexpr (EPI == EPI_STORE_BF16) {
                         if (e.bias) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += e.bias[m + r];
+                            for (int r = 0; r < 8; ++r) v[r] += e.bias[m + r];
                         }
                         if (e.in0) {
-                            uint2 x = *reinterpret_cast<const uint2*>((const bf16_t*)e.in0 + row * e.ld_in0 + m);
-                            v[0] += bf2f((bf16_t)(x.x & 0xffff)); v[1] += bf2f((bf16_t)(x.x >> 16));
-                            v[2] += bf2f((bf16_t)(x.y & 0xffff)); v[3] += bf2f((bf16_t)(x.y >> 16));
+                            float x[8]; unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), x);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += x[r];
                         }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { v[r] *= e.scale; if (e.relu) v[r] = fmaxf(v[r], 0.0f); }
-                        const uint2 pk = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                        *reinterpret_cast<uint2*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pk;
-                        if (e.out1) {
-                            // dropout of the NEXT layer's conv input applied once, here (tf.layers.dropout,
-                            // modules.py:484): x~ = bf16(bf16(x) * 1/(1-p)) or 0; the residual path keeps out0.
+                        for (int r = 0; r < 8; ++r) { v[r] *= e.scale; if (e.relu) v[r] = fmaxf(v[r], 0.0f); }
+                        const uint4 pk = pack8(v);
+                        *reinterpret_cast<uint4*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pk;
+                        if (e.out1) {     // dropout of the next layer's conv input (tf.layers.dropout, modules.py:484), from the ROUNDED value
+                            float x[8], dd[8]; unpack8(pk, x);
                             const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);
-                            const uint32_t w0 = wn_drop_word(a.key_lo, a.key_hi, e0 >> 1), w1 = wn_drop_word(a.key_lo, a.key_hi, (e0 >> 1) + 1);
-                            const float x0 = bf2f((bf16_t)(pk.x & 0xffff)), x1 = bf2f((bf16_t)(pk.x >> 16));
-                            const float x2 = bf2f((bf16_t)(pk.y & 0xffff)), x3 = bf2f((bf16_t)(pk.y >> 16));
-                            const float d0 = ((w0 & 0xffffu) >= a.thresh16) ? x0 * a.keep_scale : 0.0f;
-                            const float d1 = ((w0 >> 16) >= a.thresh16) ? x1 * a.keep_scale : 0.0f;
-                            const float d2 = ((w1 & 0xffffu) >= a.thresh16) ? x2 * a.keep_scale : 0.0f;
-                            const float d3 = ((w1 >> 16) >= a.thresh16) ? x3 * a.keep_scale : 0.0f;
-                            *reinterpret_cast<uint2*>((bf16_t*)e.out1 + row * e.ld_out1 + m) = make_uint2(pack_bf2(d0, d1), pack_bf2(d2, d3));
-                        }
-                    } else if constexpr (EPI == EPI_STORE_F32_BOT) {
-                        float* out = (float*)e.out0;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (m + r < e.M_valid) {
-                                float y = v[r] * e.scale + (e.bias ? e.bias[m + r] : 0.0f);
-                                out[((int64_t)b * e.M_valid + (m + r)) * T + t] = y;
+                            for (int p = 0; p < 4; ++p) {
+                                const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, (e0 >> 1) + p);
+                                dd[2 * p] = ((w & 0xffffu) >= a.thresh16) ? x[2 * p] * a.keep_scale : 0.0f;
+                                dd[2 * p + 1] = ((w >> 16) >= a.thresh16) ? x[2 * p + 1] * a.keep_scale : 0.0f;
                             }
+                            *reinterpret_cast<uint4*>((bf16_t*)e.out1 + row * e.ld_out1 + m) = pack8(dd);
                         }
                     } else if constexpr (EPI == EPI_DGATE) {
                         const bf16_t* TS = (const bf16_t*)e.in0;
-                        uint2 xa = *reinterpret_cast<const uint2*>(TS + row * e.ld_in0 + m);
-                        uint2 xb = *reinterpret_cast<const uint2*>(TS + row * e.ld_in0 + e.GH + m);
-                        float ta[4] = {bf2f((bf16_t)(xa.x & 0xffff)), bf2f((bf16_t)(xa.x >> 16)), bf2f((bf16_t)(xa.y & 0xffff)), bf2f((bf16_t)(xa.y >> 16))};
-                        float sg[4] = {bf2f((bf16_t)(xb.x & 0xffff)), bf2f((bf16_t)(xb.x >> 16)), bf2f((bf16_t)(xb.y & 0xffff)), bf2f((bf16_t)(xb.y >> 16))};
-                        float da[4], db[4];
+                        float ta[8], sg[8], da[8], db[8];
+                        unpack8(*reinterpret_cast<const uint4*>(TS + row * e.ld_in0 + m), ta);
+                        unpack8(*reinterpret_cast<const uint4*>(TS + row * e.ld_in0 + e.GH + m), sg);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
+                        for (int r = 0; r < 8; ++r) {
                             da[r] = v[r] * sg[r] * (1.0f - ta[r] * ta[r]);
                             db[r] = v[r] * ta[r] * sg[r] * (1.0f - sg[r]);
                         }
                         bf16_t* DZ = (bf16_t*)e.out0;
-                        *reinterpret_cast<uint2*>(DZ + row * e.ld_out0 + m) = make_uint2(pack_bf2(da[0], da[1]), pack_bf2(da[2], da[3]));
-                        *reinterpret_cast<uint2*>(DZ + row * e.ld_out0 + e.GH + m) = make_uint2(pack_bf2(db[0], db[1]), pack_bf2(db[2], db[3]));
+                        *reinterpret_cast<uint4*>(DZ + row * e.ld_out0 + m) = pack8(da);
+                        *reinterpret_cast<uint4*>(DZ + row * e.ld_out0 + e.GH + m) = pack8(db);
                     } else if constexpr (EPI == EPI_MASK_STORE) {
-                        uint2 x = *reinterpret_cast<const uint2*>((const bf16_t*)e.in0 + row * e.ld_in0 + m);
-                        float ref[4] = {bf2f((bf16_t)(x.x & 0xffff)), bf2f((bf16_t)(x.x >> 16)), bf2f((bf16_t)(x.y & 0xffff)), bf2f((bf16_t)(x.y >> 16))};
+                        float ref[8]; unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), ref);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (ref[r] > 0.0f) ? v[r] * e.scale : 0.0f;
-                        *reinterpret_cast<uint2*>((bf16_t*)e.out0 + row * e.ld_out0 + m) =
-                            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        for (int r = 0; r < 8; ++r) v[r] = (ref[r] > 0.0f) ? v[r] * e.scale : 0.0f;
+                        *reinterpret_cast<uint4*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pack8(v);
                     } else if constexpr (EPI == EPI_DX) {
                         if (a.thresh16 != 0) {
                             const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                v[r] = drop_keep(a.key_lo, a.key_hi, a.thresh16, e0 + r) ? v[r] * a.keep_scale : 0.0f;
+                            for (int p = 0; p < 4; ++p) {
+                                const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, (e0 >> 1) + p);
+                                v[2 * p] = ((w & 0xffffu) >= a.thresh16) ? v[2 * p] * a.keep_scale : 0.0f;
+                                v[2 * p + 1] = ((w >> 16) >= a.thresh16) ? v[2 * p + 1] * a.keep_scale : 0.0f;
+                            }
                         }
                         if (e.in0) {
-                            uint2 x = *reinterpret_cast<const uint2*>((const bf16_t*)e.in0 + row * e.ld_in0 + m);
-                            v[0] += bf2f((bf16_t)(x.x & 0xffff)); v[1] += bf2f((bf16_t)(x.x >> 16));
-                            v[2] += bf2f((bf16_t)(x.y & 0xffff)); v[3] += bf2f((bf16_t)(x.y >> 16));
+                            float x[8]; unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), x);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += x[r];
                         }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= e.scale;
-                        *reinterpret_cast<uint2*>((bf16_t*)e.out0 + row * e.ld_out0 + m) =
-                            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        for (int r = 0; r < 8; ++r) v[r] *= e.scale;
+                        *reinterpret_cast<uint4*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pack8(v);
                     }
                 }
             }
@@ -314,13 +640,25 @@ __global__ __launch_bounds__(WM * WN * 64) void wn_gemm_tile_kernel(const GemmAr
     }
 }
 
-// Host-side launcher: picks the workgroup shape from M.
+// Host-side launcher: picks the main loop and workgroup shape from M.
 template <int EPI>
 static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st) {
-    // all shapes stage 128 time rows per workgroup (36 KiB LDS, 2 workgroups per CU)
+    if (EPI == EPI_GATE && M % 64 != 0) WN_FAIL(ctx, WN_E_SHAPE, "gate GEMM needs gate_channels %% 64 == 0 (got M=%d)", M);
+    if constexpr (EPI != EPI_STORE_F32_BOT) {
+        if (M % 256 == 0 && a.e.M_valid == M && a.zero) {
+            // v2: 256 channels x 128 time rows per 8-wave workgroup, K-chunks of 32, 3-deep LDS-DMA ring, 2 workgroups per CU
+            a.mblocks = M / 256;
+            a.tiles_per_utt = cdiv(a.T, 128);
+            a.ntiles = a.tiles_per_utt * a.B;
+            const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI>), dim3(grid), dim3(512), 0, st, a);
+            WN_LAUNCH_CHECK(ctx);
+            return WN_OK;
+        }
+    }
+    // v1: all shapes stage 128 time rows per workgroup (36 KiB LDS, 2 workgroups per CU)
     const int nrows = 128;
     const int mrows = (M % 128 == 0) ? 128 : (M % 64 == 0) ? 64 : 32;
-    if (EPI == EPI_GATE && M % 64 != 0) WN_FAIL(ctx, WN_E_SHAPE, "gate GEMM needs gate_channels %% 64 == 0 (got M=%d)", M);
     a.mblocks = M / mrows;
     a.tiles_per_utt = cdiv(a.T, nrows);
     a.ntiles = a.tiles_per_utt * a.B;

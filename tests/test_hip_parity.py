@@ -52,6 +52,13 @@ CONFIGS = {
                        upsample_activation='LeakyRelu'),
     'wide': dict(residual_channels=128, gate_channels=256, skip_out_channels=128, cin_channels=80, num_mels=80,
                  layers=6, stacks=2),
+    # the channel widths of the benchmark configs: these (and only these) take the LDS-DMA GEMM (M % 256 == 0) and the
+    # grouped ds_read_b64_tr_b16 weight-gradient kernels; T = 400 is not a multiple of the 128-row tile
+    'paper_width_drop': dict(residual_channels=256, gate_channels=512, skip_out_channels=256, cin_channels=80, num_mels=80,
+                             layers=6, stacks=2, wavenet_dropout=0.05),
+    'c5_width_legacy': dict(residual_channels=512, gate_channels=1024, skip_out_channels=512, cin_channels=80, num_mels=80,
+                            layers=3, stacks=1, out_channels=2, upsample_type='SubPixel', legacy=True, residual_legacy=True,
+                            log_scale_min_gauss=float(np.log(1e-7))),
 }
 
 

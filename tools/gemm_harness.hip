@@ -1,0 +1,170 @@
+// Stand-alone check + timing of the tile-engine main loops (run on the GPU box):
+//   v1 = wn_gemm_tile_kernel (A fragments straight from L2), v2 = wn_gemm_lds_kernel (LDS-DMA ring).
+// Same GemmArgs, same accumulation order => outputs must be BITWISE identical.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tacotron-2_amd/csrc tools/gemm_harness.hip -o tools/gemm_harness
+#include "wn_tile.h"
+#include <vector>
+#include <random>
+#include <functional>
+
+std::string g_create_err;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static std::mt19937 rng(1234);
+static bf16_t* dev_bf16_random(size_t n, float scale) {
+    std::vector<bf16_t> h(n);
+    std::uniform_real_distribution<float> d(-scale, scale);
+    for (auto& v : h) v = f2bf(d(rng));
+    bf16_t* p; CK(hipMalloc(&p, n * 2)); CK(hipMemcpy(p, h.data(), n * 2, hipMemcpyHostToDevice)); return p;
+}
+static float* dev_f32_random(size_t n, float scale) {
+    std::vector<float> h(n);
+    std::uniform_real_distribution<float> d(-scale, scale);
+    for (auto& v : h) v = d(rng);
+    float* p; CK(hipMalloc(&p, n * 4)); CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice)); return p;
+}
+template <class Tp> static Tp* dev_zero(size_t n) { Tp* p; CK(hipMalloc(&p, n * sizeof(Tp))); CK(hipMemset(p, 0xff, n * sizeof(Tp))); return p; }
+
+struct Out { void* p; size_t bytes; };
+static bool same(const Out& a, const Out& b, const char* what) {
+    std::vector<unsigned char> ha(a.bytes), hb(b.bytes);
+    CK(hipMemcpy(ha.data(), a.p, a.bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), b.p, b.bytes, hipMemcpyDeviceToHost));
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < a.bytes; ++i) if (ha[i] != hb[i]) { if (!bad) first = i; ++bad; }
+    if (bad) printf("    MISMATCH %s: %zu of %zu bytes differ (first at %zu)\n", what, bad, a.bytes, first);
+    return bad == 0;
+}
+
+template <int MT, int NT, int WM, int WN, int EPI>
+static void launch_v1(GemmArgs a, int M, hipStream_t st) {
+    const int nrows = WN * NT * 32, mrows = WM * MT * 32;
+    a.mblocks = M / mrows; a.tiles_per_utt = cdiv(a.T, nrows); a.ntiles = a.tiles_per_utt * a.B;
+    const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+    hipLaunchKernelGGL((wn_gemm_tile_kernel<MT, NT, WM, WN, EPI>), dim3(grid), dim3(WM * WN * 64), 0, st, a);
+}
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI>
+static void launch_v2(GemmArgs a, int M, hipStream_t st) {
+    const int nrows = WN * NT * 32, mrows = WM * MT * 32;
+    a.mblocks = M / mrows; a.tiles_per_utt = cdiv(a.T, nrows); a.ntiles = a.tiles_per_utt * a.B;
+    const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+    hipLaunchKernelGGL((wn_gemm_lds_kernel<MT, NT, WM, WN, BK, NBUF, EPI>), dim3(grid), dim3(WM * WN * 64), 0, st, a);
+}
+static float time_ms(const std::function<void()>& f, int iters = 10) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0)); for (int i = 0; i < iters; ++i) f(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 8, T = argc > 2 ? atoi(argv[2]) : 11000;
+    const int R = 256, G = 512, GH = 256, S = 256, C = 80, L = 4;
+    const int64_t NT_ = (int64_t)B * T;
+    int fails = 0;
+    bf16_t* zero; CK(hipMalloc(&zero, 256)); CK(hipMemset(zero, 0, 256));
+    bf16_t* XD = dev_bf16_random(NT_ * R, 1.0f);
+    bf16_t* X = dev_bf16_random(NT_ * R, 1.0f);
+    bf16_t* cbt = dev_bf16_random(NT_ * C, 1.0f);
+    bf16_t* U = dev_bf16_random((size_t)L * NT_ * GH, 1.0f);
+    bf16_t* DZ = dev_bf16_random(NT_ * G, 1.0f);
+    bf16_t* TSin = dev_bf16_random(NT_ * G, 1.0f);
+    float* bias = dev_f32_random(1024, 0.5f);
+    auto base = [&](GemmArgs& a, const bf16_t* Apk, int K) {
+        memset(&a, 0, sizeof a); a.Apk = Apk; a.ksteps_total = K / 16; a.nrep = 1; a.B = B; a.T = T; a.zero = zero;
+        a.e.scale = 1.0f; a.e.GH = GH;
+    };
+    auto mkseg = [](const bf16_t* b, int ld, int col0, int nk, int shift) { SrcSeg s; s.base = b; s.ld = ld; s.col0 = col0; s.nk = nk; s.shift = shift; s.dropout = 0; return s; };
+
+    {   // ---------------- gate GEMM: M = 512, K = 3*256 + 80 = 848
+        const int M = G, K = 3 * R + C, d = 64;
+        bf16_t* Apk = dev_bf16_random((size_t)M * K, 0.05f);
+        bf16_t* TS1 = dev_zero<bf16_t>(NT_ * G); bf16_t* U1 = dev_zero<bf16_t>(NT_ * GH);
+        bf16_t* TS2 = dev_zero<bf16_t>(NT_ * G); bf16_t* U2 = dev_zero<bf16_t>(NT_ * GH);
+        GemmArgs a; base(a, Apk, K); a.nseg = 4;
+        a.seg[0] = mkseg(XD, R, 0, R, -2 * d); a.seg[1] = mkseg(XD, R, 0, R, -d); a.seg[2] = mkseg(XD, R, 0, R, 0); a.seg[3] = mkseg(cbt, C, 0, C, 0);
+        a.e.bias = bias; a.e.ld_out0 = G; a.e.ld_out1 = GH; a.e.M_valid = M;
+        GemmArgs a1 = a; a1.e.out0 = TS1; a1.e.out1 = U1;
+        GemmArgs a2 = a; a2.e.out0 = TS2; a2.e.out1 = U2;
+        const double fl = 2.0 * M * K * (double)NT_;
+        float t1 = time_ms([&] { launch_v1<2, 2, 2, 2, EPI_GATE>(a1, M, 0); });
+        printf("gate   v1 128x128            : %8.1f us  %7.1f TF\n", t1 * 1e3, fl / t1 / 1e9);
+#define TRY_GATE(WM_, WN_, BK_, NB_) { CK(hipMemset(TS2, 0xff, NT_ * G * 2)); CK(hipMemset(U2, 0xff, NT_ * GH * 2)); \
+        float t2 = time_ms([&] { launch_v2<2, 2, WM_, WN_, BK_, NB_, EPI_GATE>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+        bool ok = same({TS1, (size_t)NT_ * G * 2}, {TS2, (size_t)NT_ * G * 2}, "TS") & same({U1, (size_t)NT_ * GH * 2}, {U2, (size_t)NT_ * GH * 2}, "U"); \
+        printf("gate   v2 WM%d WN%d BK%d NBUF%d   : %8.1f us  %7.1f TF  %s\n", WM_, WN_, BK_, NB_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        TRY_GATE(4, 2, 64, 2) TRY_GATE(4, 2, 64, 3) TRY_GATE(4, 2, 32, 3) TRY_GATE(2, 4, 32, 3) TRY_GATE(4, 2, 32, 2)
+    }
+    {   // ---------------- out conv: M = 256, K = 256, residual add + dropout copy
+        const int M = R, K = GH;
+        bf16_t* Apk = dev_bf16_random((size_t)M * K, 0.05f);
+        bf16_t* O1 = dev_zero<bf16_t>(NT_ * R); bf16_t* D1 = dev_zero<bf16_t>(NT_ * R);
+        bf16_t* O2 = dev_zero<bf16_t>(NT_ * R); bf16_t* D2 = dev_zero<bf16_t>(NT_ * R);
+        GemmArgs a; base(a, Apk, K); a.nseg = 1; a.seg[0] = mkseg(U, GH, 0, GH, 0);
+        a.e.bias = bias; a.e.in0 = X; a.e.ld_in0 = R; a.e.scale = WN_SQRT_HALF; a.e.ld_out0 = R; a.e.ld_out1 = R; a.e.M_valid = M;
+        a.key_lo = 0x1234567u; a.key_hi = 0x89abcdefu; a.thresh16 = 3277; a.keep_scale = 1.0f / 0.95f; a.drop_ld = R;
+        GemmArgs a1 = a; a1.e.out0 = O1; a1.e.out1 = D1; GemmArgs a2 = a; a2.e.out0 = O2; a2.e.out1 = D2;
+        const double fl = 2.0 * M * K * (double)NT_;
+        float t1 = time_ms([&] { launch_v1<2, 2, 2, 2, EPI_STORE_BF16>(a1, M, 0); });
+        printf("out    v1 128x128            : %8.1f us  %7.1f TF\n", t1 * 1e3, fl / t1 / 1e9);
+#define TRY_OUT(WM_, WN_, BK_, NB_) { CK(hipMemset(O2, 0xff, NT_ * R * 2)); CK(hipMemset(D2, 0xff, NT_ * R * 2)); \
+        float t2 = time_ms([&] { launch_v2<2, 2, WM_, WN_, BK_, NB_, EPI_STORE_BF16>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+        bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "X") & same({D1, (size_t)NT_ * R * 2}, {D2, (size_t)NT_ * R * 2}, "XD"); \
+        printf("out    v2 WM%d WN%d BK%d NBUF%d   : %8.1f us  %7.1f TF  %s\n", WM_, WN_, BK_, NB_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        TRY_OUT(4, 2, 64, 3) TRY_OUT(4, 2, 32, 3) TRY_OUT(2, 4, 32, 3) TRY_OUT(4, 2, 32, 2)
+    }
+    {   // ---------------- skip sum: M = 256, K = L*256 via nrep
+        const int M = S, K = L * GH;
+        bf16_t* Apk = dev_bf16_random((size_t)M * K, 0.05f);
+        bf16_t* O1 = dev_zero<bf16_t>(NT_ * S); bf16_t* O2 = dev_zero<bf16_t>(NT_ * S);
+        GemmArgs a; base(a, Apk, K); a.nseg = 1; a.seg[0] = mkseg(U, GH, 0, GH, 0); a.nrep = L; a.rep_stride = NT_ * GH;
+        a.e.bias = bias; a.e.relu = 1; a.e.ld_out0 = S; a.e.M_valid = M;
+        GemmArgs a1 = a; a1.e.out0 = O1; GemmArgs a2 = a; a2.e.out0 = O2;
+        const double fl = 2.0 * M * K * (double)NT_;
+        float t1 = time_ms([&] { launch_v1<2, 2, 2, 2, EPI_STORE_BF16>(a1, M, 0); });
+        printf("skip   v1 128x128            : %8.1f us  %7.1f TF\n", t1 * 1e3, fl / t1 / 1e9);
+        { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 64, 3, EPI_STORE_BF16>(a2, M, 0); }); CK(hipDeviceSynchronize());
+          bool ok = same({O1, (size_t)NT_ * S * 2}, {O2, (size_t)NT_ * S * 2}, "R1");
+          printf("skip   v2 WM4 WN2 BK64 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_STORE_BF16>(a2, M, 0); }); CK(hipDeviceSynchronize());
+          bool ok = same({O1, (size_t)NT_ * S * 2}, {O2, (size_t)NT_ * S * 2}, "R1");
+          printf("skip   v2 WM4 WN2 BK32 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+    }
+    {   // ---------------- dx: M = 256, K = 3*512 (taps at +2d, +d, 0), dropout mask + residual-gradient add
+        const int M = R, K = 3 * G, d = 128;
+        bf16_t* Apk = dev_bf16_random((size_t)M * K, 0.05f);
+        bf16_t* O1 = dev_zero<bf16_t>(NT_ * R); bf16_t* O2 = dev_zero<bf16_t>(NT_ * R);
+        GemmArgs a; base(a, Apk, K); a.nseg = 3;
+        a.seg[0] = mkseg(DZ, G, 0, G, 2 * d); a.seg[1] = mkseg(DZ, G, 0, G, d); a.seg[2] = mkseg(DZ, G, 0, G, 0);
+        a.key_lo = 0x1234567u; a.key_hi = 0x89abcdefu; a.thresh16 = 3277; a.keep_scale = 1.0f / 0.95f; a.drop_ld = R;
+        a.e.in0 = X; a.e.ld_in0 = R; a.e.scale = WN_SQRT_HALF; a.e.ld_out0 = R; a.e.M_valid = M;
+        GemmArgs a1 = a; a1.e.out0 = O1; GemmArgs a2 = a; a2.e.out0 = O2;
+        const double fl = 2.0 * M * K * (double)NT_;
+        float t1 = time_ms([&] { launch_v1<2, 2, 2, 2, EPI_DX>(a1, M, 0); });
+        printf("dx     v1 128x128            : %8.1f us  %7.1f TF\n", t1 * 1e3, fl / t1 / 1e9);
+        { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 64, 3, EPI_DX>(a2, M, 0); }); CK(hipDeviceSynchronize());
+          bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "GX");
+          printf("dx     v2 WM4 WN2 BK64 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DX>(a2, M, 0); }); CK(hipDeviceSynchronize());
+          bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "GX");
+          printf("dx     v2 WM4 WN2 BK32 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+    }
+    {   // ---------------- dgate: M = 512, K = 256 + 256 (two segments), gate derivative epilogue
+        const int M = GH, K = R + S;
+        bf16_t* Apk = dev_bf16_random((size_t)M * K, 0.05f);
+        bf16_t* O1 = dev_zero<bf16_t>(NT_ * G); bf16_t* O2 = dev_zero<bf16_t>(NT_ * G);
+        GemmArgs a; base(a, Apk, K); a.nseg = 2; a.seg[0] = mkseg(X, R, 0, R, 0); a.seg[1] = mkseg(XD, S, 0, S, 0);
+        a.e.in0 = TSin; a.e.ld_in0 = G; a.e.ld_out0 = G; a.e.M_valid = M;
+        GemmArgs a1 = a; a1.e.out0 = O1; GemmArgs a2 = a; a2.e.out0 = O2;
+        const double fl = 2.0 * M * K * (double)NT_;
+        float t1 = time_ms([&] { launch_v1<2, 2, 2, 2, EPI_DGATE>(a1, M, 0); });
+        printf("dgate  v1 128x128            : %8.1f us  %7.1f TF\n", t1 * 1e3, fl / t1 / 1e9);
+        { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 64, 3, EPI_DGATE>(a2, M, 0); }); CK(hipDeviceSynchronize());
+          bool ok = same({O1, (size_t)NT_ * G * 2}, {O2, (size_t)NT_ * G * 2}, "DZ");
+          printf("dgate  v2 WM4 WN2 BK64 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DGATE>(a2, M, 0); }); CK(hipDeviceSynchronize());
+          bool ok = same({O1, (size_t)NT_ * G * 2}, {O2, (size_t)NT_ * G * 2}, "DZ");
+          printf("dgate  v2 WM4 WN2 BK32 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+    }
+    printf("harness %s (%d failing variants)\n", fails ? "FAILED" : "passed", fails);
+    return fails != 0;
+}
