@@ -177,6 +177,7 @@ extern "C" void wn_destroy(wn_ctx* c) {
     auto fr = [](PackedW& w) { if (w.dev) hipFree(w.dev); if (w.dev_segs) hipFree(w.dev_segs); w.dev = nullptr; w.dev_segs = nullptr; };
     for (auto& p : c->packs) { fr(p.w1); fr(p.wo); fr(p.ws); fr(p.w2T); fr(p.w1T); }
     fr(c->wskip); fr(c->wh1); fr(c->wh2); fr(c->wh2T); fr(c->wh1T); fr(c->wcT);
+    if (c->pack_jobs_dev) hipFree(c->pack_jobs_dev);
     if (c->b1sum) hipFree(c->b1sum);
     if (c->skip_bias_total) hipFree(c->skip_bias_total);
     if (c->tensor_offsets_dev) hipFree(c->tensor_offsets_dev);

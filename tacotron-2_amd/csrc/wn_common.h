@@ -95,6 +95,7 @@ struct wn_ctx {
     int cup_final_idx = 0;                // CUP[cup_final_idx] = upsampled conditioning [B,C,T] fp32
     std::vector<WnLayerPacks> packs;
     PackedW wskip, wh1, wh2, wh2T, wh1T, wcT;
+    void* pack_jobs_dev = nullptr; int pack_njobs = 0, pack_nblocks = 0;   // table of the single pack launch
     float* b1sum = nullptr;               // [L][G] dil bias + cin bias
     float* skip_bias_total = nullptr;     // [S]
     int32_t* tensor_offsets_dev = nullptr; // [ntensors+1] for the optimiser

@@ -8,9 +8,14 @@
 // =================================================================================== weight packing
 // Fragment order of v_mfma_f32_32x32x16_bf16's A operand:  out[((mtile*KS + ks)*64 + lane)*8 + j]
 //   <-> W[m = mtile*32 + (lane&31)][k = ks*16 + 8*(lane>>5) + j]
-__global__ void wn_pack_kernel(const float* __restrict__ params, bf16_t* __restrict__ out, int M, int K, int M_valid,
-                               int gate_il, int GH, const PackSeg* __restrict__ segs, int nseg) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+struct PackJob { bf16_t* out; const PackSeg* segs; int32_t M, K, M_valid, gate_il, GH, nseg; int32_t block0, pad; };
+// One launch packs every matrix: block -> job by binary search in the jobs' first-block table.
+__global__ void wn_pack_kernel(const float* __restrict__ params, const PackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const PackJob jb = jobs[lo];
+    const int M = jb.M, K = jb.K;
+    const int64_t idx = (int64_t)(blockIdx.x - jb.block0) * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)M * K) return;
     const int KS = K >> 4;
     const int j = idx & 7, lane = (idx >> 3) & 63;
@@ -18,21 +23,21 @@ __global__ void wn_pack_kernel(const float* __restrict__ params, bf16_t* __restr
     const int ks = (int)(rest % KS), mtile = (int)(rest / KS);
     const int m = mtile * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
     int mm = m;
-    if (gate_il) {          // rows come in 64-row groups [32 tanh rows | their 32 sigmoid partners] (modules.py:494,510)
+    if (jb.gate_il) {       // rows come in 64-row groups [32 tanh rows | their 32 sigmoid partners] (modules.py:494,510)
         const int blk = m >> 6, w = m & 63;
-        mm = (w < 32) ? blk * 32 + w : GH + blk * 32 + (w - 32);
+        mm = (w < 32) ? blk * 32 + w : jb.GH + blk * 32 + (w - 32);
     }
     float v = 0.0f;
-    if (mm < M_valid) {
-        for (int s = 0; s < nseg; ++s) {
-            const PackSeg sg = segs[s];
+    if (mm < jb.M_valid) {
+        for (int s = 0; s < jb.nseg; ++s) {
+            const PackSeg sg = jb.segs[s];
             if (k >= sg.k0 && k < sg.k0 + sg.nk) {
                 v = sg.scale * params[sg.base + (int64_t)(k - sg.k0) * sg.stride_k + (int64_t)mm * sg.stride_m];
                 break;
             }
         }
     }
-    out[idx] = f2bf(v);
+    jb.out[idx] = f2bf(v);
 }
 
 struct VecSum { int n; int64_t off[32]; float w[32]; };
@@ -44,8 +49,8 @@ __global__ void wn_vecsum_kernel(const float* __restrict__ params, float* __rest
     out[i] = a;
 }
 
-static void init_pack(wn_ctx* c, PackedW& w, int M_src, int K_src, int gate_il) {
-    w.M = (M_src + 31) / 32 * 32; w.K = (K_src + 15) / 16 * 16; w.M_valid = M_src; w.gate_interleave = gate_il; w.GH = c->GH;
+static void init_pack(wn_ctx* c, PackedW& w, int M_src, int K_src, int gate_il, int m_align = 32) {
+    w.M = (M_src + m_align - 1) / m_align * m_align; w.K = (K_src + 15) / 16 * 16; w.M_valid = M_src; w.gate_interleave = gate_il; w.GH = c->GH;
 }
 
 static int finish_pack(wn_ctx* c, PackedW& w) {
@@ -98,7 +103,7 @@ int wn_build_packs(wn_ctx* c) {
     init_pack(c, c->wh1T, S, S, 0); c->wh1T.segs.push_back({c->fin1_k, 0, S, 1, S, 1.0f});
     if ((rc = finish_pack(c, c->wh1T))) return rc;
     // d_c: rows = cin channel, K = L*G;  W[cc][l*G+g] = cin_k_l[cc][g]
-    init_pack(c, c->wcT, C, L * G, 0);
+    init_pack(c, c->wcT, C, L * G, 0, 128);      // M padded to the 128-row tile of the LDS-DMA main loop
     for (int l = 0; l < L; ++l) c->wcT.segs.push_back({c->lay[l].cin_k, l * G, G, 1, G, 1.0f});
     if ((rc = finish_pack(c, c->wcT))) return rc;
 
@@ -115,33 +120,34 @@ int wn_build_packs(wn_ctx* c) {
     return WN_OK;
 }
 
-static int launch_one_pack(wn_ctx* c, const PackedW& w, hipStream_t st) {
-    const int64_t n = (int64_t)w.M * w.K;
-    hipLaunchKernelGGL(wn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, c->params_dev, w.dev, w.M, w.K,
-                       w.gate_interleave ? c->G : w.M_valid, w.gate_interleave, w.GH, w.dev_segs, (int)w.segs.size());
-    WN_LAUNCH_CHECK(c);
-    return WN_OK;
+static void add_pack_job(wn_ctx* c, std::vector<PackJob>& jobs, int& nblocks, const PackedW& w) {
+    PackJob j; j.out = w.dev; j.segs = w.dev_segs; j.M = w.M; j.K = w.K; j.M_valid = w.gate_interleave ? c->G : w.M_valid;
+    j.gate_il = w.gate_interleave; j.GH = w.GH; j.nseg = (int)w.segs.size(); j.block0 = nblocks; j.pad = 0;
+    nblocks += cdiv((int64_t)w.M * w.K, 256);
+    jobs.push_back(j);
 }
 
 int wn_launch_pack(wn_ctx* c, const float* params, hipStream_t st) {
     WN_HIP(c, hipMemcpyAsync(c->params_dev, params, (size_t)c->n_params * 4, hipMemcpyDeviceToDevice, st));
-    int rc;
+    if (!c->pack_jobs_dev) {          // job table: built once (pack buffers never move)
+        std::vector<PackJob> jobs; int nblocks = 0;
+        for (int l = 0; l < c->L; ++l) {
+            WnLayerPacks& p = c->packs[l];
+            add_pack_job(c, jobs, nblocks, p.w1); add_pack_job(c, jobs, nblocks, p.wo); add_pack_job(c, jobs, nblocks, p.ws);
+            add_pack_job(c, jobs, nblocks, p.w2T); add_pack_job(c, jobs, nblocks, p.w1T);
+        }
+        add_pack_job(c, jobs, nblocks, c->wskip); add_pack_job(c, jobs, nblocks, c->wh1); add_pack_job(c, jobs, nblocks, c->wh2);
+        add_pack_job(c, jobs, nblocks, c->wh2T); add_pack_job(c, jobs, nblocks, c->wh1T); add_pack_job(c, jobs, nblocks, c->wcT);
+        WN_HIP(c, hipMalloc((void**)&c->pack_jobs_dev, jobs.size() * sizeof(PackJob)));
+        WN_HIP(c, hipMemcpy(c->pack_jobs_dev, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+        c->pack_njobs = (int)jobs.size(); c->pack_nblocks = nblocks;
+    }
+    hipLaunchKernelGGL(wn_pack_kernel, dim3(c->pack_nblocks), dim3(256), 0, st, c->params_dev, (const PackJob*)c->pack_jobs_dev, c->pack_njobs);
+    WN_LAUNCH_CHECK(c);
     for (int l = 0; l < c->L; ++l) {
-        WnLayerPacks& p = c->packs[l];
-        if ((rc = launch_one_pack(c, p.w1, st))) return rc;
-        if ((rc = launch_one_pack(c, p.wo, st))) return rc;
-        if ((rc = launch_one_pack(c, p.ws, st))) return rc;
-        if ((rc = launch_one_pack(c, p.w2T, st))) return rc;
-        if ((rc = launch_one_pack(c, p.w1T, st))) return rc;
         VecSum vs; vs.n = 2; vs.off[0] = c->lay[l].dil_b; vs.off[1] = c->lay[l].cin_b; vs.w[0] = vs.w[1] = 1.0f;
         hipLaunchKernelGGL(wn_vecsum_kernel, dim3(cdiv(c->G, 256)), dim3(256), 0, st, c->params_dev, c->b1sum + (size_t)l * c->G, c->G, vs);
     }
-    if ((rc = launch_one_pack(c, c->wskip, st))) return rc;
-    if ((rc = launch_one_pack(c, c->wh1, st))) return rc;
-    if ((rc = launch_one_pack(c, c->wh2, st))) return rc;
-    if ((rc = launch_one_pack(c, c->wh2T, st))) return rc;
-    if ((rc = launch_one_pack(c, c->wh1T, st))) return rc;
-    if ((rc = launch_one_pack(c, c->wcT, st))) return rc;
     if (c->L > 32) WN_FAIL(c, WN_E_UNSUPPORTED, "layers > 32");
     VecSum vs; vs.n = c->L;
     for (int l = 0; l < c->L; ++l) { vs.off[l] = c->lay[l].skip_b; vs.w[l] = c->skip_scale[l]; }
@@ -273,8 +279,12 @@ __global__ void wn_up_fwd(const float* __restrict__ in, float* __restrict__ out,
     if (cbt) cbt[((int64_t)b * Tout + to) * C + f] = f2bf(v);
 }
 
-// dpre = dout * act'(out);  dK, dbias accumulated with atomics;  (one thread per output element)
-__global__ void wn_up_bwd_params(const float* __restrict__ in, const float* __restrict__ out, const float* __restrict__ dout,
+// dpre = dout * act'(out);  dK[kf][j], dbias.  One workgroup per (b, f) row; thread x owns phase j = x % s of the stride-s
+// output grid (to = j + s*q), so its kernel taps are fixed and accumulate in registers; one LDS atomic per thread and
+// tap at the end, one global atomic per workgroup and tap.  (The v0 kernel did an LDS atomic per ELEMENT and tap on ~30
+// addresses: 290 us on the last upsample layer.)
+#define WN_UP_MAXTAP 27
+__global__ __launch_bounds__(256) void wn_up_bwd_params(const float* __restrict__ in, const float* __restrict__ out, const float* __restrict__ dout,
                                  float* __restrict__ dK, float* __restrict__ dbias, int B, int C, int Tin, int s, int fk,
                                  int type, int act, float alpha) {
     extern __shared__ float sh[];          // [nk + nb]
@@ -283,26 +293,42 @@ __global__ void wn_up_bwd_params(const float* __restrict__ in, const float* __re
     for (int i = threadIdx.x; i < nk + nb; i += blockDim.x) sh[i] = 0.0f;
     __syncthreads();
     const int Tout = Tin * s;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (int64_t)B * C * Tout) {
-        const int to = (int)(idx % Tout); const int64_t bf = idx / Tout;
-        const int f = (int)(bf % C), b = (int)(bf / C);
-        const int t = to / s, j = to - t * s;
-        const float dp = dout[idx] * act_grad(out[idx], act, alpha);
-        if (dp != 0.0f) {
-            const float* inb = in + (int64_t)b * C * Tin;
-            const int pf = (fk - 1) / 2;
+    const int b = blockIdx.x / C, f = blockIdx.x % C;
+    const int groups = blockDim.x / s;                 // (threads beyond groups*s idle)
+    const int j = threadIdx.x % s, q0 = threadIdx.x / s;
+    const int pf = (fk - 1) / 2;
+    const int ntap = (type == 1) ? fk : fk * 3;
+    float dk[WN_UP_MAXTAP], db = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WN_UP_MAXTAP; ++i) dk[i] = 0.0f;
+    if (q0 < groups) {
+        const float* inb = in + (int64_t)b * C * Tin;
+        const int64_t rowo = ((int64_t)b * C + f) * Tout;
+        for (int t = q0; t < Tin; t += groups) {
+            const int64_t o = rowo + (int64_t)t * s + j;
+            const float dp = dout[o] * act_grad(out[o], act, alpha);
+            db += dp;
             if (type == 1) {
-                atomicAdd(&sh[nk], dp);
-                for (int kf = 0; kf < fk; ++kf) { const int fs = f - kf + pf; if (fs >= 0 && fs < C) atomicAdd(&sh[kf * s + j], inb[(int64_t)fs * Tin + t] * dp); }
+#pragma unroll
+                for (int kf = 0; kf < 9; ++kf) {
+                    if (kf < fk) { const int fs = f - kf + pf; if (fs >= 0 && fs < C) dk[kf] += inb[(int64_t)fs * Tin + t] * dp; }
+                }
             } else {
-                atomicAdd(&sh[nk + j], dp);
-                for (int kf = 0; kf < fk; ++kf) {
-                    const int fs = f + kf - pf; if (fs < 0 || fs >= C) continue;
-                    for (int kt = 0; kt < 3; ++kt) { const int tsrc = t + kt - 1; if (tsrc >= 0 && tsrc < Tin) atomicAdd(&sh[(kf * 3 + kt) * s + j], inb[(int64_t)fs * Tin + tsrc] * dp); }
+#pragma unroll
+                for (int kf = 0; kf < 9; ++kf) {
+                    if (kf < fk) {
+                        const int fs = f + kf - pf;
+                        if (fs >= 0 && fs < C) {
+#pragma unroll
+                            for (int kt = 0; kt < 3; ++kt) { const int tsrc = t + kt - 1; if (tsrc >= 0 && tsrc < Tin) dk[kf * 3 + kt] += inb[(int64_t)fs * Tin + tsrc] * dp; }
+                        }
+                    }
                 }
             }
         }
+        if (type == 1) atomicAdd(&sh[nk], db); else atomicAdd(&sh[nk + j], db);
+#pragma unroll
+        for (int i = 0; i < WN_UP_MAXTAP; ++i) if (i < ntap) atomicAdd(&sh[i * s + j], dk[i]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nk; i += blockDim.x) if (sh[i] != 0.0f) unsafeAtomicAdd(&dK[i], sh[i]);
@@ -380,7 +406,9 @@ int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t 
         const int nk = (type == 1) ? fk * s : fk * 3 * s, nb = (type == 1) ? 1 : s;
         if ((size_t)(nk + nb) * 4 > 60000) WN_FAIL(c, WN_E_UNSUPPORTED, "upsample scale %d too large for the LDS partials", s);
         const int64_t n = (int64_t)B * C * Tout;
-        hipLaunchKernelGGL(wn_up_bwd_params, dim3(cdiv(n, 256)), dim3(256), (nk + nb) * 4, st, in, c->CUP[i], dout,
+        if (s > 256) WN_FAIL(c, WN_E_UNSUPPORTED, "upsample scale %d > 256", s);
+        (void)n;
+        hipLaunchKernelGGL(wn_up_bwd_params, dim3(B * C), dim3(256), (nk + nb) * 4, st, in, c->CUP[i], dout,
                            grads + c->up_k[i], grads + c->up_b[i], B, C, Tin, s, fk, type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
         WN_LAUNCH_CHECK(c);
         if (i > 0) {

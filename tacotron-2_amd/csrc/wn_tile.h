@@ -408,74 +408,87 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     const int chunks_per_rep = [&] { int n = 0; for (int s = 0; s < a.nseg; ++s) n += (a.seg[s].nk + BK - 1) / BK; return n; }();
     const int nchunks = chunks_per_rep * a.nrep;
 
-    // ---- staging iterator (chunk being DMA'd) and compute iterator (k-step base of the chunk being multiplied)
-    int s_rep = 0, s_sg = 0, s_cc = 0, s_kstep = 0;
-    int c_sg = 0, c_cc = 0, c_kstep = 0;
-
-    // per-lane constants of the B image: LDS byte offset lane*16 inside a 1-KiB piece -> (row, slot)
-    const int b_row_in = (lane * 16) / Cfg::RB, b_slot = lane % Cfg::SPR;
+    // ---- staging iterator (chunk being DMA'd) and compute iterator (chunk being multiplied).  Everything the loop needs
+    // from the segment descriptors is kept in registers and refreshed only when the iterator enters a new segment:
+    // a dynamically indexed a.seg[i] would be an s_load + s_waitcnt lgkmcnt(0) (which also drains the ds_reads) per chunk.
+    int s_rep = 0, s_sg = 0, s_left = a.seg[0].nk, s_kstep = 0;
+    const bf16_t* s_ptr = a.seg[0].base + a.seg[0].col0;                // + rep offset + channels already staged (wave-uniform)
+    // per-lane constants of the B image: piece g = wave + p*NW holds rows g*(1024/RB)...; LDS byte lane*16 -> (row, slot)
+    int b_c8[Cfg::B_PW], b_t[Cfg::B_PW], b_off[Cfg::B_PW];
+    auto enter_segment = [&]() {          // per-lane element offsets inside the current segment (-1: reads the zero page)
+        const int ld = a.seg[s_sg].ld, shift = a.seg[s_sg].shift;       // one s_load per SEGMENT, not per chunk
+#pragma unroll
+        for (int p = 0; p < Cfg::B_PW; ++p) {
+            const int ts = b_t[p] + shift;
+            b_off[p] = (b_t[p] < T && ts >= 0 && ts < T) ? (int)((rowbase + ts) * ld + b_c8[p]) : -1;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < Cfg::B_PW; ++p) {
+        const int row = (wave + p * Cfg::NW) * (1024 / Cfg::RB) + (lane * 16) / Cfg::RB;
+        b_c8[p] = ((lane % Cfg::SPR) ^ ((row / Cfg::RPL) % Cfg::SPR)) * 8;
+        b_t[p] = t0 + row;
+    }
+    enter_segment();
 
     auto stage = [&](auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
         char* const abuf = lds + BUF * Cfg::BUF_BYTES;
         char* const bbuf = abuf + Cfg::A_BYTES;
-        const SrcSeg& s = a.seg[s_sg];
-        const int kc = min(BK, s.nk - s_cc * BK);
-        // A: fragment f = mt*KS + ks  <-  Apk[(mtile_wg + mt)][s_kstep + ks]
+        const int kc = min(BK, s_left);
+        // A: fragment f = mt*KS + ks  <-  Apk[(mtile_wg + mt)][s_kstep + ks]; wave-uniform base + lane*16
 #pragma unroll
         for (int p = 0; p < Cfg::A_PW; ++p) {
             const int f = wave + p * Cfg::NW;
-            const int mt = f / Cfg::KS, ks = f % Cfg::KS;
-            const bf16_t* src = (ks * 16 < kc) ? a.Apk + (((int64_t)(mtile_wg + mt) * a.ksteps_total + s_kstep + ks) * 64 + lane) * 8 : a.zero;
+            const bf16_t* base = a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512;
+            const bf16_t* src = ((f % Cfg::KS) * 16 < kc) ? base + lane * 8 : a.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(abuf + f * 1024), 16, 0, 0);
         }
-        // B: piece g covers rows g*(1024/RB) ...
-        const bf16_t* base = s.base + (int64_t)s_rep * a.rep_stride + s.col0 + s_cc * BK;
 #pragma unroll
         for (int p = 0; p < Cfg::B_PW; ++p) {
-            const int g = wave + p * Cfg::NW;
-            const int row = g * (1024 / Cfg::RB) + b_row_in;
-            const int c = b_slot ^ ((row / Cfg::RPL) % Cfg::SPR);
-            const int t = t0 + row, ts = t + s.shift;
-            const bool ok = (c * 8 < kc) && (t < T) && (ts >= 0) && (ts < T);
-            const bf16_t* src = ok ? base + (rowbase + ts) * s.ld + c * 8 : a.zero;
+            const bf16_t* src = (b_off[p] >= 0 && b_c8[p] < kc) ? s_ptr + b_off[p] : a.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(bbuf + g * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(bbuf + (wave + p * Cfg::NW) * 1024), 16, 0, 0);
         }
-        s_kstep += kc >> 4;
-        ++s_cc;
-        if (s_cc * BK >= s.nk) { s_cc = 0; ++s_sg; if (s_sg == a.nseg) { s_sg = 0; ++s_rep; } }
+        s_kstep += kc >> 4; s_left -= BK; s_ptr += BK;
+        if (s_left <= 0) {
+            ++s_sg; if (s_sg == a.nseg) { s_sg = 0; ++s_rep; }
+            s_left = a.seg[s_sg].nk; s_ptr = a.seg[s_sg].base + a.seg[s_sg].col0 + (int64_t)s_rep * a.rep_stride;
+            enter_segment();
+        }
     };
 
-    auto compute = [&](auto bufc) {
-        constexpr int BUF = decltype(bufc)::value;
-        const char* const abuf = lds + BUF * Cfg::BUF_BYTES;
-        const char* const bbuf = abuf + Cfg::A_BYTES;
-        const int kc = min(BK, a.seg[c_sg].nk - c_cc * BK);
+    // fragment read offsets (loop invariant): A lane-linear, B swizzled
+    int b_rd[NT][Cfg::KS];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int ks = 0; ks < Cfg::KS; ++ks) {
-            if (ks * 16 < kc) {
-                bf16x8_t af[MT], bfr[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(abuf + (((wm * MT + i) * Cfg::KS + ks) * 64 + lane) * 16));
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int row = (wn * NT + j) * 32 + (lane & 31);
-                    const int c = (ks * 2 + (lane >> 5)) ^ ((row / Cfg::RPL) % Cfg::SPR);
-                    bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bbuf + row * Cfg::RB + c * 16));
-                }
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
+            const int row = (wn * NT + j) * 32 + (lane & 31);
+            b_rd[j][ks] = Cfg::A_BYTES + row * Cfg::RB + (((ks * 2 + (lane >> 5)) ^ ((row / Cfg::RPL) % Cfg::SPR)) * 16);
         }
-        c_kstep += kc >> 4;
-        ++c_cc;
-        if (c_cc * BK >= a.seg[c_sg].nk) { c_cc = 0; ++c_sg; if (c_sg == a.nseg) c_sg = 0; }
+    const int a_rd = (wm * MT * Cfg::KS * 64 + lane) * 16;
+    auto compute = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+        // every k-step of the chunk, unconditionally: in a partial chunk (segment width % BK != 0) the tail k-steps of BOTH
+        // operands were DMA'd from the zero page, so they add exact zeros -- no branch around the accumulators
+#pragma unroll
+        for (int ks = 0; ks < Cfg::KS; ++ks) {
+            bf16x8_t af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
     };
 
     // one ring step: chunk `ch` lives in buffer BUF; chunk ch+NBUF-1 is DMA'd into the buffer freed by chunk ch-1
@@ -652,6 +665,17 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.ntiles = a.tiles_per_utt * a.B;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI>), dim3(grid), dim3(512), 0, st, a);
+            WN_LAUNCH_CHECK(ctx);
+            return WN_OK;
+        }
+    }
+    if constexpr (EPI == EPI_STORE_F32_BOT) {
+        if (M % 128 == 0 && a.zero) {      // d c_up: M = cin padded to 128, K = L*G: 128 channels x 256 time rows per workgroup
+            a.mblocks = M / 128;
+            a.tiles_per_utt = cdiv(a.T, 256);
+            a.ntiles = a.tiles_per_utt * a.B;
+            const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 2, 4, 32, 3, EPI>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
             return WN_OK;
         }

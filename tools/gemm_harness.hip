@@ -88,11 +88,11 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * M * K * (double)NT_;
         float t1 = time_ms([&] { launch_v1<2, 2, 2, 2, EPI_GATE>(a1, M, 0); });
         printf("gate   v1 128x128            : %8.1f us  %7.1f TF\n", t1 * 1e3, fl / t1 / 1e9);
-#define TRY_GATE(WM_, WN_, BK_, NB_) { CK(hipMemset(TS2, 0xff, NT_ * G * 2)); CK(hipMemset(U2, 0xff, NT_ * GH * 2)); \
-        float t2 = time_ms([&] { launch_v2<2, 2, WM_, WN_, BK_, NB_, EPI_GATE>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+#define TRY_GATE2(MT_, NT_, WM_, WN_, BK_, NB_) { CK(hipMemset(TS2, 0xff, NT_ * G * 2)); CK(hipMemset(U2, 0xff, NT_ * GH * 2)); \
+        float t2 = time_ms([&] { launch_v2<MT_, NT_, WM_, WN_, BK_, NB_, EPI_GATE>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
         bool ok = same({TS1, (size_t)NT_ * G * 2}, {TS2, (size_t)NT_ * G * 2}, "TS") & same({U1, (size_t)NT_ * GH * 2}, {U2, (size_t)NT_ * GH * 2}, "U"); \
-        printf("gate   v2 WM%d WN%d BK%d NBUF%d   : %8.1f us  %7.1f TF  %s\n", WM_, WN_, BK_, NB_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
-        TRY_GATE(4, 2, 64, 2) TRY_GATE(4, 2, 64, 3) TRY_GATE(4, 2, 32, 3) TRY_GATE(2, 4, 32, 3) TRY_GATE(4, 2, 32, 2)
+        printf("gate   v2 MT%d NT%d WM%d WN%d BK%d NBUF%d   : %8.1f us  %7.1f TF  %s\n", MT_, NT_, WM_, WN_, BK_, NB_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        TRY_GATE2(2, 2, 4, 2, 32, 3) TRY_GATE2(2, 2, 4, 2, 32, 2) TRY_GATE2(4, 2, 2, 2, 32, 3) TRY_GATE2(4, 2, 2, 2, 32, 2) TRY_GATE2(2, 4, 2, 2, 32, 3) TRY_GATE2(4, 2, 2, 2, 64, 2) TRY_GATE2(4, 2, 4, 1, 32, 3)
     }
     {   // ---------------- out conv: M = 256, K = 256, residual add + dropout copy
         const int M = R, K = GH;
