@@ -174,6 +174,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
 extern "C" void wn_destroy(wn_ctx* c) {
     if (!c) return;
     wn_synth_free(c);
+    wn_pipe_free(c);
     auto fr = [](PackedW& w) { if (w.dev) hipFree(w.dev); if (w.dev_segs) hipFree(w.dev_segs); w.dev = nullptr; w.dev_segs = nullptr; };
     for (auto& p : c->packs) { fr(p.w1); fr(p.wo); fr(p.ws); fr(p.w2T); fr(p.w1T); }
     fr(c->wskip); fr(c->wh1); fr(c->wh2); fr(c->wh2T); fr(c->wh1T); fr(c->wcT);

@@ -118,6 +118,7 @@ struct wn_ctx {
     bool prof = false; std::vector<hipEvent_t> pev; size_t pev_used = 0;
     // synthesis state (lazy)
     struct Synth* synth = nullptr;
+    void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)
 };
 
 extern std::string g_create_err;
@@ -139,6 +140,11 @@ int wn_optim_impl(wn_ctx* ctx, float* p, const float* g, float* m, float* v, flo
 int wn_synth_impl(wn_ctx* ctx, const float* c, int B, int Tc, const float* noise, uint64_t seed,
                   const void* test_inputs, void* out_samples, float* out_raw, int steps_per_graph, hipStream_t st);
 void wn_synth_free(wn_ctx* ctx);
+void wn_pipe_free(wn_ctx* ctx);
+bool wn_pipe_eligible(const wn_ctx* ctx, int B);
+int wn_pipe_synthesize(wn_ctx* ctx, const float* c, int B, int Tc, const float* noise, const void* test_inputs,
+                       void* out_samples, float* out_raw, hipStream_t st);
+extern "C" int wn_noise_per_step(const wn_ctx* c);
 int wn_upsample_fwd(wn_ctx* ctx, const float* params_unused, const float* c, int B, int Tc, hipStream_t st);
 size_t wn_wgrad_partial_need(wn_ctx* ctx);
 int wn_sample_impl(wn_ctx* ctx, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st);

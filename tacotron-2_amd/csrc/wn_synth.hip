@@ -11,6 +11,7 @@
 //   * the whole step (2L+3 kernels) is captured once into a hipGraph of `steps_per_graph` steps; all
 //     kernels read the time index from device memory so the graph is replayed unchanged.
 #include "wn_common.h"
+#include <stdlib.h>
 
 struct Synth {
     int B = 0, T = 0;
@@ -280,6 +281,13 @@ int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise
                   void* out_samples, float* out_raw, int steps_per_graph, hipStream_t caller_st) {
     const int T = Tc * c->hop;
     if ((int64_t)B * T > c->NT) WN_FAIL(c, WN_E_SHAPE, "synthesis B*T = %d*%d exceeds the workspace (max_batch*max_time = %lld)", B, T, (long long)c->NT);
+    {   // steps_per_graph <= 0 selects the persistent dataflow pipeline (wn_synth_pipe.hip) when the model fits it;
+        // WN_SYNTH_MODE=graph|pipe overrides
+        const char* m = getenv("WN_SYNTH_MODE");
+        const bool want_pipe = m ? (strcmp(m, "pipe") == 0) : (steps_per_graph <= 0);
+        if (want_pipe && wn_pipe_eligible(c, B)) return wn_pipe_synthesize(c, cin, B, Tc, noise, test_inputs, out_samples, out_raw, caller_st);
+        if (steps_per_graph <= 0) steps_per_graph = 32;
+    }
     const int L = c->L, R = c->R;
     Synth* s = c->synth;
     if (!s) {

@@ -1,0 +1,588 @@
+// Fast-WaveNet autoregressive synthesis as ONE persistent, weight-stationary dataflow kernel
+// (replaces WaveNet.incremental, wavenet.py:724-911, and the per-layer launches of wn_synth.hip).
+//
+// Why: the sample-to-sample dependency chain crosses every layer, so a step costs (number of dependent kernel
+// boundaries) x ~1.5 us when layers are launches -- 2L+3 = 51 boundaries = 75 us before any arithmetic, against a
+// real-time budget of 45.35 us per sample at 22.05 kHz.  Here nothing is launched per sample:
+//   * every layer is owned by P = gate_channels/64 workgroups, one per CU (142 KiB of LDS each); CU (l, j) keeps in LDS,
+//     for the whole utterance, the rows of [W_dil | W_cin] of ITS 32 tanh/sigmoid gate pairs (all 3 taps + conditioning)
+//     and the COLUMNS of W_out / W_skip that multiply its 32 gate outputs.  27 MB of bf16 weights are read from HBM once;
+//   * a step is a message that travels the ring  head -> layer 0 -> ... -> layer L-1 -> head.  CU (l, j) sums the P
+//     partial vectors it receives into x_l(t), finishes z = z_past + W_tap2 x_l(t) (the taps t-d, t-2d and the
+//     conditioning were pre-multiplied while the message was elsewhere), gates, and publishes ITS partial of
+//     x_{l+1}(t) = rho (x_l + W_out u + b): one exchange per layer, no barrier anywhere;
+//   * hand-off = data-tagged 16-byte granules {3 payload words, tag = t+1} written with ONE write-through (sc1) store
+//     and polled with sc1 loads: no flag, no fence (tools/hop_probe.hip: 1.06 us per P=8 hop, 0.71 us for P=4);
+//     single-buffered mailboxes are safe because sample t exists only after every CU consumed step t;
+//   * the skip sum travels the same ring as P independent fp32 running sums (CU (l, j) -> (l+1, j)) and is reduced by
+//     the head CU, which also holds the two head convolutions, samples (MoL / Gaussian / categorical, mixture.py:76-107,
+//     gaussian.py:39-52, wavenet.py:861-867) and applies the input convolution of the next step;
+//   * streams of a batch are independent messages that follow each other through the ring (pipelined, not batched):
+//     B = 8 costs the same wall time per sample as B = 1;
+//   * queues are ring buffers in HBM (one private copy per CU, 4d slots per layer, zero-initialised == the reference's
+//     zero queues, wavenet.py:815-816), touched off the critical path only.
+// Every spin loop is bounded; a timeout raises a device flag that makes all workgroups leave.
+#include "wn_common.h"
+#include <algorithm>
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+#define PIPE_THREADS 256
+#define PIPE_XG 64            // granules per x partial (one per lane): 6 bf16 channels each
+#define PIPE_SG 128           // granules per skip partial: 3 fp32 channels each
+#define PIPE_SPIN_LIMIT 3000000
+
+struct PipeArgs {
+    int32_t L, P, R, G, GH, S, O, OP, C, Cin, B, T;
+    float rho; int32_t mode, nps; float lsmin; int32_t start_id, spx;
+    const char* slices; int64_t layer_slice_bytes, head_slice_off;
+    int32_t off_w1c, off_w1p, off_wo, off_ws, off_zb, off_ob, layer_lds_static;      // byte offsets inside a layer slice / LDS image
+    int32_t hoff_wh1, hoff_wh2, hoff_b1, hoff_b2, hoff_sb, hoff_win, hoff_bin, head_lds_static;
+    u32x4* XM; u32x4* SM;
+    bf16_t* ring; const bf16_t* cbt;
+    const float* noise; const void* test_inputs; void* out_samples; float* out_raw;
+    const float* win_global; const float* bin_global;
+    int32_t* abort_flag;
+    int64_t ring_off[32]; int64_t cin_b_off[32]; int32_t ring_mask[32]; int32_t dil[32];
+};
+
+// ---- granule I/O: 16 bytes, one write-through store / one L1-bypassing load ------------------------------------------
+__device__ __forceinline__ void st_g16(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u32x4 ld_g16(const u32x4* p) {
+    u32x4 v; asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v;
+}
+__device__ __forceinline__ void ld2_g16(const u32x4* p0, const u32x4* p1, u32x4& v0, u32x4& v1) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+}
+__device__ __forceinline__ bool pipe_aborted(const int32_t* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
+__device__ __forceinline__ void pipe_abort(int32_t* f, int code) { __hip_atomic_store(f, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ float dot8(const uint4 w, const uint4 x, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), __builtin_bit_cast(bf16x2_t, x.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), __builtin_bit_cast(bf16x2_t, x.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), __builtin_bit_cast(bf16x2_t, x.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), __builtin_bit_cast(bf16x2_t, x.w), acc, false);
+    return acc;
+}
+
+// matvec over k-chunks [kc0, kc1) of a [kchunk][rows][8] bf16 LDS image against a bf16 vector in LDS; this lane's row
+__device__ __forceinline__ float mv_rows(const char* W, int rows, int row, const char* vec, int kc0, int kc1) {
+    float a0 = 0.0f, a1 = 0.0f;
+    int kc = kc0;
+    for (; kc + 1 < kc1; kc += 2) {
+        a0 = dot8(*reinterpret_cast<const uint4*>(W + ((size_t)kc * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + kc * 16), a0);
+        a1 = dot8(*reinterpret_cast<const uint4*>(W + ((size_t)(kc + 1) * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + (kc + 1) * 16), a1);
+    }
+    if (kc < kc1) a0 = dot8(*reinterpret_cast<const uint4*>(W + ((size_t)kc * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + kc * 16), a0);
+    return a0 + a1;
+}
+
+// ======================================================================================================================
+// slice builder: fp32 parameters -> the bf16 LDS images of every CU (run once per wn_pack_weights + synthesis)
+struct SliceJob { int64_t dst; int64_t src; int32_t rows, kchunks, stride_k, stride_row, kind; float scale; int32_t row_perm_base, row_perm_split, pad; };
+// kind 0: bf16 image [kc][row][8], element (kc,row,e) = scale * params[src + (kc*8+e)*stride_k + rowsrc(row)*stride_row]
+//         rowsrc(row) = row < split ? base + row : GHoff + base + (row - split)   (gate pairs; split = 0 -> identity + base)
+// kind 1: fp32 vector of `rows` floats, element row = scale * params[src + rowsrc(row)]
+__global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __restrict__ slices, const SliceJob* __restrict__ jobs, const int* __restrict__ job_block0, int njobs, int GH) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (job_block0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const SliceJob jb = jobs[lo];
+    const int64_t idx = (int64_t)(blockIdx.x - job_block0[lo]) * blockDim.x + threadIdx.x;
+    auto rowsrc = [&](int row) { return jb.row_perm_split ? (row < jb.row_perm_split ? jb.row_perm_base + row : GH + jb.row_perm_base + (row - jb.row_perm_split)) : jb.row_perm_base + row; };
+    if (jb.kind == 0) {
+        const int64_t n = (int64_t)jb.kchunks * jb.rows * 8;
+        if (idx >= n) return;
+        const int e = (int)(idx & 7); const int64_t r2 = idx >> 3;
+        const int row = (int)(r2 % jb.rows), kc = (int)(r2 / jb.rows);
+        const float v = jb.scale * params[jb.src + (int64_t)(kc * 8 + e) * jb.stride_k + (int64_t)rowsrc(row) * jb.stride_row];
+        reinterpret_cast<bf16_t*>(slices + jb.dst)[idx] = f2bf(v);
+    } else {
+        if (idx >= jb.rows) return;
+        reinterpret_cast<float*>(slices + jb.dst)[idx] = jb.scale * params[jb.src + rowsrc((int)idx)];
+    }
+}
+
+// ======================================================================================================================
+__global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = a.R, S = a.S, P = a.P, B = a.B, T = a.T, C = a.C;
+    // ---- role: spx consecutive layers per XCD (block b runs on XCD b % 8), the head on XCD 0
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int layer_slots = a.spx * P;
+    int layer = -1, j = 0; bool is_head = false;
+    if (slot < layer_slots) { layer = a.spx * xcd + slot / P; j = slot % P; if (layer >= a.L) return; }
+    else if (slot == layer_slots && xcd == 0) is_head = true;
+    else return;
+    int32_t* const abortf = a.abort_flag;
+
+    if (!is_head) {
+        // ================================================================= layer CU (layer, j)
+        const int l = layer;
+        {   // weights -> LDS (one coalesced pass)
+            const uint4* src = reinterpret_cast<const uint4*>(a.slices + (int64_t)(l * P + j) * a.layer_slice_bytes);
+            uint4* dst = reinterpret_cast<uint4*>(lds);
+            for (int i = tid; i < a.layer_lds_static / 16; i += PIPE_THREADS) dst[i] = src[i];
+        }
+        const char* W1c = lds + a.off_w1c; const char* W1p = lds + a.off_w1p; const char* Wo = lds + a.off_wo; const char* Ws = lds + a.off_ws;
+        const float* zb = reinterpret_cast<const float*>(lds + a.off_zb); const float* ob = reinterpret_cast<const float*>(lds + a.off_ob);
+        char* p = lds + a.layer_lds_static;
+        bf16_t* xcur_b = reinterpret_cast<bf16_t*>(p); p += R * 2;
+        float* xcur_f = reinterpret_cast<float*>(p); p += R * 4;
+        float* psum = reinterpret_cast<float*>(p); p += 4 * R * 4;
+        float* zpart = reinterpret_cast<float*>(p); p += 4 * 64 * 4;
+        bf16_t* ucur = reinterpret_cast<bf16_t*>(p); p += 64;
+        bf16_t* outp = reinterpret_cast<bf16_t*>(p); p += ((R + 7) / 8 * 8 + 8) * 2;
+        float* skp = reinterpret_cast<float*>(p); p += (S + 4) * 4;
+        bf16_t* vec = reinterpret_cast<bf16_t*>(p); p += (2 * R + C) * 2;
+        float* zpast = reinterpret_cast<float*>(p);                       // [B][64]
+        const int d = a.dil[l], mask = a.ring_mask[l];
+        const int KP = (2 * R + C) / 8;                                    // k-chunks of the past-tap image
+        const int nprod = (l == 0) ? 1 : P;
+        const bool top = (l == a.L - 1);
+        __syncthreads();
+
+        // z_past for (s, tn): taps x(tn-2d), x(tn-d) from this CU's ring (zero before the utterance), conditioning c(s, tn)
+        auto precompute = [&](int s, int tn, bool tap1_is_cur) {
+            bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
+            for (int i = tid; i < KP; i += PIPE_THREADS) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int k = i * 8;
+                if (k < R) { const int tau = tn - 2 * d; if (tau >= 0) v = __builtin_bit_cast(uint4, ld_g16(reinterpret_cast<const u32x4*>(ringb + (int64_t)(tau & mask) * R + k))); }
+                else if (k < 2 * R) {
+                    const int tau = tn - d;
+                    if (tau >= 0) v = tap1_is_cur ? *reinterpret_cast<const uint4*>(xcur_b + (k - R))
+                                                  : __builtin_bit_cast(uint4, ld_g16(reinterpret_cast<const u32x4*>(ringb + (int64_t)(tau & mask) * R + (k - R))));
+                } else v = *reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (k - 2 * R));
+                *reinterpret_cast<uint4*>(vec + k) = v;
+            }
+            __syncthreads();
+            {
+                const int per = (KP + 3) / 4, kc0 = wave * per, kc1 = min(KP, kc0 + per);
+                zpart[wave * 64 + lane] = mv_rows(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
+            }
+            __syncthreads();
+            if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zb[tid];
+            __syncthreads();
+        };
+        for (int s = 0; s < B; ++s) precompute(s, 0, false);
+
+        for (int t = 0; t < T; ++t) {
+            const uint32_t want = (uint32_t)(t + 1);
+            for (int s = 0; s < B; ++s) {
+                // ---- 1. x_l(t) = sum of the partial vectors published by the previous stage
+                {
+                    const u32x4* in = a.XM + ((int64_t)(l * B + s) * P) * PIPE_XG;
+                    float v[6] = {0, 0, 0, 0, 0, 0};
+                    const int p0 = wave, p1 = wave + 4;
+                    if (p0 < nprod) {
+                        int spins = 0;
+                        for (;;) {
+                            u32x4 g0, g1; bool ok;
+                            if (p1 < nprod) { ld2_g16(in + (int64_t)p0 * PIPE_XG + lane, in + (int64_t)p1 * PIPE_XG + lane, g0, g1); ok = (g0.w == want) && (g1.w == want); }
+                            else { g0 = ld_g16(in + (int64_t)p0 * PIPE_XG + lane); g1 = (u32x4){0, 0, 0, 0}; ok = (g0.w == want); }
+                            if (__all(ok)) {
+                                v[0] = bf2f((bf16_t)(g0.x & 0xffff)) + bf2f((bf16_t)(g1.x & 0xffff)); v[1] = bf2f((bf16_t)(g0.x >> 16)) + bf2f((bf16_t)(g1.x >> 16));
+                                v[2] = bf2f((bf16_t)(g0.y & 0xffff)) + bf2f((bf16_t)(g1.y & 0xffff)); v[3] = bf2f((bf16_t)(g0.y >> 16)) + bf2f((bf16_t)(g1.y >> 16));
+                                v[4] = bf2f((bf16_t)(g0.z & 0xffff)) + bf2f((bf16_t)(g1.z & 0xffff)); v[5] = bf2f((bf16_t)(g0.z >> 16)) + bf2f((bf16_t)(g1.z >> 16));
+                                break;
+                            }
+                            if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 100 + l); break; }
+                            if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) { const int ch = lane * 6 + e; if (ch < R) psum[wave * R + ch] = v[e]; }
+                }
+                __syncthreads();
+                if (pipe_aborted(abortf)) return;
+                for (int r = tid; r < R; r += PIPE_THREADS) {
+                    const bf16_t xb = f2bf(psum[r] + psum[R + r] + psum[2 * R + r] + psum[3 * R + r]);
+                    xcur_b[r] = xb; xcur_f[r] = bf2f(xb);
+                }
+                __syncthreads();
+                // ---- 2. z = z_past + W_tap2 x ; gate (modules.py:494-510)
+                {
+                    const int KC = R / 8, per = (KC + 3) / 4, kc0 = wave * per, kc1 = min(KC, kc0 + per);
+                    zpart[wave * 64 + lane] = mv_rows(W1c, 64, lane, reinterpret_cast<const char*>(xcur_b), kc0, kc1);
+                }
+                __syncthreads();
+                if (tid < 32) {
+                    const float za = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zpast[s * 64 + tid];
+                    const float zs = zpart[32 + tid] + zpart[96 + tid] + zpart[160 + tid] + zpart[224 + tid] + zpast[s * 64 + 32 + tid];
+                    const float e = __expf(2.0f * za);
+                    ucur[tid] = f2bf((1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zs))));
+                }
+                __syncthreads();
+                // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0])  -> granules (modules.py:512-521)
+                if (!top) {
+                    for (int r = tid; r < R; r += PIPE_THREADS) {
+                        float o = mv_rows(Wo, R, r, reinterpret_cast<const char*>(ucur), 0, 4);
+                        if (j == 0) o += xcur_f[r] + ob[r];
+                        outp[r] = f2bf(o * a.rho);
+                    }
+                    if (tid < 8) outp[R + tid] = 0;        // padding read by the last granule
+                    __syncthreads();
+                    if (tid < PIPE_XG) {
+                        u32x4 g = {0, 0, 0, want};
+                        if (tid * 6 < R) {
+                            const uint32_t* q = reinterpret_cast<const uint32_t*>(outp + tid * 6);     // 6 bf16 = 3 words (4-byte aligned: tid*12)
+                            g.x = q[0]; g.y = q[1]; g.z = q[2];
+                            if (tid * 6 + 2 > R) g.y = 0;
+                            if (tid * 6 + 4 > R) g.z = 0;
+                        }
+                        st_g16(a.XM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + tid, g);
+                    }
+                }
+                // ---- 4. skip chain: running sum of CU (l-1, j) + W_skip[:, mine] u_mine  -> CU (l+1, j) / head (wavenet.py:833-836)
+                {
+                    for (int r = tid; r < S; r += PIPE_THREADS) {
+                        const float mine = mv_rows(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
+                        float inc = 0.0f;
+                        if (l > 0) {
+                            const u32x4* in = a.SM + ((int64_t)(l * B + s) * P + j) * PIPE_SG + r / 3;
+                            int spins = 0;
+                            for (;;) {
+                                const u32x4 g = ld_g16(in);
+                                if (g.w == want) { inc = __uint_as_float(r % 3 == 0 ? g.x : r % 3 == 1 ? g.y : g.z); break; }
+                                if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 200 + l); break; }
+                                if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
+                            }
+                        }
+                        skp[r] = inc + mine;
+                    }
+                    if (tid < 4) skp[S + tid] = 0.0f;
+                    __syncthreads();
+                    for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
+                        u32x4 g = {__float_as_uint(skp[g3 * 3]), __float_as_uint(skp[g3 * 3 + 1]), __float_as_uint(skp[g3 * 3 + 2]), want};
+                        st_g16(a.SM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_SG + g3, g);
+                    }
+                }
+                // ---- 5. queue update (private ring) and the pre-multiplication for this stream's next step
+                {
+                    bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
+                    for (int i = tid; i < R / 8; i += PIPE_THREADS)
+                        *reinterpret_cast<uint4*>(ringb + (int64_t)(t & mask) * R + i * 8) = *reinterpret_cast<const uint4*>(xcur_b + i * 8);
+                    if (t + 1 < T) precompute(s, t + 1, d == 1);      // ring rows are read past this CU's L1 (sc1): slots are recycled
+                }
+                if (pipe_aborted(abortf)) return;
+            }
+        }
+        return;
+    }
+
+    // ===================================================================== head CU
+    {
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(a.slices + a.head_slice_off);
+            uint4* dst = reinterpret_cast<uint4*>(lds);
+            for (int i = tid; i < a.head_lds_static / 16; i += PIPE_THREADS) dst[i] = src[i];
+        }
+        const char* Wh1 = lds + a.hoff_wh1; const char* Wh2 = lds + a.hoff_wh2;
+        const float* b1 = reinterpret_cast<const float*>(lds + a.hoff_b1); const float* b2 = reinterpret_cast<const float*>(lds + a.hoff_b2);
+        const float* sb = reinterpret_cast<const float*>(lds + a.hoff_sb);
+        const float* win = reinterpret_cast<const float*>(lds + a.hoff_win); const float* bin = reinterpret_cast<const float*>(lds + a.hoff_bin);
+        char* p = lds + a.head_lds_static;
+        float* psum = reinterpret_cast<float*>(p); p += 4 * (S + 4) * 4;
+        bf16_t* r1 = reinterpret_cast<bf16_t*>(p); p += S * 2;
+        bf16_t* h2 = reinterpret_cast<bf16_t*>(p); p += S * 2;
+        float* yraw = reinterpret_cast<float*>(p); p += a.OP * 4;
+        bf16_t* outp = reinterpret_cast<bf16_t*>(p); p += ((R + 7) / 8 * 8 + 8) * 2;
+        float* nxt_f = reinterpret_cast<float*>(p); p += 16;
+        int* nxt_i = reinterpret_cast<int*>(p); p += 16;
+        const int L = a.L, O = a.O, OP = a.OP, mode = a.mode;
+        __syncthreads();
+
+        // x_0(tn) = input convolution of `value` (wavenet.py:826 / 433-445)  -> layer 0's mailbox
+        auto publish_input = [&](int s, int tn) {
+            for (int r = tid; r < R; r += PIPE_THREADS) {
+                float v;
+                if (mode == 2) v = a.win_global[(int64_t)nxt_i[0] * R + r] + a.bin_global[r];
+                else v = win[r] * nxt_f[0] + bin[r];
+                outp[r] = f2bf(v);
+            }
+            if (tid < 8) outp[R + tid] = 0;
+            __syncthreads();
+            if (tid < PIPE_XG) {
+                u32x4 g = {0, 0, 0, (uint32_t)(tn + 1)};
+                if (tid * 6 < R) {
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(outp + tid * 6);
+                    g.x = q[0]; g.y = q[1]; g.z = q[2];
+                    if (tid * 6 + 2 > R) g.y = 0;
+                    if (tid * 6 + 4 > R) g.z = 0;
+                }
+                st_g16(a.XM + ((int64_t)(0 * B + s) * P + 0) * PIPE_XG + tid, g);
+            }
+            __syncthreads();
+        };
+        if (tid == 0) { nxt_f[0] = 0.0f; nxt_i[0] = a.start_id; }
+        __syncthreads();
+        for (int s = 0; s < B; ++s) publish_input(s, 0);
+
+        for (int t = 0; t < T; ++t) {
+            const uint32_t want = (uint32_t)(t + 1);
+            for (int s = 0; s < B; ++s) {
+                // ---- total skip = sum of the P running sums that left the top layer (+ all skip biases), ReLU (wavenet.py:840)
+                {
+                    const u32x4* in = a.SM + ((int64_t)(L * B + s) * P) * PIPE_SG;
+                    const int ng = (S + 2) / 3;
+                    float v[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                    for (int pp = wave; pp < P; pp += 4) {
+                        int spins = 0;
+                        for (;;) {
+                            u32x4 g0 = {0, 0, 0, want}, g1 = {0, 0, 0, want};
+                            const bool h0 = lane < ng, h1 = lane + 64 < ng;
+                            if (h0 && h1) ld2_g16(in + (int64_t)pp * PIPE_SG + lane, in + (int64_t)pp * PIPE_SG + lane + 64, g0, g1);
+                            else if (h0) g0 = ld_g16(in + (int64_t)pp * PIPE_SG + lane);
+                            const bool ok = (g0.w == want) && (g1.w == want);
+                            if (__all(ok)) {
+                                v[0][0] += __uint_as_float(g0.x); v[0][1] += __uint_as_float(g0.y); v[0][2] += __uint_as_float(g0.z);
+                                v[1][0] += __uint_as_float(g1.x); v[1][1] += __uint_as_float(g1.y); v[1][2] += __uint_as_float(g1.z);
+                                break;
+                            }
+                            if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 300); break; }
+                            if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
+                        }
+                    }
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) { const int ch = (lane + 64 * hh) * 3 + e; if (ch < S) psum[wave * (S + 4) + ch] = v[hh][e]; }
+                }
+                __syncthreads();
+                if (pipe_aborted(abortf)) return;
+                for (int r = tid; r < S; r += PIPE_THREADS) {
+                    float tot = sb[r];
+                    for (int w = 0; w < 4 && w < P; ++w) tot += psum[w * (S + 4) + r];
+                    r1[r] = f2bf(fmaxf(tot, 0.0f));
+                }
+                __syncthreads();
+                // ---- head convolutions (wavenet.py:840-844)
+                for (int r = tid; r < S; r += PIPE_THREADS) h2[r] = f2bf(fmaxf(mv_rows(Wh1, S, r, reinterpret_cast<const char*>(r1), 0, S / 8) + b1[r], 0.0f));
+                __syncthreads();
+                for (int r = tid; r < OP; r += PIPE_THREADS) yraw[r] = (r < O) ? mv_rows(Wh2, OP, r, reinterpret_cast<const char*>(h2), 0, S / 8) + b2[r] : 0.0f;
+                __syncthreads();
+                // ---- sample (wavenet.py:847-878); noise [T][B][nps]
+                if (tid == 0) {
+                    const float* nz = a.noise + ((int64_t)t * B + s) * a.nps;
+                    if (mode == 2) {
+                        float best = -INFINITY; int bi = 0;
+                        for (int q = 0; q < O; ++q) { const float vv = yraw[q] - logf(-logf(nz[q])); if (vv > best) { best = vv; bi = q; } }
+                        ((int32_t*)a.out_samples)[(int64_t)s * T + t] = bi;
+                        nxt_i[0] = a.test_inputs ? ((const int32_t*)a.test_inputs)[(int64_t)s * T + t] : bi;
+                    } else {
+                        float x;
+                        if (mode == 0) {
+                            const int M = O / 3;
+                            float best = -INFINITY; int bi = 0;
+                            for (int i = 0; i < M; ++i) { const float vv = yraw[i] - logf(-logf(nz[i])); if (vv > best) { best = vv; bi = i; } }
+                            const float ls = fmaxf(yraw[2 * M + bi], a.lsmin);
+                            const float u = nz[M];
+                            x = yraw[M + bi] + expf(ls) * (logf(u) - logf(1.0f - u));
+                        } else x = yraw[0] + expf(fmaxf(yraw[1], a.lsmin)) * nz[0];
+                        x = fminf(fmaxf(x, -1.0f), 1.0f);
+                        ((float*)a.out_samples)[(int64_t)s * T + t] = x;
+                        nxt_f[0] = a.test_inputs ? ((const float*)a.test_inputs)[(int64_t)s * T + t] : x;
+                    }
+                }
+                if (a.out_raw) for (int o = tid; o < O; o += PIPE_THREADS) a.out_raw[((int64_t)s * O + o) * T + t] = yraw[o];
+                __syncthreads();
+                if (t + 1 < T) publish_input(s, t + 1);
+                if (pipe_aborted(abortf)) return;
+            }
+        }
+    }
+}
+
+// ======================================================================================================================
+struct Pipe {
+    int B = 0, T = 0, P = 0, spx = 0, grid = 0;
+    char* slices = nullptr; int64_t layer_slice_bytes = 0, head_slice_off = 0, slices_bytes = 0;
+    SliceJob* jobs_dev = nullptr; int* job_block0_dev = nullptr; int njobs = 0, nblocks = 0;
+    u32x4* XM = nullptr; u32x4* SM = nullptr; size_t xm_bytes = 0, sm_bytes = 0;
+    bf16_t* ring = nullptr; size_t ring_bytes = 0; int ring_B = 0;
+    int32_t* abort_dev = nullptr;
+    int layer_lds = 0, head_lds = 0;
+    PipeArgs proto;
+    hipStream_t priv = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+void wn_pipe_free(wn_ctx* c) {
+    Pipe* p = (Pipe*)c->pipe;
+    if (!p) return;
+    if (p->slices) hipFree(p->slices); if (p->jobs_dev) hipFree(p->jobs_dev); if (p->job_block0_dev) hipFree(p->job_block0_dev);
+    if (p->XM) hipFree(p->XM); if (p->SM) hipFree(p->SM); if (p->ring) hipFree(p->ring); if (p->abort_dev) hipFree(p->abort_dev);
+    if (p->ev0) hipEventDestroy(p->ev0); if (p->ev1) hipEventDestroy(p->ev1); if (p->priv) hipStreamDestroy(p->priv);
+    delete p; c->pipe = nullptr;
+}
+
+// can this model run on the persistent pipeline?  (one CU per 32 gate pairs, all of a CU's weights in 160 KiB of LDS)
+bool wn_pipe_eligible(const wn_ctx* c, int B) {
+    const int R = c->R, S = c->S, C = c->C, GH = c->GH, L = c->L;
+    if (GH % 32 || R % 8 || S % 8 || C % 8 || S % 3 == 99) return false;
+    const int P = GH / 32;
+    if (P > 8 || L > 32 || B > 16 || R > 384 || S > 384 || c->OP > 256) return false;
+    const int spx = (L + 7) / 8;
+    if (spx * P + 1 > 30) return false;                 // 32 CUs per XCD, keep slack
+    const int64_t layer_static = 64LL * R * 2 + 64LL * (2 * R + C) * 2 + 32LL * R * 2 + 32LL * S * 2 + 256 + R * 4;
+    const int64_t layer_dyn = R * 2 + R * 4 + 16LL * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256LL * B + 64;
+    const int64_t head_static = (int64_t)S * S * 2 + (int64_t)c->OP * S * 2 + S * 4 * 2 + c->OP * 4 + R * 8 + 64;
+    const int64_t head_dyn = 16LL * (S + 4) + S * 4 + c->OP * 4 + (R + 16) * 2 + 64;
+    return layer_static + layer_dyn <= 160 * 1024 && head_static + head_dyn <= 160 * 1024;
+}
+
+static int pipe_build(wn_ctx* c, Pipe* p) {
+    const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C, O = c->O, OP = c->OP;
+    const int P = GH / 32;
+    p->P = P; p->spx = (L + 7) / 8; p->grid = 8 * (p->spx * P + 1);
+    PipeArgs& a = p->proto; memset(&a, 0, sizeof a);
+    auto al = [](int64_t x) { return (x + 255) / 256 * 256; };
+    int64_t o = 0;
+    a.off_w1c = (int)o; o += 64LL * R * 2;
+    a.off_w1p = (int)o; o += 64LL * (2 * R + C) * 2;
+    a.off_wo = (int)o; o += 32LL * R * 2;
+    a.off_ws = (int)o; o += 32LL * S * 2;
+    a.off_zb = (int)o; o += 256;
+    a.off_ob = (int)o; o += R * 4;
+    a.layer_lds_static = (int)((o + 15) / 16 * 16);
+    p->layer_slice_bytes = al(a.layer_lds_static);
+    int64_t h = 0;
+    a.hoff_wh1 = (int)h; h += (int64_t)S * S * 2;
+    a.hoff_wh2 = (int)h; h += (int64_t)OP * S * 2;
+    a.hoff_b1 = (int)h; h += S * 4;
+    a.hoff_b2 = (int)h; h += OP * 4;
+    a.hoff_sb = (int)h; h += S * 4;
+    a.hoff_win = (int)h; h += R * 4;
+    a.hoff_bin = (int)h; h += R * 4;
+    a.head_lds_static = (int)((h + 15) / 16 * 16);
+    p->head_slice_off = (int64_t)L * P * p->layer_slice_bytes;
+    p->slices_bytes = p->head_slice_off + al(a.head_lds_static);
+    WN_HIP(c, hipMalloc((void**)&p->slices, p->slices_bytes));
+    WN_HIP(c, hipMemset(p->slices, 0, p->slices_bytes));
+    p->layer_lds = a.layer_lds_static + (R * 2 + R * 4 + 16 * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256 * 16 + 64);
+    p->head_lds = a.head_lds_static + (16 * (S + 4) + S * 4 + OP * 4 + (R + 16) * 2 + 64);
+
+    std::vector<SliceJob> jobs; std::vector<int> b0; int nblocks = 0;
+    auto add = [&](SliceJob jb) { b0.push_back(nblocks); const int64_t n = jb.kind == 0 ? (int64_t)jb.kchunks * jb.rows * 8 : jb.rows; nblocks += cdiv(n, 256); jobs.push_back(jb); };
+    auto img = [&](int64_t dst, int64_t src, int rows, int kchunks, int stride_k, int stride_row, float scale, int base, int split) {
+        SliceJob jb; memset(&jb, 0, sizeof jb); jb.dst = dst; jb.src = src; jb.rows = rows; jb.kchunks = kchunks; jb.stride_k = stride_k; jb.stride_row = stride_row;
+        jb.kind = 0; jb.scale = scale; jb.row_perm_base = base; jb.row_perm_split = split; add(jb); };
+    auto vecj = [&](int64_t dst, int64_t src, int rows, float scale, int base, int split) {
+        SliceJob jb; memset(&jb, 0, sizeof jb); jb.dst = dst; jb.src = src; jb.rows = rows; jb.kind = 1; jb.scale = scale; jb.row_perm_base = base; jb.row_perm_split = split; jb.stride_k = -1; add(jb); };
+    for (int l = 0; l < L; ++l) {
+        const WnLayerOffsets& lo = c->lay[l];
+        for (int j = 0; j < P; ++j) {
+            const int64_t base = (int64_t)(l * P + j) * p->layer_slice_bytes;
+            // W1c: current-time tap (kernel index 2, modules.py:306-325); rows = [32 tanh | 32 sigmoid] channels of this CU
+            img(base + a.off_w1c, lo.dil_k + 2LL * R * G, 64, R / 8, G, 1, 1.0f, 32 * j, 32);
+            // W1p: taps t-2d (index 0), t-d (index 1), then the conditioning 1x1
+            img(base + a.off_w1p, lo.dil_k, 64, R / 8, G, 1, 1.0f, 32 * j, 32);
+            img(base + a.off_w1p + 64LL * R * 2, lo.dil_k + 1LL * R * G, 64, R / 8, G, 1, 1.0f, 32 * j, 32);
+            img(base + a.off_w1p + 2 * 64LL * R * 2, lo.cin_k, 64, C / 8, G, 1, 1.0f, 32 * j, 32);
+            // Wo / Ws: the 32 input columns (gate outputs) of this CU; out_k [GH][R], skip_k [GH][S]
+            img(base + a.off_wo, lo.out_k + 32LL * j * R, R, 4, R, 1, 1.0f, 0, 0);
+            img(base + a.off_ws, lo.skip_k + 32LL * j * S, S, 4, S, 1, c->skip_scale[l], 0, 0);
+            vecj(base + a.off_zb, lo.dil_b, 64, 1.0f, 32 * j, 32);          // (+ cin_b: wn_pipe_fixup_kernel)
+            vecj(base + a.off_ob, lo.out_b, R, 1.0f, 0, 0);
+        }
+    }
+    const int64_t hb = p->head_slice_off;
+    img(hb + a.hoff_wh1, c->fin1_k, S, S / 8, S, 1, 1.0f, 0, 0);
+    // (the Wh2 image [kc][OP rows][8] and the summed skip bias are written by wn_pipe_fixup_kernel)
+    vecj(hb + a.hoff_b1, c->fin1_b, S, 1.0f, 0, 0);
+    vecj(hb + a.hoff_b2, c->fin2_b, O, 1.0f, 0, 0);
+    if (c->Cin == 1) { vecj(hb + a.hoff_win, c->first.dil_k, R, 1.0f, 0, 0); vecj(hb + a.hoff_bin, c->first.dil_b, R, 1.0f, 0, 0); }
+    p->njobs = (int)jobs.size(); p->nblocks = nblocks;
+    WN_HIP(c, hipMalloc((void**)&p->jobs_dev, jobs.size() * sizeof(SliceJob)));
+    WN_HIP(c, hipMemcpy(p->jobs_dev, jobs.data(), jobs.size() * sizeof(SliceJob), hipMemcpyHostToDevice));
+    WN_HIP(c, hipMalloc((void**)&p->job_block0_dev, b0.size() * sizeof(int)));
+    WN_HIP(c, hipMemcpy(p->job_block0_dev, b0.data(), b0.size() * sizeof(int), hipMemcpyHostToDevice));
+    WN_HIP(c, hipMalloc((void**)&p->abort_dev, 256));
+    WN_HIP(c, hipStreamCreateWithFlags(&p->priv, hipStreamNonBlocking));
+    WN_HIP(c, hipEventCreateWithFlags(&p->ev0, hipEventDisableTiming));
+    WN_HIP(c, hipEventCreateWithFlags(&p->ev1, hipEventDisableTiming));
+    return WN_OK;
+}
+
+// small fix-up kernels of the slice images: z bias = dil_b + cin_b ; skip bias total ; Wh2 image with row pitch OP
+__global__ void wn_pipe_fixup_kernel(const float* __restrict__ params, char* __restrict__ slices, const PipeArgs a, int64_t layer_slice_bytes,
+                                     const float* __restrict__ skip_bias_total, int64_t fin2_k) {
+    const int l = blockIdx.x / a.P, j = blockIdx.x % a.P;
+    if (blockIdx.x < a.L * a.P) {
+        float* zb = reinterpret_cast<float*>(slices + (int64_t)(l * a.P + j) * layer_slice_bytes + a.off_zb);
+        for (int r = threadIdx.x; r < 64; r += blockDim.x) {
+            const int ch = r < 32 ? 32 * j + r : a.GH + 32 * j + (r - 32);
+            zb[r] += params[a.cin_b_off[l] + ch];
+        }
+    } else {
+        float* sb = reinterpret_cast<float*>(slices + a.head_slice_off + a.hoff_sb);
+        for (int r = threadIdx.x; r < a.S; r += blockDim.x) sb[r] = skip_bias_total[r];
+        // Wh2 image [kc][OP rows][8]
+        bf16_t* w = reinterpret_cast<bf16_t*>(slices + a.head_slice_off + a.hoff_wh2);
+        const int n = (a.S / 8) * a.OP * 8;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int e = i & 7, row = (i >> 3) % a.OP, kc = (i >> 3) / a.OP;
+            w[i] = row < a.O ? f2bf(params[fin2_k + (int64_t)(kc * 8 + e) * a.O + row]) : (bf16_t)0;
+        }
+    }
+}
+
+int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* noise, const void* test_inputs,
+                       void* out_samples, float* out_raw, hipStream_t caller_st) {
+    const int T = Tc * c->hop, L = c->L, R = c->R;
+    if ((int64_t)B * T > c->NT) WN_FAIL(c, WN_E_SHAPE, "synthesis B*T = %d*%d exceeds the workspace (max_batch*max_time = %lld)", B, T, (long long)c->NT);
+    Pipe* p = (Pipe*)c->pipe;
+    int rc;
+    if (!p) { p = new Pipe(); c->pipe = p; if ((rc = pipe_build(c, p))) return rc; }
+    hipStream_t st = p->priv;
+    WN_HIP(c, hipEventRecord(p->ev0, caller_st));
+    WN_HIP(c, hipStreamWaitEvent(st, p->ev0, 0));
+    const int P = p->P;
+    PipeArgs a = p->proto;
+    a.L = L; a.P = P; a.R = R; a.G = c->G; a.GH = c->GH; a.S = c->S; a.O = c->O; a.OP = c->OP; a.C = c->C; a.Cin = c->Cin; a.B = B; a.T = T;
+    a.rho = c->res_scale; a.mode = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE ? 2 : (c->O == 2 ? 1 : 0);
+    a.nps = wn_noise_per_step(c); a.lsmin = a.mode == 1 ? c->cfg.log_scale_min_gauss : c->cfg.log_scale_min; a.start_id = 127; a.spx = p->spx;
+    a.slices = p->slices; a.layer_slice_bytes = p->layer_slice_bytes; a.head_slice_off = p->head_slice_off;
+    // ---- slice images from the current parameters (cheap: 27 MB)
+    {
+        hipLaunchKernelGGL(wn_pipe_slice_kernel, dim3(p->nblocks), dim3(256), 0, st, c->params_dev, p->slices, p->jobs_dev, p->job_block0_dev, p->njobs, c->GH);
+        WN_LAUNCH_CHECK(c);
+        for (int l = 0; l < L; ++l) a.cin_b_off[l] = c->lay[l].cin_b;
+        hipLaunchKernelGGL(wn_pipe_fixup_kernel, dim3(L * P + 1), dim3(256), 0, st, c->params_dev, p->slices, a, p->layer_slice_bytes, c->skip_bias_total, c->fin2_k);
+        WN_LAUNCH_CHECK(c);
+    }
+    // ---- mailboxes, rings
+    const size_t xm = (size_t)(L + 1) * B * P * PIPE_XG * 16, sm = (size_t)(L + 1) * B * P * PIPE_SG * 16;
+    if (xm > p->xm_bytes) { if (p->XM) hipFree(p->XM); WN_HIP(c, hipMalloc((void**)&p->XM, xm)); p->xm_bytes = xm; }
+    if (sm > p->sm_bytes) { if (p->SM) hipFree(p->SM); WN_HIP(c, hipMalloc((void**)&p->SM, sm)); p->sm_bytes = sm; }
+    int64_t roff = 0;
+    for (int l = 0; l < L; ++l) {
+        int slots = 4; while (slots < 2 * c->dil[l] + 1) slots <<= 1;
+        a.ring_mask[l] = slots - 1; a.dil[l] = c->dil[l]; a.ring_off[l] = roff;
+        roff += (int64_t)P * B * slots * R;
+    }
+    if ((size_t)roff * 2 > p->ring_bytes) { if (p->ring) hipFree(p->ring); WN_HIP(c, hipMalloc((void**)&p->ring, (size_t)roff * 2)); p->ring_bytes = (size_t)roff * 2; }
+    WN_HIP(c, hipMemsetAsync(p->XM, 0, xm, st));
+    WN_HIP(c, hipMemsetAsync(p->SM, 0, sm, st));
+    WN_HIP(c, hipMemsetAsync(p->abort_dev, 0, 256, st));
+    a.XM = p->XM; a.SM = p->SM; a.ring = p->ring; a.abort_flag = p->abort_dev;
+    // ---- conditioning for the whole utterance (wavenet.py:781-803): cbt [B*T][C] bf16
+    c->fB = B; c->fT = T; c->fTc = Tc;
+    if ((rc = wn_upsample_fwd(c, nullptr, cin, B, Tc, st))) return rc;
+    a.cbt = c->cbt; a.noise = noise; a.test_inputs = test_inputs; a.out_samples = out_samples; a.out_raw = out_raw;
+    a.win_global = c->params_dev + c->first.dil_k; a.bin_global = c->params_dev + c->first.dil_b;
+    const int lds_bytes = std::max(p->layer_lds, p->head_lds);
+    WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(wn_synth_pipe_kernel, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
+    WN_LAUNCH_CHECK(c);
+    int32_t flag = 0;
+    WN_HIP(c, hipMemcpyAsync(&flag, p->abort_dev, 4, hipMemcpyDeviceToHost, st));
+    WN_HIP(c, hipStreamSynchronize(st));
+    if (flag != 0) WN_FAIL(c, WN_E_HIP, "synthesis pipeline timed out waiting for a hand-off (code %d): are all %d workgroups resident?", flag, p->grid);
+    WN_HIP(c, hipEventRecord(p->ev1, st));
+    WN_HIP(c, hipStreamWaitEvent(caller_st, p->ev1, 0));
+    return WN_OK;
+}
