@@ -130,31 +130,38 @@ def cpu_baseline_subprocess(workload, hard_timeout=150):
         return {'value': None, 'unit': 'audio_samples/s', 'cores': None, 'kind': 'port', 'sample': 'timed out after %d s' % hard_timeout}
 
 
-def measure_synthesis(hp, eng_params_flat, device, seconds=0.25, batches=(1, 8)):
-    """Autoregressive synthesis RTF at hp.sample_rate for `seconds` of audio per stream."""
+def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8)):
+    """Autoregressive synthesis RTF at hp.sample_rate (BASELINE configs[3]: batch {1, 8} x 5 s from fixed mel conditioning).
+    'pipe' = the persistent dataflow pipeline (steps_per_graph=0), timed on the full 5 s clip; 'graph' = the
+    launch-per-layer hipGraph path, timed on 0.25 s (it is ~10x slower) for comparison."""
     from wavenet_vocoder import _ext
     hop = int(np.prod(hp.upsample_scales))
-    Tc = max(2, int(round(seconds * hp.sample_rate / hop)))
-    T = Tc * hop
     out = {}
-    for B in batches:
-        _log('synthesis B=%d T=%d' % (B, T))
-        eng = _ext.Engine(hp, B, T)
-        eng.pack_weights(eng_params_flat)
-        nps = eng.noise_per_step
-        c = torch.rand(B, hp.cin_channels, Tc, device=device)
-        noise = (torch.rand(T, B, nps, device=device) * 0.98 + 0.01) if hp.out_channels != 2 else torch.randn(T, B, nps, device=device)
-        samples = torch.empty(B, T, device=device)
-        eng.synthesize(c, noise, samples, None, None, steps_per_graph=hp.mi355_steps_per_graph)      # warm-up + graph build
-        torch.cuda.synchronize()
-        t0 = time.time()
-        eng.synthesize(c, noise, samples, None, None, steps_per_graph=hp.mi355_steps_per_graph)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-        out['B%d' % B] = {'seconds_of_audio_per_stream': T / hp.sample_rate, 'wall_s': dt,
-                          'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt,
-                          'us_per_step': dt / T * 1e6}
-        eng.close()
+    for mode, secs, spg in (('pipe', seconds, 0), ('graph', min(seconds, 0.25), int(hp.mi355_steps_per_graph) or 16)):
+        Tc = max(2, int(round(secs * hp.sample_rate / hop)))
+        T = Tc * hop
+        for B in batches:
+            _log('synthesis %s B=%d T=%d' % (mode, B, T))
+            eng = _ext.Engine(hp, B, T)
+            eng.pack_weights(eng_params_flat)
+            nps = eng.noise_per_step
+            c = torch.rand(B, hp.cin_channels, Tc, device=device)
+            noise = (torch.rand(T, B, nps, device=device) * 0.98 + 0.01) if hp.out_channels != 2 else torch.randn(T, B, nps, device=device)
+            samples = torch.empty(B, T, device=device)
+            if mode == 'graph':
+                eng.synthesize(c, noise, samples, None, None, steps_per_graph=spg)      # warm-up + graph build
+            else:
+                cw = c[:, :, :8].contiguous(); Tw = 8 * hop                            # short warm-up (weight slices, LDS images)
+                eng.synthesize(cw, noise[:Tw].contiguous(), torch.empty(B, Tw, device=device), None, None, steps_per_graph=0)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            eng.synthesize(c, noise, samples, None, None, steps_per_graph=spg)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            out['%s_B%d' % (mode, B)] = {'seconds_of_audio_per_stream': T / hp.sample_rate, 'wall_s': dt,
+                                        'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt,
+                                        'us_per_step': dt / T * 1e6, 'finite': bool(torch.isfinite(samples).all().item())}
+            eng.close()
     return out
 
 

@@ -24,12 +24,13 @@
 // Every spin loop is bounded; a timeout raises a device flag that makes all workgroups leave.
 #include "wn_common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 #define PIPE_THREADS 256
-#define PIPE_XG 64            // granules per x partial (one per lane): 6 bf16 channels each
+#define PIPE_XG 128           // granule slots per x partial: 4 bf16 channels each (R/4 used; lane g polls g and g+64)
 #define PIPE_SG 128           // granules per skip partial: 3 fp32 channels each
 #define PIPE_SPIN_LIMIT 3000000
 
@@ -44,6 +45,7 @@ struct PipeArgs {
     const float* noise; const void* test_inputs; void* out_samples; float* out_raw;
     const float* win_global; const float* bin_global;
     int32_t* abort_flag;
+    unsigned long long* trace; int32_t trace_t0, trace_n;     // optional timestamps (WN_PIPE_TRACE=1): [trace_n][2*(L+2)] of s_memrealtime
     int64_t ring_off[32]; int64_t cin_b_off[32]; int32_t ring_mask[32]; int32_t dil[32];
 };
 
@@ -56,8 +58,28 @@ __device__ __forceinline__ void ld2_g16(const u32x4* p0, const u32x4* p1, u32x4&
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
 }
+// workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait ~1 us for the acknowledgement
+// of the write-through granule stores that were just issued
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Polling loads as buffer loads with the sc1 cache policy (aux = 16): the compiler tracks them in vmcnt (no hand-written waits).
+// (Keeping 3 polls in flight, one every ~1/3 round trip, was tried: the extra fabric traffic slows EVERY hop, 46 -> 52 us/step.)
+__device__ __forceinline__ u32x4 poll_ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    asm volatile("" ::: "memory");          // keeps successive polls of the same address from being merged
+    return v;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t poll_rsrc(const void* base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000); }
+
 __device__ __forceinline__ bool pipe_aborted(const int32_t* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 __device__ __forceinline__ void pipe_abort(int32_t* f, int code) { __hip_atomic_store(f, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// cross-lane moves on the DPP path (a few cycles) instead of __shfl (ds_bpermute: an LDS round trip each)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+#define DPP_XOR1 0xB1            // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E            // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141    // lane i <- lane 7-i inside every group of 8 (reaches the other quad)
+#define DPP_QUAD_BCAST(k) ((k) * 0x55)
 
 __device__ __forceinline__ float dot8(const uint4 w, const uint4 x, float acc) {
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), __builtin_bit_cast(bf16x2_t, x.x), acc, false);
@@ -133,6 +155,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         bf16_t* xcur_b = reinterpret_cast<bf16_t*>(p); p += R * 2;
         float* xcur_f = reinterpret_cast<float*>(p); p += R * 4;
         float* psum = reinterpret_cast<float*>(p); p += 4 * R * 4;
+        bf16_t* xwave = reinterpret_cast<bf16_t*>(p); p += 4 * R * 2;         // per-wave private copies of x_l(t) (fast path)
         float* zpart = reinterpret_cast<float*>(p); p += 4 * 64 * 4;
         bf16_t* ucur = reinterpret_cast<bf16_t*>(p); p += 64;
         bf16_t* outp = reinterpret_cast<bf16_t*>(p); p += ((R + 7) / 8 * 8 + 8) * 2;
@@ -143,7 +166,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         const int KP = (2 * R + C) / 8;                                    // k-chunks of the past-tap image
         const int nprod = (l == 0) ? 1 : P;
         const bool top = (l == a.L - 1);
-        __syncthreads();
+        lds_barrier();
 
         // z_past for (s, tn): taps x(tn-2d), x(tn-d) from this CU's ring (zero before the utterance), conditioning c(s, tn)
         auto precompute = [&](int s, int tn, bool tap1_is_cur) {
@@ -159,103 +182,166 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 } else v = *reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (k - 2 * R));
                 *reinterpret_cast<uint4*>(vec + k) = v;
             }
-            __syncthreads();
+            lds_barrier();
             {
                 const int per = (KP + 3) / 4, kc0 = wave * per, kc1 = min(KP, kc0 + per);
                 zpart[wave * 64 + lane] = mv_rows(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
             }
-            __syncthreads();
+            lds_barrier();
             if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zb[tid];
-            __syncthreads();
+            lds_barrier();
         };
         for (int s = 0; s < B; ++s) precompute(s, 0, false);
+
+        // ---- fast path (R == 256): the critical-path weights live in REGISTERS for the whole utterance.
+        //   z rows: wave w owns gate pairs 8w..8w+7; lane = (pair = lane>>3, k8 = lane&7: a 32-channel eighth of K) holds BOTH rows
+        //   of its pair (tanh and sigmoid) over its eighth -> 2 x 4 k-chunks = 32 VGPRs; the 8 partial sums are combined with DPP
+        //   (quad xor 1, xor 2, half-row mirror) and the gate is evaluated in the lane that owns the pair: no LDS round trip.
+        //   out rows: thread r owns row r of W_out[:, my 32 columns] -> 4 k-chunks = 16 VGPRs.
+        const bool fast = (R == 256);
+        uint4 w1t[4], w1s[4], wor[4];
+        const int pr = lane >> 3, k8 = lane & 7;
+        const int zrow_t = 8 * wave + pr, zrow_s = 32 + 8 * wave + pr;
+        if (fast) {
+#pragma unroll
+            for (int cix = 0; cix < 4; ++cix) {
+                w1t[cix] = *reinterpret_cast<const uint4*>(W1c + ((size_t)(4 * k8 + cix) * 64 + zrow_t) * 16);
+                w1s[cix] = *reinterpret_cast<const uint4*>(W1c + ((size_t)(4 * k8 + cix) * 64 + zrow_s) * 16);
+            }
+#pragma unroll
+            for (int cix = 0; cix < 4; ++cix) wor[cix] = *reinterpret_cast<const uint4*>(Wo + ((size_t)cix * R + tid) * 16);
+        }
+        const int NXG = R / 4;
 
         for (int t = 0; t < T; ++t) {
             const uint32_t want = (uint32_t)(t + 1);
             for (int s = 0; s < B; ++s) {
-                // ---- 1. x_l(t) = sum of the partial vectors published by the previous stage
+                // ---- 1. x_l(t) = sum of the partial vectors published by the previous stage (granule g = channels 4g..4g+3)
                 {
-                    const u32x4* in = a.XM + ((int64_t)(l * B + s) * P) * PIPE_XG;
-                    float v[6] = {0, 0, 0, 0, 0, 0};
-                    const int p0 = wave, p1 = wave + 4;
-                    if (p0 < nprod) {
-                        int spins = 0;
-                        for (;;) {
-                            u32x4 g0, g1; bool ok;
-                            if (p1 < nprod) { ld2_g16(in + (int64_t)p0 * PIPE_XG + lane, in + (int64_t)p1 * PIPE_XG + lane, g0, g1); ok = (g0.w == want) && (g1.w == want); }
-                            else { g0 = ld_g16(in + (int64_t)p0 * PIPE_XG + lane); g1 = (u32x4){0, 0, 0, 0}; ok = (g0.w == want); }
-                            if (__all(ok)) {
-                                v[0] = bf2f((bf16_t)(g0.x & 0xffff)) + bf2f((bf16_t)(g1.x & 0xffff)); v[1] = bf2f((bf16_t)(g0.x >> 16)) + bf2f((bf16_t)(g1.x >> 16));
-                                v[2] = bf2f((bf16_t)(g0.y & 0xffff)) + bf2f((bf16_t)(g1.y & 0xffff)); v[3] = bf2f((bf16_t)(g0.y >> 16)) + bf2f((bf16_t)(g1.y >> 16));
-                                v[4] = bf2f((bf16_t)(g0.z & 0xffff)) + bf2f((bf16_t)(g1.z & 0xffff)); v[5] = bf2f((bf16_t)(g0.z >> 16)) + bf2f((bf16_t)(g1.z >> 16));
-                                break;
+                    const __amdgpu_buffer_rsrc_t rs = poll_rsrc(a.XM + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
+                    for (int g = lane; g < NXG; g += 64) {
+                        float v[4] = {0, 0, 0, 0};
+                        const int p0 = wave, p1 = wave + 4;
+                        if (p0 < nprod) {
+                            const bool two = p1 < nprod;
+                            const int o0 = (p0 * PIPE_XG + g) * 16, o1 = two ? (p1 * PIPE_XG + g) * 16 : o0;
+                            u32x4 g0, g1;
+                            int spins = 0;
+                            for (;;) {          // ONE poll in flight: more concurrent polls measurably slow every hop (fabric contention)
+                                g0 = poll_ld(rs, o0); g1 = poll_ld(rs, o1);
+                                if (__all(g0.w == want && g1.w == want)) break;
+                                if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 100 + l); break; }
+                                if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
                             }
-                            if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 100 + l); break; }
-                            if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
+                            if (!two) g1 = (u32x4){0, 0, 0, 0};
+                            v[0] = bf2f((bf16_t)(g0.x & 0xffff)) + bf2f((bf16_t)(g1.x & 0xffff)); v[1] = bf2f((bf16_t)(g0.x >> 16)) + bf2f((bf16_t)(g1.x >> 16));
+                            v[2] = bf2f((bf16_t)(g0.y & 0xffff)) + bf2f((bf16_t)(g1.y & 0xffff)); v[3] = bf2f((bf16_t)(g0.y >> 16)) + bf2f((bf16_t)(g1.y >> 16));
                         }
+                        *reinterpret_cast<float4*>(psum + wave * R + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
                     }
+                }
+                lds_barrier();                                                                   // (A) the 4 waves' partial sums
+                if (a.trace && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l] = wall_clock64();
+                if (fast) {
+                    // every wave rebuilds the full bf16 x_l(t) for itself (no second barrier): lane g -> channels 4g..4g+3
+                    bf16_t* myx = xwave + wave * R;
+                    {
+                        const float4 q0 = *reinterpret_cast<const float4*>(psum + lane * 4), q1 = *reinterpret_cast<const float4*>(psum + R + lane * 4);
+                        const float4 q2 = *reinterpret_cast<const float4*>(psum + 2 * R + lane * 4), q3 = *reinterpret_cast<const float4*>(psum + 3 * R + lane * 4);
+                        const uint2 pk = make_uint2(pack_bf2(q0.x + q1.x + q2.x + q3.x, q0.y + q1.y + q2.y + q3.y), pack_bf2(q0.z + q1.z + q2.z + q3.z, q0.w + q1.w + q2.w + q3.w));
+                        *reinterpret_cast<uint2*>(myx + lane * 4) = pk;
+                        if (wave == 0) *reinterpret_cast<uint2*>(xcur_b + lane * 4) = pk;               // the copy the off-critical-path steps read
+                    }
+                    // ---- 2. z = z_past + W_tap2 x ; gate (modules.py:494-510), all inside the wave
+                    float zt = 0.0f, zs = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) { const int ch = lane * 6 + e; if (ch < R) psum[wave * R + ch] = v[e]; }
-                }
-                __syncthreads();
-                if (pipe_aborted(abortf)) return;
-                for (int r = tid; r < R; r += PIPE_THREADS) {
-                    const bf16_t xb = f2bf(psum[r] + psum[R + r] + psum[2 * R + r] + psum[3 * R + r]);
-                    xcur_b[r] = xb; xcur_f[r] = bf2f(xb);
-                }
-                __syncthreads();
-                // ---- 2. z = z_past + W_tap2 x ; gate (modules.py:494-510)
-                {
-                    const int KC = R / 8, per = (KC + 3) / 4, kc0 = wave * per, kc1 = min(KC, kc0 + per);
-                    zpart[wave * 64 + lane] = mv_rows(W1c, 64, lane, reinterpret_cast<const char*>(xcur_b), kc0, kc1);
-                }
-                __syncthreads();
-                if (tid < 32) {
-                    const float za = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zpast[s * 64 + tid];
-                    const float zs = zpart[32 + tid] + zpart[96 + tid] + zpart[160 + tid] + zpart[224 + tid] + zpast[s * 64 + 32 + tid];
-                    const float e = __expf(2.0f * za);
-                    ucur[tid] = f2bf((1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zs))));
-                }
-                __syncthreads();
-                // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0])  -> granules (modules.py:512-521)
-                if (!top) {
-                    for (int r = tid; r < R; r += PIPE_THREADS) {
-                        float o = mv_rows(Wo, R, r, reinterpret_cast<const char*>(ucur), 0, 4);
-                        if (j == 0) o += xcur_f[r] + ob[r];
-                        outp[r] = f2bf(o * a.rho);
+                    for (int cix = 0; cix < 4; ++cix) {
+                        const uint4 xv = *reinterpret_cast<const uint4*>(myx + (4 * k8 + cix) * 8);
+                        zt = dot8(w1t[cix], xv, zt); zs = dot8(w1s[cix], xv, zs);
                     }
-                    if (tid < 8) outp[R + tid] = 0;        // padding read by the last granule
-                    __syncthreads();
-                    if (tid < PIPE_XG) {
-                        u32x4 g = {0, 0, 0, want};
-                        if (tid * 6 < R) {
-                            const uint32_t* q = reinterpret_cast<const uint32_t*>(outp + tid * 6);     // 6 bf16 = 3 words (4-byte aligned: tid*12)
-                            g.x = q[0]; g.y = q[1]; g.z = q[2];
-                            if (tid * 6 + 2 > R) g.y = 0;
-                            if (tid * 6 + 4 > R) g.z = 0;
+                    zt += dpp_f<DPP_XOR1>(zt); zs += dpp_f<DPP_XOR1>(zs);
+                    zt += dpp_f<DPP_XOR2>(zt); zs += dpp_f<DPP_XOR2>(zs);
+                    zt += dpp_f<DPP_HALF_MIRROR>(zt); zs += dpp_f<DPP_HALF_MIRROR>(zs);
+                    if (k8 == 0) {
+                        zt += zpast[s * 64 + zrow_t]; zs += zpast[s * 64 + zrow_s];
+                        const float e = __expf(2.0f * zt);
+                        ucur[8 * wave + pr] = f2bf((1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zs))));
+                    }
+                    lds_barrier();                                                                 // (B) the 32 gate outputs of this CU
+                    // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0]) -> granules (modules.py:512-521)
+                    if (!top) {
+                        float o = 0.0f, o2 = 0.0f;
+                        o = dot8(wor[0], *reinterpret_cast<const uint4*>(ucur), o); o2 = dot8(wor[1], *reinterpret_cast<const uint4*>(ucur + 8), o2);
+                        o = dot8(wor[2], *reinterpret_cast<const uint4*>(ucur + 16), o); o2 = dot8(wor[3], *reinterpret_cast<const uint4*>(ucur + 24), o2);
+                        o += o2;
+                        if (j == 0) o += bf2f(myx[tid]) + ob[tid];
+                        const uint32_t me = f2bf(o * a.rho);
+                        const uint32_t n1 = dpp_u<DPP_QUAD_BCAST(1)>(me), n2 = dpp_u<DPP_QUAD_BCAST(2)>(me), n3 = dpp_u<DPP_QUAD_BCAST(3)>(me);
+                        if (a.trace && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
+                        if ((lane & 3) == 0) {
+                            u32x4 g = {me | (n1 << 16), n2 | (n3 << 16), 0, want};
+                            st_g16(a.XM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + (tid >> 2), g);
                         }
-                        st_g16(a.XM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + tid, g);
+                    }
+                    if (tid < R) xcur_f[tid] = bf2f(myx[tid]);
+                } else {
+                    for (int r = tid; r < R; r += PIPE_THREADS) {
+                        const bf16_t xb = f2bf(psum[r] + psum[R + r] + psum[2 * R + r] + psum[3 * R + r]);
+                        xcur_b[r] = xb; xcur_f[r] = bf2f(xb);
+                    }
+                    lds_barrier();
+                    // ---- 2. z = z_past + W_tap2 x ; gate (modules.py:494-510)
+                    {
+                        const int KC = R / 8, per = (KC + 3) / 4, kc0 = wave * per, kc1 = min(KC, kc0 + per);
+                        zpart[wave * 64 + lane] = mv_rows(W1c, 64, lane, reinterpret_cast<const char*>(xcur_b), kc0, kc1);
+                    }
+                    lds_barrier();
+                    if (tid < 32) {
+                        const float za = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zpast[s * 64 + tid];
+                        const float zs = zpart[32 + tid] + zpart[96 + tid] + zpart[160 + tid] + zpart[224 + tid] + zpast[s * 64 + 32 + tid];
+                        const float e = __expf(2.0f * za);
+                        ucur[tid] = f2bf((1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zs))));
+                    }
+                    lds_barrier();
+                    // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0])  -> granules (modules.py:512-521)
+                    if (!top) {
+                        for (int r = tid; r < R; r += PIPE_THREADS) {
+                            float o = mv_rows(Wo, R, r, reinterpret_cast<const char*>(ucur), 0, 4);
+                            if (j == 0) o += xcur_f[r] + ob[r];
+                            outp[r] = f2bf(o * a.rho);
+                        }
+                        lds_barrier();
+                        for (int g = tid; g < NXG; g += PIPE_THREADS) {
+                            const uint2 q = *reinterpret_cast<const uint2*>(outp + g * 4);
+                            u32x4 gr = {q.x, q.y, 0, want};
+                            st_g16(a.XM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + g, gr);
+                        }
                     }
                 }
+                lds_barrier();
+                if (a.trace && (!fast || top) && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
                 // ---- 4. skip chain: running sum of CU (l-1, j) + W_skip[:, mine] u_mine  -> CU (l+1, j) / head (wavenet.py:833-836)
                 {
                     for (int r = tid; r < S; r += PIPE_THREADS) {
                         const float mine = mv_rows(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
                         float inc = 0.0f;
                         if (l > 0) {
-                            const u32x4* in = a.SM + ((int64_t)(l * B + s) * P + j) * PIPE_SG + r / 3;
+                            const __amdgpu_buffer_rsrc_t rs = poll_rsrc(a.SM + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
+                            const int o = (r / 3) * 16;
+                            u32x4 g;
                             int spins = 0;
                             for (;;) {
-                                const u32x4 g = ld_g16(in);
-                                if (g.w == want) { inc = __uint_as_float(r % 3 == 0 ? g.x : r % 3 == 1 ? g.y : g.z); break; }
+                                g = poll_ld(rs, o);
+                                if (g.w == want) break;
                                 if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 200 + l); break; }
                                 if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
                             }
+                            inc = __uint_as_float(r % 3 == 0 ? g.x : r % 3 == 1 ? g.y : g.z);
                         }
                         skp[r] = inc + mine;
                     }
                     if (tid < 4) skp[S + tid] = 0.0f;
-                    __syncthreads();
+                    lds_barrier();
                     for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
                         u32x4 g = {__float_as_uint(skp[g3 * 3]), __float_as_uint(skp[g3 * 3 + 1]), __float_as_uint(skp[g3 * 3 + 2]), want};
                         st_g16(a.SM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_SG + g3, g);
@@ -294,7 +380,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         float* nxt_f = reinterpret_cast<float*>(p); p += 16;
         int* nxt_i = reinterpret_cast<int*>(p); p += 16;
         const int L = a.L, O = a.O, OP = a.OP, mode = a.mode;
-        __syncthreads();
+        lds_barrier();
 
         // x_0(tn) = input convolution of `value` (wavenet.py:826 / 433-445)  -> layer 0's mailbox
         auto publish_input = [&](int s, int tn) {
@@ -304,69 +390,116 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 else v = win[r] * nxt_f[0] + bin[r];
                 outp[r] = f2bf(v);
             }
-            if (tid < 8) outp[R + tid] = 0;
-            __syncthreads();
-            if (tid < PIPE_XG) {
-                u32x4 g = {0, 0, 0, (uint32_t)(tn + 1)};
-                if (tid * 6 < R) {
-                    const uint32_t* q = reinterpret_cast<const uint32_t*>(outp + tid * 6);
-                    g.x = q[0]; g.y = q[1]; g.z = q[2];
-                    if (tid * 6 + 2 > R) g.y = 0;
-                    if (tid * 6 + 4 > R) g.z = 0;
-                }
-                st_g16(a.XM + ((int64_t)(0 * B + s) * P + 0) * PIPE_XG + tid, g);
+            lds_barrier();
+            for (int g = tid; g < R / 4; g += PIPE_THREADS) {
+                const uint2 q = *reinterpret_cast<const uint2*>(outp + g * 4);
+                u32x4 gr = {q.x, q.y, 0, (uint32_t)(tn + 1)};
+                st_g16(a.XM + ((int64_t)(0 * B + s) * P + 0) * PIPE_XG + g, gr);
             }
-            __syncthreads();
+            lds_barrier();
         };
         if (tid == 0) { nxt_f[0] = 0.0f; nxt_i[0] = a.start_id; }
-        __syncthreads();
+        lds_barrier();
         for (int s = 0; s < B; ++s) publish_input(s, 0);
 
         for (int t = 0; t < T; ++t) {
             const uint32_t want = (uint32_t)(t + 1);
             for (int s = 0; s < B; ++s) {
+                // (prefetch, off the critical path) this step's noise and teacher-forcing value
+                float nz_pre = 0.0f, ti_pre = 0.0f;       // nz_pre: lane i < M: -log(-log u1_i) (Gumbel); lane M: log u2 - log(1 - u2) (logistic)
+                if (mode == 0 && wave == 0) {
+                    const int M = O / 3;
+                    if (lane < a.nps) { const float uu = a.noise[((int64_t)t * B + s) * a.nps + lane]; nz_pre = (lane < M) ? -logf(-logf(uu)) : logf(uu) - logf(1.0f - uu); }
+                    if (a.test_inputs) ti_pre = ((const float*)a.test_inputs)[(int64_t)s * T + t];
+                }
                 // ---- total skip = sum of the P running sums that left the top layer (+ all skip biases), ReLU (wavenet.py:840)
                 {
-                    const u32x4* in = a.SM + ((int64_t)(L * B + s) * P) * PIPE_SG;
+                    const __amdgpu_buffer_rsrc_t rs = poll_rsrc(a.SM + ((int64_t)(L * B + s) * P) * PIPE_SG, P * PIPE_SG * 16);
                     const int ng = (S + 2) / 3;
                     float v[2][3] = {{0, 0, 0}, {0, 0, 0}};
-                    for (int pp = wave; pp < P; pp += 4) {
+                    const bool h0 = lane < ng, h1 = lane + 64 < ng;
+                    const int pa = wave, pb = wave + 4;
+                    if (pa < P) {
+                        // a lane without a granule / a missing second producer re-reads a valid slot (the tag test stays uniform)
+                        const int oa0 = (pa * PIPE_SG + (h0 ? lane : 0)) * 16, oa1 = (pa * PIPE_SG + (h1 ? lane + 64 : 0)) * 16;
+                        const int qb = (pb < P) ? pb : pa;
+                        const int ob0 = (qb * PIPE_SG + (h0 ? lane : 0)) * 16, ob1 = (qb * PIPE_SG + (h1 ? lane + 64 : 0)) * 16;
+                        struct Q { u32x4 a0, a1, b0, b1; };
+                        auto issue = [&]() { Q q; q.a0 = poll_ld(rs, oa0); q.a1 = poll_ld(rs, oa1); q.b0 = poll_ld(rs, ob0); q.b1 = poll_ld(rs, ob1); return q; };
+                        auto good = [&](const Q& q) { return __all(q.a0.w == want && q.a1.w == want && q.b0.w == want && q.b1.w == want) != 0; };
+                        Q g;
                         int spins = 0;
                         for (;;) {
-                            u32x4 g0 = {0, 0, 0, want}, g1 = {0, 0, 0, want};
-                            const bool h0 = lane < ng, h1 = lane + 64 < ng;
-                            if (h0 && h1) ld2_g16(in + (int64_t)pp * PIPE_SG + lane, in + (int64_t)pp * PIPE_SG + lane + 64, g0, g1);
-                            else if (h0) g0 = ld_g16(in + (int64_t)pp * PIPE_SG + lane);
-                            const bool ok = (g0.w == want) && (g1.w == want);
-                            if (__all(ok)) {
-                                v[0][0] += __uint_as_float(g0.x); v[0][1] += __uint_as_float(g0.y); v[0][2] += __uint_as_float(g0.z);
-                                v[1][0] += __uint_as_float(g1.x); v[1][1] += __uint_as_float(g1.y); v[1][2] += __uint_as_float(g1.z);
-                                break;
-                            }
+                            g = issue();
+                            if (good(g)) break;
                             if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 300); break; }
                             if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
                         }
+                        const float fb = (pb < P) ? 1.0f : 0.0f;
+                        if (h0) { v[0][0] = __uint_as_float(g.a0.x) + fb * __uint_as_float(g.b0.x); v[0][1] = __uint_as_float(g.a0.y) + fb * __uint_as_float(g.b0.y); v[0][2] = __uint_as_float(g.a0.z) + fb * __uint_as_float(g.b0.z); }
+                        if (h1) { v[1][0] = __uint_as_float(g.a1.x) + fb * __uint_as_float(g.b1.x); v[1][1] = __uint_as_float(g.a1.y) + fb * __uint_as_float(g.b1.y); v[1][2] = __uint_as_float(g.a1.z) + fb * __uint_as_float(g.b1.z); }
                     }
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                         for (int e = 0; e < 3; ++e) { const int ch = (lane + 64 * hh) * 3 + e; if (ch < S) psum[wave * (S + 4) + ch] = v[hh][e]; }
                 }
-                __syncthreads();
-                if (pipe_aborted(abortf)) return;
+                lds_barrier();
+                if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L] = wall_clock64();
                 for (int r = tid; r < S; r += PIPE_THREADS) {
                     float tot = sb[r];
                     for (int w = 0; w < 4 && w < P; ++w) tot += psum[w * (S + 4) + r];
                     r1[r] = f2bf(fmaxf(tot, 0.0f));
                 }
-                __syncthreads();
+                lds_barrier();
                 // ---- head convolutions (wavenet.py:840-844)
-                for (int r = tid; r < S; r += PIPE_THREADS) h2[r] = f2bf(fmaxf(mv_rows(Wh1, S, r, reinterpret_cast<const char*>(r1), 0, S / 8) + b1[r], 0.0f));
-                __syncthreads();
-                for (int r = tid; r < OP; r += PIPE_THREADS) yraw[r] = (r < O) ? mv_rows(Wh2, OP, r, reinterpret_cast<const char*>(h2), 0, S / 8) + b2[r] : 0.0f;
-                __syncthreads();
-                // ---- sample (wavenet.py:847-878); noise [T][B][nps]
-                if (tid == 0) {
+                if (S == 256) {          // fully unrolled: every LDS read of a row is in flight before the first dot product
+                    uint4 wv[32];
+#pragma unroll
+                    for (int kc = 0; kc < 32; ++kc) wv[kc] = *reinterpret_cast<const uint4*>(Wh1 + ((size_t)kc * 256 + tid) * 16);
+                    float h0 = 0.0f, h1 = 0.0f, h2a = 0.0f, h3 = 0.0f;
+#pragma unroll
+                    for (int kc = 0; kc < 32; kc += 4) {
+                        h0 = dot8(wv[kc], *reinterpret_cast<const uint4*>(r1 + kc * 8), h0); h1 = dot8(wv[kc + 1], *reinterpret_cast<const uint4*>(r1 + (kc + 1) * 8), h1);
+                        h2a = dot8(wv[kc + 2], *reinterpret_cast<const uint4*>(r1 + (kc + 2) * 8), h2a); h3 = dot8(wv[kc + 3], *reinterpret_cast<const uint4*>(r1 + (kc + 3) * 8), h3);
+                    }
+                    h2[tid] = f2bf(fmaxf((h0 + h1) + (h2a + h3) + b1[tid], 0.0f));
+                } else {
+                    for (int r = tid; r < S; r += PIPE_THREADS) h2[r] = f2bf(fmaxf(mv_rows(Wh1, S, r, reinterpret_cast<const char*>(r1), 0, S / 8) + b1[r], 0.0f));
+                }
+                lds_barrier();
+                if (S == 256 && OP == 32) {      // thread = (row = tid >> 3, k-eighth = tid & 7): 4 chunks each, summed with DPP
+                    const int row = tid >> 3, ke = tid & 7;
+                    float y = 0.0f;
+#pragma unroll
+                    for (int cix = 0; cix < 4; ++cix) y = dot8(*reinterpret_cast<const uint4*>(Wh2 + ((size_t)(ke * 4 + cix) * 32 + row) * 16), *reinterpret_cast<const uint4*>(h2 + (ke * 4 + cix) * 8), y);
+                    y += __shfl_xor(y, 1); y += __shfl_xor(y, 2); y += __shfl_xor(y, 4);
+                    if (ke == 0) yraw[row] = (row < O) ? y + b2[row] : 0.0f;
+                } else {
+                    for (int r = tid; r < OP; r += PIPE_THREADS) yraw[r] = (r < O) ? mv_rows(Wh2, OP, r, reinterpret_cast<const char*>(h2), 0, S / 8) + b2[r] : 0.0f;
+                }
+                lds_barrier();
+                if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 1] = wall_clock64();
+                // ---- sample (wavenet.py:847-878); noise [T][B][nps] was prefetched while the message was in the stack
+                if (mode == 0 && O / 3 <= 16) {
+                    if (wave == 0) {         // mixture.py:76-107: Gumbel-max over the mixture logits (first maximum wins), then the logistic
+                        const int M = O / 3;
+                        float v = (lane < M) ? yraw[lane] + nz_pre : -INFINITY; int bi = lane;
+#pragma unroll
+                        for (int off = 8; off >= 1; off >>= 1) {
+                            const float ov = __shfl_xor(v, off); const int oi = __shfl_xor(bi, off);
+                            if (ov > v || (ov == v && oi < bi)) { v = ov; bi = oi; }
+                        }
+                        const float lgt = __shfl(nz_pre, M);
+                        if (lane == 0) {
+                            const float ls = fmaxf(yraw[2 * M + bi], a.lsmin);
+                            float x = yraw[M + bi] + expf(ls) * lgt;
+                            x = fminf(fmaxf(x, -1.0f), 1.0f);
+                            ((float*)a.out_samples)[(int64_t)s * T + t] = x;
+                            nxt_f[0] = a.test_inputs ? ti_pre : x;
+                        }
+                    }
+                } else if (tid == 0) {
                     const float* nz = a.noise + ((int64_t)t * B + s) * a.nps;
                     if (mode == 2) {
                         float best = -INFINITY; int bi = 0;
@@ -389,8 +522,10 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     }
                 }
                 if (a.out_raw) for (int o = tid; o < O; o += PIPE_THREADS) a.out_raw[((int64_t)s * O + o) * T + t] = yraw[o];
-                __syncthreads();
+                lds_barrier();
+                if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 2] = wall_clock64();
                 if (t + 1 < T) publish_input(s, t + 1);
+                if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 3] = wall_clock64();
                 if (pipe_aborted(abortf)) return;
             }
         }
@@ -422,13 +557,13 @@ void wn_pipe_free(wn_ctx* c) {
 // can this model run on the persistent pipeline?  (one CU per 32 gate pairs, all of a CU's weights in 160 KiB of LDS)
 bool wn_pipe_eligible(const wn_ctx* c, int B) {
     const int R = c->R, S = c->S, C = c->C, GH = c->GH, L = c->L;
-    if (GH % 32 || R % 8 || S % 8 || C % 8 || S % 3 == 99) return false;
+    if (GH % 32 || R % 8 || S % 8 || C % 8 || R > 512) return false;
     const int P = GH / 32;
     if (P > 8 || L > 32 || B > 16 || R > 384 || S > 384 || c->OP > 256) return false;
     const int spx = (L + 7) / 8;
     if (spx * P + 1 > 30) return false;                 // 32 CUs per XCD, keep slack
     const int64_t layer_static = 64LL * R * 2 + 64LL * (2 * R + C) * 2 + 32LL * R * 2 + 32LL * S * 2 + 256 + R * 4;
-    const int64_t layer_dyn = R * 2 + R * 4 + 16LL * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256LL * B + 64;
+    const int64_t layer_dyn = R * 2 + R * 4 + 16LL * R + 8LL * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256LL * B + 64;
     const int64_t head_static = (int64_t)S * S * 2 + (int64_t)c->OP * S * 2 + S * 4 * 2 + c->OP * 4 + R * 8 + 64;
     const int64_t head_dyn = 16LL * (S + 4) + S * 4 + c->OP * 4 + (R + 16) * 2 + 64;
     return layer_static + layer_dyn <= 160 * 1024 && head_static + head_dyn <= 160 * 1024;
@@ -462,7 +597,7 @@ static int pipe_build(wn_ctx* c, Pipe* p) {
     p->slices_bytes = p->head_slice_off + al(a.head_lds_static);
     WN_HIP(c, hipMalloc((void**)&p->slices, p->slices_bytes));
     WN_HIP(c, hipMemset(p->slices, 0, p->slices_bytes));
-    p->layer_lds = a.layer_lds_static + (R * 2 + R * 4 + 16 * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256 * 16 + 64);
+    p->layer_lds = a.layer_lds_static + (R * 2 + R * 4 + 16 * R + 8 * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256 * 16 + 64);
     p->head_lds = a.head_lds_static + (16 * (S + 4) + S * 4 + OP * 4 + (R + 16) * 2 + 64);
 
     std::vector<SliceJob> jobs; std::vector<int> b0; int nblocks = 0;
@@ -574,6 +709,12 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     if ((rc = wn_upsample_fwd(c, nullptr, cin, B, Tc, st))) return rc;
     a.cbt = c->cbt; a.noise = noise; a.test_inputs = test_inputs; a.out_samples = out_samples; a.out_raw = out_raw;
     a.win_global = c->params_dev + c->first.dil_k; a.bin_global = c->params_dev + c->first.dil_b;
+    unsigned long long* trace_dev = nullptr; const int trace_n = 32;
+    if (getenv("WN_PIPE_TRACE") && T > 600) {
+        WN_HIP(c, hipMalloc((void**)&trace_dev, (size_t)trace_n * 2 * (L + 2) * 8));
+        WN_HIP(c, hipMemsetAsync(trace_dev, 0, (size_t)trace_n * 2 * (L + 2) * 8, st));
+        a.trace = trace_dev; a.trace_t0 = 500; a.trace_n = trace_n;
+    }
     const int lds_bytes = std::max(p->layer_lds, p->head_lds);
     WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(wn_synth_pipe_kernel, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
@@ -581,6 +722,24 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     int32_t flag = 0;
     WN_HIP(c, hipMemcpyAsync(&flag, p->abort_dev, 4, hipMemcpyDeviceToHost, st));
     WN_HIP(c, hipStreamSynchronize(st));
+    if (trace_dev) {      // per-stage latencies in units of the 100 MHz real-time counter (10 ns)
+        std::vector<unsigned long long> h((size_t)trace_n * 2 * (L + 2));
+        hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost); hipFree(trace_dev);
+        const int W = 2 * (L + 2);
+        std::vector<double> hop(L + 1, 0.0), comp(L, 0.0); double hskip = 0, hconv = 0, hsamp = 0, hpub = 0, step = 0;
+        for (int i = 0; i < trace_n; ++i) {
+            const unsigned long long* r = &h[(size_t)i * W];
+            for (int l = 0; l < L; ++l) { comp[l] += (double)(r[2 * l + 1] - r[2 * l]); if (l > 0) hop[l] += (double)(r[2 * l] - r[2 * (l - 1) + 1]); }
+            hskip += (double)(r[2 * L] - r[2 * (L - 1) + 1]); hconv += (double)(r[2 * L + 1] - r[2 * L]); hsamp += (double)(r[2 * L + 2] - r[2 * L + 1]); hpub += (double)(r[2 * L + 3] - r[2 * L + 2]);
+            if (i + 1 < trace_n) { hop[0] += (double)(h[(size_t)(i + 1) * W] - r[2 * L + 3]); step += (double)(h[(size_t)(i + 1) * W] - r[0]); }
+        }
+        fprintf(stderr, "[pipe trace] us: step %.2f | head: skip-wait %.2f conv %.2f sample %.2f publish %.2f | head->L0 hop %.2f\n", step / (trace_n - 1) / 100.0,
+                hskip / trace_n / 100.0, hconv / trace_n / 100.0, hsamp / trace_n / 100.0, hpub / trace_n / 100.0, hop[0] / (trace_n - 1) / 100.0);
+        fprintf(stderr, "[pipe trace] per layer (hop-in, compute) us:");
+        for (int l = 0; l < L; ++l) fprintf(stderr, " %d:(%.2f,%.2f)", l, l ? hop[l] / trace_n / 100.0 : 0.0, comp[l] / trace_n / 100.0);
+        fprintf(stderr, "\n[pipe trace] head us: skip-wait %.2f conv %.2f sample %.2f publish %.2f | head->L0 hop %.2f | step %.2f\n", hskip / trace_n / 100.0, hconv / trace_n / 100.0,
+                hsamp / trace_n / 100.0, hpub / trace_n / 100.0, hop[0] / (trace_n - 1) / 100.0, step / (trace_n - 1) / 100.0);
+    }
     if (flag != 0) WN_FAIL(c, WN_E_HIP, "synthesis pipeline timed out waiting for a hand-off (code %d): are all %d workgroups resident?", flag, p->grid);
     WN_HIP(c, hipEventRecord(p->ev1, st));
     WN_HIP(c, hipStreamWaitEvent(caller_st, p->ev1, 0));
