@@ -40,7 +40,9 @@ struct PipeArgs {
     const char* slices; int64_t layer_slice_bytes, head_slice_off;
     int32_t off_w1c, off_w1p, off_wo, off_ws, off_zb, off_ob, layer_lds_static;      // byte offsets inside a layer slice / LDS image
     int32_t hoff_wh1, hoff_wh2, hoff_b1, hoff_b2, hoff_sb, hoff_win, hoff_bin, head_lds_static;
-    u32x4* XM; u32x4* SM;
+    u32x4* XM; u32x4* SM;            // mailboxes written with write-through (sc1) stores: visible to every XCD
+    u32x4* XML; u32x4* SML;          // the same mailboxes written with plain stores: they live in the WRITER's XCD L2, readable (sc1 loads) by CUs of that XCD only
+    int32_t* xcc_tab;                // [grid] XCC id + 1 of every workgroup (0 = not started)
     bf16_t* ring; const bf16_t* cbt;
     const float* noise; const void* test_inputs; void* out_samples; float* out_raw;
     const float* win_global; const float* bin_global;
@@ -51,6 +53,7 @@ struct PipeArgs {
 
 // ---- granule I/O: 16 bytes, one write-through store / one L1-bypassing load ------------------------------------------
 __device__ __forceinline__ void st_g16(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_g16_local(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ u32x4 ld_g16(const u32x4* p) {
     u32x4 v; asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v;
 }
@@ -140,6 +143,21 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
     else if (slot == layer_slots && xcd == 0) is_head = true;
     else return;
     int32_t* const abortf = a.abort_flag;
+    // ---- which XCD am I really on?  (block -> XCD = b % 8 is observed, not guaranteed: the table makes the fast path a pure
+    // speed choice -- a hand-off whose two ends share an XCD uses the plain-store copy of the mailbox, served by that XCD's L2
+    // in about half the round trip of the write-through copy)
+    int my_xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc)); my_xcc &= 0xf;
+    if (threadIdx.x == 0) __hip_atomic_store(a.xcc_tab + blockIdx.x, my_xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto block_of = [&](int lay, int jj) { return (((lay % a.spx) * P + jj) << 3) | (lay / a.spx); };     // inverse of the role map
+    const int head_block = (a.spx * P) << 3;
+    auto same_xcc = [&](int block) {
+        int v = 0, spins = 0;
+        while ((v = __hip_atomic_load(a.xcc_tab + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 50); break; }
+        }
+        return v - 1 == my_xcc;
+    };
 
     if (!is_head) {
         // ================================================================= layer CU (layer, j)
@@ -165,6 +183,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         const int d = a.dil[l], mask = a.ring_mask[l];
         const int KP = (2 * R + C) / 8;                                    // k-chunks of the past-tap image
         const int nprod = (l == 0) ? 1 : P;
+        const bool loc0 = (wave < nprod) && same_xcc(l == 0 ? head_block : block_of(l - 1, wave));
+        const bool loc1 = (wave + 4 < nprod) && same_xcc(block_of(l - 1, wave + 4));
+        const bool loc_skip = (l > 0) && same_xcc(block_of(l - 1, j));
         const bool top = (l == a.L - 1);
         lds_barrier();
 
@@ -218,7 +239,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
             for (int s = 0; s < B; ++s) {
                 // ---- 1. x_l(t) = sum of the partial vectors published by the previous stage (granule g = channels 4g..4g+3)
                 {
-                    const __amdgpu_buffer_rsrc_t rs = poll_rsrc(a.XM + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
+                    const __amdgpu_buffer_rsrc_t rs0 = poll_rsrc((loc0 ? a.XML : a.XM) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
+                    const __amdgpu_buffer_rsrc_t rs1 = poll_rsrc((loc1 ? a.XML : a.XM) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
                     for (int g = lane; g < NXG; g += 64) {
                         float v[4] = {0, 0, 0, 0};
                         const int p0 = wave, p1 = wave + 4;
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                             u32x4 g0, g1;
                             int spins = 0;
                             for (;;) {          // ONE poll in flight: more concurrent polls measurably slow every hop (fabric contention)
-                                g0 = poll_ld(rs, o0); g1 = poll_ld(rs, o1);
+                                g0 = poll_ld(rs0, o0); g1 = poll_ld(two ? rs1 : rs0, o1);
                                 if (__all(g0.w == want && g1.w == want)) break;
                                 if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 100 + l); break; }
                                 if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
@@ -265,7 +287,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     if (k8 == 0) {
                         zt += zpast[s * 64 + zrow_t]; zs += zpast[s * 64 + zrow_s];
                         const float e = __expf(2.0f * zt);
-                        ucur[8 * wave + pr] = f2bf((1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zs))));
+                        ucur[8 * wave + pr] = f2bf((1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f)) * __builtin_amdgcn_rcpf(1.0f + __expf(-zs)));
                     }
                     lds_barrier();                                                                 // (B) the 32 gate outputs of this CU
                     // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0]) -> granules (modules.py:512-521)
@@ -280,7 +302,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         if (a.trace && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
                         if ((lane & 3) == 0) {
                             u32x4 g = {me | (n1 << 16), n2 | (n3 << 16), 0, want};
-                            st_g16(a.XM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + (tid >> 2), g);
+                            const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + (tid >> 2);
+                            st_g16_local(a.XML + gi, g); st_g16(a.XM + gi, g);
                         }
                     }
                     if (tid < R) xcur_f[tid] = bf2f(myx[tid]);
@@ -314,7 +337,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         for (int g = tid; g < NXG; g += PIPE_THREADS) {
                             const uint2 q = *reinterpret_cast<const uint2*>(outp + g * 4);
                             u32x4 gr = {q.x, q.y, 0, want};
-                            st_g16(a.XM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + g, gr);
+                            const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + g;
+                            st_g16_local(a.XML + gi, gr); st_g16(a.XM + gi, gr);
                         }
                     }
                 }
@@ -322,29 +346,31 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 if (a.trace && (!fast || top) && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
                 // ---- 4. skip chain: running sum of CU (l-1, j) + W_skip[:, mine] u_mine  -> CU (l+1, j) / head (wavenet.py:833-836)
                 {
-                    for (int r = tid; r < S; r += PIPE_THREADS) {
-                        const float mine = mv_rows(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
-                        float inc = 0.0f;
-                        if (l > 0) {
-                            const __amdgpu_buffer_rsrc_t rs = poll_rsrc(a.SM + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
-                            const int o = (r / 3) * 16;
+                    // own contribution first (the running sum of CU (l-1, j) is published ~1 us after its x partial: no point in
+                    // polling early, and every useless poll slows somebody's critical hop)
+                    for (int r = tid; r < S; r += PIPE_THREADS) skp[r] = mv_rows(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
+                    if (tid < 4) skp[S + tid] = 0.0f;
+                    lds_barrier();
+                    if (l > 0) {       // one poll per GRANULE (3 channels), by the first (S+2)/3 threads
+                        const __amdgpu_buffer_rsrc_t rs = poll_rsrc((loc_skip ? a.SML : a.SM) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
+                        for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
                             u32x4 g;
                             int spins = 0;
                             for (;;) {
-                                g = poll_ld(rs, o);
+                                g = poll_ld(rs, g3 * 16);
                                 if (g.w == want) break;
+                                __builtin_amdgcn_s_sleep(2);
                                 if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 200 + l); break; }
                                 if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
                             }
-                            inc = __uint_as_float(r % 3 == 0 ? g.x : r % 3 == 1 ? g.y : g.z);
+                            skp[g3 * 3] += __uint_as_float(g.x); skp[g3 * 3 + 1] += __uint_as_float(g.y); skp[g3 * 3 + 2] += __uint_as_float(g.z);
                         }
-                        skp[r] = inc + mine;
                     }
-                    if (tid < 4) skp[S + tid] = 0.0f;
                     lds_barrier();
                     for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
                         u32x4 g = {__float_as_uint(skp[g3 * 3]), __float_as_uint(skp[g3 * 3 + 1]), __float_as_uint(skp[g3 * 3 + 2]), want};
-                        st_g16(a.SM + ((int64_t)((l + 1) * B + s) * P + j) * PIPE_SG + g3, g);
+                        const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_SG + g3;
+                        st_g16_local(a.SML + gi, g); st_g16(a.SM + gi, g);
                     }
                 }
                 // ---- 5. queue update (private ring) and the pre-multiplication for this stream's next step
@@ -380,7 +406,17 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         float* nxt_f = reinterpret_cast<float*>(p); p += 16;
         int* nxt_i = reinterpret_cast<int*>(p); p += 16;
         const int L = a.L, O = a.O, OP = a.OP, mode = a.mode;
+        const bool hloc0 = (wave < P) && same_xcc(block_of(L - 1, wave)), hloc1 = (wave + 4 < P) && same_xcc(block_of(L - 1, wave + 4));
         lds_barrier();
+        // fast head (S == 256, O <= 32): both head convolutions multiply from REGISTERS (128 + 16 VGPRs of weights per thread)
+        const bool hfast = (S == 256 && OP == 32);
+        uint4 wh1r[32], wh2r[4];
+        if (hfast) {
+#pragma unroll
+            for (int kc = 0; kc < 32; ++kc) wh1r[kc] = *reinterpret_cast<const uint4*>(Wh1 + ((size_t)kc * 256 + tid) * 16);
+#pragma unroll
+            for (int cix = 0; cix < 4; ++cix) wh2r[cix] = *reinterpret_cast<const uint4*>(Wh2 + ((size_t)((tid & 7) * 4 + cix) * 32 + (tid >> 3)) * 16);
+        }
 
         // x_0(tn) = input convolution of `value` (wavenet.py:826 / 433-445)  -> layer 0's mailbox
         auto publish_input = [&](int s, int tn) {
@@ -394,7 +430,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
             for (int g = tid; g < R / 4; g += PIPE_THREADS) {
                 const uint2 q = *reinterpret_cast<const uint2*>(outp + g * 4);
                 u32x4 gr = {q.x, q.y, 0, (uint32_t)(tn + 1)};
-                st_g16(a.XM + ((int64_t)(0 * B + s) * P + 0) * PIPE_XG + g, gr);
+                const int64_t gi = ((int64_t)(0 * B + s) * P + 0) * PIPE_XG + g;
+                st_g16_local(a.XML + gi, gr); st_g16(a.XM + gi, gr);
             }
             lds_barrier();
         };
@@ -414,7 +451,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 }
                 // ---- total skip = sum of the P running sums that left the top layer (+ all skip biases), ReLU (wavenet.py:840)
                 {
-                    const __amdgpu_buffer_rsrc_t rs = poll_rsrc(a.SM + ((int64_t)(L * B + s) * P) * PIPE_SG, P * PIPE_SG * 16);
+                    const __amdgpu_buffer_rsrc_t rsa = poll_rsrc((hloc0 ? a.SML : a.SM) + ((int64_t)(L * B + s) * P) * PIPE_SG, P * PIPE_SG * 16);
+                    const __amdgpu_buffer_rsrc_t rsb = poll_rsrc((hloc1 ? a.SML : a.SM) + ((int64_t)(L * B + s) * P) * PIPE_SG, P * PIPE_SG * 16);
                     const int ng = (S + 2) / 3;
                     float v[2][3] = {{0, 0, 0}, {0, 0, 0}};
                     const bool h0 = lane < ng, h1 = lane + 64 < ng;
@@ -425,7 +463,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         const int qb = (pb < P) ? pb : pa;
                         const int ob0 = (qb * PIPE_SG + (h0 ? lane : 0)) * 16, ob1 = (qb * PIPE_SG + (h1 ? lane + 64 : 0)) * 16;
                         struct Q { u32x4 a0, a1, b0, b1; };
-                        auto issue = [&]() { Q q; q.a0 = poll_ld(rs, oa0); q.a1 = poll_ld(rs, oa1); q.b0 = poll_ld(rs, ob0); q.b1 = poll_ld(rs, ob1); return q; };
+                        auto issue = [&]() { Q q; q.a0 = poll_ld(rsa, oa0); q.a1 = poll_ld(rsa, oa1); q.b0 = poll_ld(pb < P ? rsb : rsa, ob0); q.b1 = poll_ld(pb < P ? rsb : rsa, ob1); return q; };
                         auto good = [&](const Q& q) { return __all(q.a0.w == want && q.a1.w == want && q.b0.w == want && q.b1.w == want) != 0; };
                         Q g;
                         int spins = 0;
@@ -453,27 +491,24 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 }
                 lds_barrier();
                 // ---- head convolutions (wavenet.py:840-844)
-                if (S == 256) {          // fully unrolled: every LDS read of a row is in flight before the first dot product
-                    uint4 wv[32];
-#pragma unroll
-                    for (int kc = 0; kc < 32; ++kc) wv[kc] = *reinterpret_cast<const uint4*>(Wh1 + ((size_t)kc * 256 + tid) * 16);
+                if (hfast) {
                     float h0 = 0.0f, h1 = 0.0f, h2a = 0.0f, h3 = 0.0f;
 #pragma unroll
                     for (int kc = 0; kc < 32; kc += 4) {
-                        h0 = dot8(wv[kc], *reinterpret_cast<const uint4*>(r1 + kc * 8), h0); h1 = dot8(wv[kc + 1], *reinterpret_cast<const uint4*>(r1 + (kc + 1) * 8), h1);
-                        h2a = dot8(wv[kc + 2], *reinterpret_cast<const uint4*>(r1 + (kc + 2) * 8), h2a); h3 = dot8(wv[kc + 3], *reinterpret_cast<const uint4*>(r1 + (kc + 3) * 8), h3);
+                        h0 = dot8(wh1r[kc], *reinterpret_cast<const uint4*>(r1 + kc * 8), h0); h1 = dot8(wh1r[kc + 1], *reinterpret_cast<const uint4*>(r1 + (kc + 1) * 8), h1);
+                        h2a = dot8(wh1r[kc + 2], *reinterpret_cast<const uint4*>(r1 + (kc + 2) * 8), h2a); h3 = dot8(wh1r[kc + 3], *reinterpret_cast<const uint4*>(r1 + (kc + 3) * 8), h3);
                     }
                     h2[tid] = f2bf(fmaxf((h0 + h1) + (h2a + h3) + b1[tid], 0.0f));
                 } else {
                     for (int r = tid; r < S; r += PIPE_THREADS) h2[r] = f2bf(fmaxf(mv_rows(Wh1, S, r, reinterpret_cast<const char*>(r1), 0, S / 8) + b1[r], 0.0f));
                 }
                 lds_barrier();
-                if (S == 256 && OP == 32) {      // thread = (row = tid >> 3, k-eighth = tid & 7): 4 chunks each, summed with DPP
+                if (hfast) {      // thread = (row = tid >> 3, k-eighth = tid & 7): 4 chunks each, summed with DPP
                     const int row = tid >> 3, ke = tid & 7;
                     float y = 0.0f;
 #pragma unroll
-                    for (int cix = 0; cix < 4; ++cix) y = dot8(*reinterpret_cast<const uint4*>(Wh2 + ((size_t)(ke * 4 + cix) * 32 + row) * 16), *reinterpret_cast<const uint4*>(h2 + (ke * 4 + cix) * 8), y);
-                    y += __shfl_xor(y, 1); y += __shfl_xor(y, 2); y += __shfl_xor(y, 4);
+                    for (int cix = 0; cix < 4; ++cix) y = dot8(wh2r[cix], *reinterpret_cast<const uint4*>(h2 + (ke * 4 + cix) * 8), y);
+                    y += dpp_f<DPP_XOR1>(y); y += dpp_f<DPP_XOR2>(y); y += dpp_f<DPP_HALF_MIRROR>(y);
                     if (ke == 0) yraw[row] = (row < O) ? y + b2[row] : 0.0f;
                 } else {
                     for (int r = tid; r < OP; r += PIPE_THREADS) yraw[r] = (r < O) ? mv_rows(Wh2, OP, r, reinterpret_cast<const char*>(h2), 0, S / 8) + b2[r] : 0.0f;
@@ -485,11 +520,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     if (wave == 0) {         // mixture.py:76-107: Gumbel-max over the mixture logits (first maximum wins), then the logistic
                         const int M = O / 3;
                         float v = (lane < M) ? yraw[lane] + nz_pre : -INFINITY; int bi = lane;
-#pragma unroll
-                        for (int off = 8; off >= 1; off >>= 1) {
-                            const float ov = __shfl_xor(v, off); const int oi = __shfl_xor(bi, off);
-                            if (ov > v || (ov == v && oi < bi)) { v = ov; bi = oi; }
-                        }
+#define ARGMAX_STEP(CTRL) { const float ov = dpp_f<CTRL>(v); const int oi = (int)dpp_u<CTRL>((uint32_t)bi); if (ov > v || (ov == v && oi < bi)) { v = ov; bi = oi; } }
+                        ARGMAX_STEP(DPP_XOR1) ARGMAX_STEP(DPP_XOR2) ARGMAX_STEP(DPP_HALF_MIRROR) ARGMAX_STEP(0x140 /* row_mirror: the other half of the 16 */)
+#undef ARGMAX_STEP
                         const float lgt = __shfl(nz_pre, M);
                         if (lane == 0) {
                             const float ls = fmaxf(yraw[2 * M + bi], a.lsmin);
@@ -537,7 +570,7 @@ struct Pipe {
     int B = 0, T = 0, P = 0, spx = 0, grid = 0;
     char* slices = nullptr; int64_t layer_slice_bytes = 0, head_slice_off = 0, slices_bytes = 0;
     SliceJob* jobs_dev = nullptr; int* job_block0_dev = nullptr; int njobs = 0, nblocks = 0;
-    u32x4* XM = nullptr; u32x4* SM = nullptr; size_t xm_bytes = 0, sm_bytes = 0;
+    u32x4* XM = nullptr; u32x4* SM = nullptr; u32x4* XML = nullptr; u32x4* SML = nullptr; size_t xm_bytes = 0, sm_bytes = 0;
     bf16_t* ring = nullptr; size_t ring_bytes = 0; int ring_B = 0;
     int32_t* abort_dev = nullptr;
     int layer_lds = 0, head_lds = 0;
@@ -549,7 +582,7 @@ void wn_pipe_free(wn_ctx* c) {
     Pipe* p = (Pipe*)c->pipe;
     if (!p) return;
     if (p->slices) hipFree(p->slices); if (p->jobs_dev) hipFree(p->jobs_dev); if (p->job_block0_dev) hipFree(p->job_block0_dev);
-    if (p->XM) hipFree(p->XM); if (p->SM) hipFree(p->SM); if (p->ring) hipFree(p->ring); if (p->abort_dev) hipFree(p->abort_dev);
+    if (p->XM) hipFree(p->XM); if (p->SM) hipFree(p->SM); if (p->XML) hipFree(p->XML); if (p->SML) hipFree(p->SML); if (p->ring) hipFree(p->ring); if (p->abort_dev) hipFree(p->abort_dev);
     if (p->ev0) hipEventDestroy(p->ev0); if (p->ev1) hipEventDestroy(p->ev1); if (p->priv) hipStreamDestroy(p->priv);
     delete p; c->pipe = nullptr;
 }
@@ -635,7 +668,7 @@ static int pipe_build(wn_ctx* c, Pipe* p) {
     WN_HIP(c, hipMemcpy(p->jobs_dev, jobs.data(), jobs.size() * sizeof(SliceJob), hipMemcpyHostToDevice));
     WN_HIP(c, hipMalloc((void**)&p->job_block0_dev, b0.size() * sizeof(int)));
     WN_HIP(c, hipMemcpy(p->job_block0_dev, b0.data(), b0.size() * sizeof(int), hipMemcpyHostToDevice));
-    WN_HIP(c, hipMalloc((void**)&p->abort_dev, 256));
+    WN_HIP(c, hipMalloc((void**)&p->abort_dev, 256 + 4096));       // [0]: abort flag; +256: XCC table (grid <= 1024 entries)
     WN_HIP(c, hipStreamCreateWithFlags(&p->priv, hipStreamNonBlocking));
     WN_HIP(c, hipEventCreateWithFlags(&p->ev0, hipEventDisableTiming));
     WN_HIP(c, hipEventCreateWithFlags(&p->ev1, hipEventDisableTiming));
@@ -691,8 +724,8 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     }
     // ---- mailboxes, rings
     const size_t xm = (size_t)(L + 1) * B * P * PIPE_XG * 16, sm = (size_t)(L + 1) * B * P * PIPE_SG * 16;
-    if (xm > p->xm_bytes) { if (p->XM) hipFree(p->XM); WN_HIP(c, hipMalloc((void**)&p->XM, xm)); p->xm_bytes = xm; }
-    if (sm > p->sm_bytes) { if (p->SM) hipFree(p->SM); WN_HIP(c, hipMalloc((void**)&p->SM, sm)); p->sm_bytes = sm; }
+    if (xm > p->xm_bytes) { if (p->XM) hipFree(p->XM); if (p->XML) hipFree(p->XML); WN_HIP(c, hipMalloc((void**)&p->XM, xm)); WN_HIP(c, hipMalloc((void**)&p->XML, xm)); p->xm_bytes = xm; }
+    if (sm > p->sm_bytes) { if (p->SM) hipFree(p->SM); if (p->SML) hipFree(p->SML); WN_HIP(c, hipMalloc((void**)&p->SM, sm)); WN_HIP(c, hipMalloc((void**)&p->SML, sm)); p->sm_bytes = sm; }
     int64_t roff = 0;
     for (int l = 0; l < L; ++l) {
         int slots = 4; while (slots < 2 * c->dil[l] + 1) slots <<= 1;
@@ -702,8 +735,10 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     if ((size_t)roff * 2 > p->ring_bytes) { if (p->ring) hipFree(p->ring); WN_HIP(c, hipMalloc((void**)&p->ring, (size_t)roff * 2)); p->ring_bytes = (size_t)roff * 2; }
     WN_HIP(c, hipMemsetAsync(p->XM, 0, xm, st));
     WN_HIP(c, hipMemsetAsync(p->SM, 0, sm, st));
-    WN_HIP(c, hipMemsetAsync(p->abort_dev, 0, 256, st));
-    a.XM = p->XM; a.SM = p->SM; a.ring = p->ring; a.abort_flag = p->abort_dev;
+    WN_HIP(c, hipMemsetAsync(p->XML, 0, xm, st));
+    WN_HIP(c, hipMemsetAsync(p->SML, 0, sm, st));
+    WN_HIP(c, hipMemsetAsync(p->abort_dev, 0, 256 + 4096, st));
+    a.XM = p->XM; a.SM = p->SM; a.XML = p->XML; a.SML = p->SML; a.ring = p->ring; a.abort_flag = p->abort_dev; a.xcc_tab = p->abort_dev + 64;
     // ---- conditioning for the whole utterance (wavenet.py:781-803): cbt [B*T][C] bf16
     c->fB = B; c->fT = T; c->fTc = Tc;
     if ((rc = wn_upsample_fwd(c, nullptr, cin, B, Tc, st))) return rc;
