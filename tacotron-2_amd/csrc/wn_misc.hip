@@ -11,33 +11,39 @@
 struct PackJob { bf16_t* out; const PackSeg* segs; int32_t M, K, M_valid, gate_il, GH, nseg; int32_t block0, pad; };
 // One launch packs every matrix: block -> job by binary search in the jobs' first-block table.
 __global__ void wn_pack_kernel(const float* __restrict__ params, const PackJob* __restrict__ jobs, int njobs) {
+    // one thread = one lane's 8-element fragment piece (8 consecutive k of one row): 8 loads that are coalesced across the
+    // 32 lanes of a row group wherever the source is row-contiguous, one 16-B store.
     int lo = 0, hi = njobs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
     const PackJob jb = jobs[lo];
     const int M = jb.M, K = jb.K;
-    const int64_t idx = (int64_t)(blockIdx.x - jb.block0) * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)M * K) return;
+    const int64_t idx8 = (int64_t)(blockIdx.x - jb.block0) * blockDim.x + threadIdx.x;
+    if (idx8 * 8 >= (int64_t)M * K) return;
     const int KS = K >> 4;
-    const int j = idx & 7, lane = (idx >> 3) & 63;
-    const int64_t rest = idx >> 9;
+    const int lane = (int)(idx8 & 63);
+    const int64_t rest = idx8 >> 6;
     const int ks = (int)(rest % KS), mtile = (int)(rest / KS);
-    const int m = mtile * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
+    const int m = mtile * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
     int mm = m;
     if (jb.gate_il) {       // rows come in 64-row groups [32 tanh rows | their 32 sigmoid partners] (modules.py:494,510)
         const int blk = m >> 6, w = m & 63;
         mm = (w < 32) ? blk * 32 + w : jb.GH + blk * 32 + (w - 32);
     }
-    float v = 0.0f;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
     if (mm < jb.M_valid) {
         for (int s = 0; s < jb.nseg; ++s) {
             const PackSeg sg = jb.segs[s];
-            if (k >= sg.k0 && k < sg.k0 + sg.nk) {
-                v = sg.scale * params[sg.base + (int64_t)(k - sg.k0) * sg.stride_k + (int64_t)mm * sg.stride_m];
-                break;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                if (k >= sg.k0 && k < sg.k0 + sg.nk)
+                    v[j] = sg.scale * params[sg.base + (int64_t)(k - sg.k0) * sg.stride_k + (int64_t)mm * sg.stride_m];
             }
         }
     }
-    jb.out[idx] = f2bf(v);
+    *reinterpret_cast<uint4*>(jb.out + idx8 * 8) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
 
 struct VecSum { int n; int64_t off[32]; float w[32]; };
@@ -47,6 +53,12 @@ __global__ void wn_vecsum_kernel(const float* __restrict__ params, float* __rest
     float a = 0.0f;
     for (int j = 0; j < vs.n; ++j) a += vs.w[j] * params[vs.off[j] + i];
     out[i] = a;
+}
+// out[y][i] = params[a.off[y] + i] + params[b.off[y] + i] for every layer y in one launch (dilated-conv bias + conditioning bias)
+struct PairSum { int64_t a[32], b[32]; };
+__global__ void wn_pairsum_kernel(const float* __restrict__ params, float* __restrict__ out, int len, PairSum ps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (i < len) out[(size_t)y * len + i] = params[ps.a[y] + i] + params[ps.b[y] + i];
 }
 
 static void init_pack(wn_ctx* c, PackedW& w, int M_src, int K_src, int gate_il, int m_align = 32) {
@@ -123,7 +135,7 @@ int wn_build_packs(wn_ctx* c) {
 static void add_pack_job(wn_ctx* c, std::vector<PackJob>& jobs, int& nblocks, const PackedW& w) {
     PackJob j; j.out = w.dev; j.segs = w.dev_segs; j.M = w.M; j.K = w.K; j.M_valid = w.gate_interleave ? c->G : w.M_valid;
     j.gate_il = w.gate_interleave; j.GH = w.GH; j.nseg = (int)w.segs.size(); j.block0 = nblocks; j.pad = 0;
-    nblocks += cdiv((int64_t)w.M * w.K, 256);
+    nblocks += cdiv((int64_t)w.M * w.K / 8, 256);
     jobs.push_back(j);
 }
 
@@ -144,11 +156,12 @@ int wn_launch_pack(wn_ctx* c, const float* params, hipStream_t st) {
     }
     hipLaunchKernelGGL(wn_pack_kernel, dim3(c->pack_nblocks), dim3(256), 0, st, c->params_dev, (const PackJob*)c->pack_jobs_dev, c->pack_njobs);
     WN_LAUNCH_CHECK(c);
-    for (int l = 0; l < c->L; ++l) {
-        VecSum vs; vs.n = 2; vs.off[0] = c->lay[l].dil_b; vs.off[1] = c->lay[l].cin_b; vs.w[0] = vs.w[1] = 1.0f;
-        hipLaunchKernelGGL(wn_vecsum_kernel, dim3(cdiv(c->G, 256)), dim3(256), 0, st, c->params_dev, c->b1sum + (size_t)l * c->G, c->G, vs);
-    }
     if (c->L > 32) WN_FAIL(c, WN_E_UNSUPPORTED, "layers > 32");
+    {
+        PairSum ps;
+        for (int l = 0; l < c->L; ++l) { ps.a[l] = c->lay[l].dil_b; ps.b[l] = c->lay[l].cin_b; }
+        hipLaunchKernelGGL(wn_pairsum_kernel, dim3(cdiv(c->G, 256), c->L), dim3(256), 0, st, c->params_dev, c->b1sum, c->G, ps);
+    }
     VecSum vs; vs.n = c->L;
     for (int l = 0; l < c->L; ++l) { vs.off[l] = c->lay[l].skip_b; vs.w[l] = c->skip_scale[l]; }
     hipLaunchKernelGGL(wn_vecsum_kernel, dim3(cdiv(c->S, 256)), dim3(256), 0, st, c->params_dev, c->skip_bias_total, c->S, vs);
@@ -666,37 +679,60 @@ __device__ __forceinline__ int find_tensor(const int32_t* __restrict__ offs, int
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (offs[mid] <= i) lo = mid; else hi = mid - 1; }
     return lo;
 }
-__global__ void wn_norm2_kernel(const float* __restrict__ g, const int32_t* __restrict__ offs, int nt, int64_t n, float* __restrict__ norm2) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    float s = 0.0f; int id = -1;
-    if (i < n) {
-        const float4 v = *reinterpret_cast<const float4*>(g + i);
-        s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        id = find_tensor(offs, nt, i);
-    }
-    const int id0 = __shfl(id, 0);
-    if (__all(id == id0) && id0 >= 0) {
+#define WN_NORM_SPAN 4096      // floats per wave
+__global__ __launch_bounds__(256) void wn_norm2_kernel(const float* __restrict__ g, const int32_t* __restrict__ offs, int nt, int64_t n, float* __restrict__ norm2) {
+    // every wave walks a contiguous span; the running sum is flushed (wave reduction + ONE atomic) only when the span crosses
+    // into another tensor, so the ~200 norm accumulators see a few thousand atomics instead of one per wave-load
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t i0 = wave * WN_NORM_SPAN, i1 = i0 + WN_NORM_SPAN < n ? i0 + WN_NORM_SPAN : n;
+    if (i0 >= n) return;
+    int id = find_tensor(offs, nt, i0);
+    int64_t i = i0;
+    while (i < i1) {
+        const int64_t tend = (id + 1 < nt) ? (int64_t)offs[id + 1] : n;
+        const int64_t e = tend < i1 ? tend : i1;
+        float s = 0.0f;
+        for (int64_t j = i + lane; j < e; j += 64) { const float v = g[j]; s += v * v; }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&norm2[id0], s);
-    } else if (id >= 0 && s != 0.0f) unsafeAtomicAdd(&norm2[id], s);
+        if (lane == 0) unsafeAtomicAdd(&norm2[id], s);
+        i = e; ++id;
+    }
 }
 __global__ void wn_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                float* __restrict__ ema, const int32_t* __restrict__ offs, int nt, int64_t n,
                                const float* __restrict__ norm2, int clip, float max_norm, float max_value,
                                float lr_t, float b1, float b2, float eps, float ema_decay) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    float gi = g[i];
-    if (clip) {
-        const float nrm = sqrtf(norm2[find_tensor(offs, nt, i)]);
-        gi = gi * max_norm / fmaxf(nrm, max_norm);
-        gi = fminf(fmaxf(gi, -max_value), max_value);
+    auto upd = [&](float gi, float& pi, float& mi, float& vi, float& ei, float cs) {
+        if (clip) gi = fminf(fmaxf(gi * max_norm / cs, -max_value), max_value);      // tf.clip_by_norm: t * clip / max(norm, clip)
+        mi = b1 * mi + (1.0f - b1) * gi;
+        vi = b2 * vi + (1.0f - b2) * gi * gi;
+        pi = pi - lr_t * mi / (sqrtf(vi) + eps);
+        ei = ei - (1.0f - ema_decay) * (ei - pi);
+    };
+    auto clip_scale = [&](int64_t j) { return fmaxf(sqrtf(norm2[find_tensor(offs, nt, j)]), max_norm); };      // the denominator
+    if (i + 3 < n) {
+        float4 G = *reinterpret_cast<const float4*>(g + i), P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i);
+        float4 V = *reinterpret_cast<float4*>(v + i), E = *reinterpret_cast<float4*>(ema + i);
+        float c0 = 1.0f, c1 = 1.0f, c2 = 1.0f, c3 = 1.0f;
+        if (clip) {
+            const int t0 = find_tensor(offs, nt, i);
+            const int64_t tend = (t0 + 1 < nt) ? (int64_t)offs[t0 + 1] : n;
+            c0 = fmaxf(sqrtf(norm2[t0]), max_norm);
+            if (i + 3 < tend) { c1 = c2 = c3 = c0; }
+            else { c1 = clip_scale(i + 1); c2 = clip_scale(i + 2); c3 = clip_scale(i + 3); }
+        }
+        upd(G.x, P.x, M.x, V.x, E.x, c0); upd(G.y, P.y, M.y, V.y, E.y, c1); upd(G.z, P.z, M.z, V.z, E.z, c2); upd(G.w, P.w, M.w, V.w, E.w, c3);
+        *reinterpret_cast<float4*>(p + i) = P; *reinterpret_cast<float4*>(m + i) = M; *reinterpret_cast<float4*>(v + i) = V; *reinterpret_cast<float4*>(ema + i) = E;
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            float pi = p[j], mi = m[j], vi = v[j], ei = ema[j];
+            upd(g[j], pi, mi, vi, ei, clip ? clip_scale(j) : 1.0f);
+            p[j] = pi; m[j] = mi; v[j] = vi; ema[j] = ei;
+        }
     }
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    const float pi = p[i] - lr_t * mi / (sqrtf(vi) + eps);
-    m[i] = mi; v[i] = vi; p[i] = pi;
-    ema[i] = ema[i] - (1.0f - ema_decay) * (ema[i] - pi);
 }
 
 int wn_optim_impl(wn_ctx* c, float* p, const float* g, float* m, float* v, float* ema, float lr, int64_t step, hipStream_t st) {
@@ -705,11 +741,11 @@ int wn_optim_impl(wn_ctx* c, float* p, const float* g, float* m, float* v, float
     const int64_t n = c->n_params;
     if (h.clip_gradients) {
         WN_HIP(c, hipMemsetAsync(c->norm2_dev, 0, nt * 4, st));
-        hipLaunchKernelGGL(wn_norm2_kernel, dim3(cdiv(n / 4 + 1, 256)), dim3(256), 0, st, g, c->tensor_offsets_dev, nt, n, c->norm2_dev);
+        hipLaunchKernelGGL(wn_norm2_kernel, dim3(cdiv(cdiv(n, WN_NORM_SPAN), 4)), dim3(256), 0, st, g, c->tensor_offsets_dev, nt, n, c->norm2_dev);
     }
     const double t = (double)(step + 1);
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)h.adam_beta2, t)) / (1.0 - pow((double)h.adam_beta1, t)));
-    hipLaunchKernelGGL(wn_adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, p, g, m, v, ema, c->tensor_offsets_dev, nt, n, c->norm2_dev,
+    hipLaunchKernelGGL(wn_adam_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, st, p, g, m, v, ema, c->tensor_offsets_dev, nt, n, c->norm2_dev,
                        h.clip_gradients, h.gradient_max_norm, h.gradient_max_value, lr_t, h.adam_beta1, h.adam_beta2, h.adam_epsilon, h.ema_decay);
     WN_LAUNCH_CHECK(c);
     return WN_OK;

@@ -49,6 +49,7 @@ struct GemmArgs {
     int32_t tiles_per_utt, ntiles;
     uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;   // dropout mask spec (row pitch of the dropped tensor)
     const bf16_t* zero;         // >= 16 B of zeros in device memory (source of out-of-range rows for the LDS-DMA kernel)
+    int32_t stagger;            // shader cycles the second-resident workgroups of the first round wait before starting (0: off)
     EpiArgs e;
 };
 
@@ -57,11 +58,12 @@ enum { EPI_GATE = 0, EPI_STORE_BF16 = 1, EPI_STORE_F32_BOT = 2, EPI_DGATE = 3, E
 #define TILE_LDS_STRIDE 72   // halfs per staged row: 64 channels + 8 pad (144 B)
 
 __device__ __forceinline__ float fast_tanh(float x) {
-    // tanh(x) = 1 - 2/(exp(2x)+1); exact to ~1 ulp of __expf, saturates cleanly
-    float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+    // tanh(x) = 1 - 2/(exp(2x)+1) on v_exp_f32 + v_rcp_f32 (1 ulp each; the result is rounded to bf16 anyway); saturates
+    // cleanly: exp -> inf gives rcp 0 -> +1, exp -> 0 gives -1.  An IEEE divide here costs ~10 VALU instructions per element.
+    float e = __builtin_amdgcn_exp2f(x * 2.885390082f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
-__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.442695041f)); }
 
 __device__ __forceinline__ bool drop_keep(uint32_t key_lo, uint32_t key_hi, uint32_t thresh16, uint32_t e) {
     uint32_t w = wn_drop_word(key_lo, key_hi, e >> 1);
@@ -374,7 +376,7 @@ struct LdsGemmCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI>
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 0>
 __global__ __launch_bounds__(WM * WN * 64, (lds_gemm_min_waves(MT, NT, WM, WN, BK, NBUF)))
 void wn_gemm_lds_kernel(const GemmArgs a) {
     using Cfg = LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>;
@@ -389,6 +391,17 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     const int mblk = q % a.mblocks;
     const int tile = (q / a.mblocks) * 8 + xcd;
     if (tile >= a.ntiles) return;
+    if (a.stagger > 0 && id < 512) {
+        // All tiles cost the same, so co-resident (and neighbouring) workgroups would reach their MFMA-idle, store-heavy
+        // epilogues at the same moment.  First-round workgroups therefore start with a placement-dependent delay; later
+        // rounds inherit the offsets.  Placement is a heuristic (dispatch order is not architecturally defined): speed only.
+        constexpr bool two_res = lds_gemm_min_waves(MT, NT, WM, WN, BK, NBUF) * 4 / (WM * WN) >= 2;
+        const int delay = two_res ? (q >= 32 ? a.stagger : 0) : (id < 256 ? ((q & 7) * a.stagger) >> 3 : 0);
+        if (delay > 0) {
+            const uint64_t t_start = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t_start < (uint64_t)delay) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const int b = tile / a.tiles_per_utt;
     const int t0 = (tile - b * a.tiles_per_utt) * Cfg::TTILE;
     const int T = a.T;
@@ -407,6 +420,11 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
 
     const int chunks_per_rep = [&] { int n = 0; for (int s = 0; s < a.nseg; ++s) n += (a.seg[s].nk + BK - 1) / BK; return n; }();
     const int nchunks = chunks_per_rep * a.nrep;
+#ifdef WN_EPI_ABLATE     // harness-only bottleneck probes: stagger < 0 carries flag bits (1: no DMA, 2: no LDS fragment reads, 4: no barrier)
+    const int dbg = a.stagger < 0 ? -a.stagger : 0;
+#else
+    constexpr int dbg = 0;
+#endif
 
     // ---- staging iterator (chunk being DMA'd) and compute iterator (chunk being multiplied).  Everything the loop needs
     // from the segment descriptors is kept in registers and refreshed only when the iterator enters a new segment:
@@ -437,6 +455,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         char* const bbuf = abuf + Cfg::A_BYTES;
         const int kc = min(BK, s_left);
         // A: fragment f = mt*KS + ks  <-  Apk[(mtile_wg + mt)][s_kstep + ks]; wave-uniform base + lane*16
+        if (!(dbg & 1)) {
 #pragma unroll
         for (int p = 0; p < Cfg::A_PW; ++p) {
             const int f = wave + p * Cfg::NW;
@@ -450,6 +469,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
             const bf16_t* src = (b_off[p] >= 0 && b_c8[p] < kc) ? s_ptr + b_off[p] : a.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(bbuf + (wave + p * Cfg::NW) * 1024), 16, 0, 0);
+        }
         }
         s_kstep += kc >> 4; s_left -= BK; s_ptr += BK;
         if (s_left <= 0) {
@@ -498,9 +518,44 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         const int younger = min(NBUF - 2, nchunks - 1 - ch);
         if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
-        compute(bufc);
+        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+        if constexpr (PIPE == 0) {
+            if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+            compute(bufc);
+        } else {
+            // PIPE 1: every fragment of the chunk is requested from LDS straight after the barrier, the DMA issue + iterator
+            // bookkeeping of the next chunk runs while those reads are in flight, then the chunk's MFMAs go back to back.
+            const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+            bf16x8_t af[Cfg::KS][MT], bfr[Cfg::KS][NT];
+            if (dbg & 2) {
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) af[ks][i] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, ch, ks, i));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bfr[ks][j] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, ch, ks, j));
+                }
+            } else
+#pragma unroll
+            for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < Cfg::KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        }
     };
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
 
@@ -664,7 +719,8 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.tiles_per_utt = cdiv(a.T, 128);
             a.ntiles = a.tiles_per_utt * a.B;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
-            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI>), dim3(grid), dim3(512), 0, st, a);
+            a.stagger = grid >= 1024 ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
+            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
             return WN_OK;
         }

@@ -42,12 +42,12 @@ static void launch_v1(GemmArgs a, int M, hipStream_t st) {
     const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
     hipLaunchKernelGGL((wn_gemm_tile_kernel<MT, NT, WM, WN, EPI>), dim3(grid), dim3(WM * WN * 64), 0, st, a);
 }
-template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI>
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 0>
 static void launch_v2(GemmArgs a, int M, hipStream_t st) {
     const int nrows = WN * NT * 32, mrows = WM * MT * 32;
     a.mblocks = M / mrows; a.tiles_per_utt = cdiv(a.T, nrows); a.ntiles = a.tiles_per_utt * a.B;
     const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
-    hipLaunchKernelGGL((wn_gemm_lds_kernel<MT, NT, WM, WN, BK, NBUF, EPI>), dim3(grid), dim3(WM * WN * 64), 0, st, a);
+    hipLaunchKernelGGL((wn_gemm_lds_kernel<MT, NT, WM, WN, BK, NBUF, EPI, PIPE>), dim3(grid), dim3(WM * WN * 64), 0, st, a);
 }
 static float time_ms(const std::function<void()>& f, int iters = 10) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -92,7 +92,19 @@ int main(int argc, char** argv) {
         float t2 = time_ms([&] { launch_v2<MT_, NT_, WM_, WN_, BK_, NB_, EPI_GATE>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
         bool ok = same({TS1, (size_t)NT_ * G * 2}, {TS2, (size_t)NT_ * G * 2}, "TS") & same({U1, (size_t)NT_ * GH * 2}, {U2, (size_t)NT_ * GH * 2}, "U"); \
         printf("gate   v2 MT%d NT%d WM%d WN%d BK%d NBUF%d   : %8.1f us  %7.1f TF  %s\n", MT_, NT_, WM_, WN_, BK_, NB_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
-        TRY_GATE2(2, 2, 4, 2, 32, 3) TRY_GATE2(2, 2, 4, 2, 32, 2) TRY_GATE2(4, 2, 2, 2, 32, 3) TRY_GATE2(4, 2, 2, 2, 32, 2) TRY_GATE2(2, 4, 2, 2, 32, 3) TRY_GATE2(4, 2, 2, 2, 64, 2) TRY_GATE2(4, 2, 4, 1, 32, 3)
+#define TRY_GATE3(MT_, NT_, WM_, WN_, BK_, NB_, PP_) { CK(hipMemset(TS2, 0xff, NT_ * G * 2)); CK(hipMemset(U2, 0xff, NT_ * GH * 2)); \
+        float t2 = time_ms([&] { launch_v2<MT_, NT_, WM_, WN_, BK_, NB_, EPI_GATE, PP_>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+        bool ok = same({TS1, (size_t)NT_ * G * 2}, {TS2, (size_t)NT_ * G * 2}, "TS") & same({U1, (size_t)NT_ * GH * 2}, {U2, (size_t)NT_ * GH * 2}, "U"); \
+        printf("gate   v2 MT%d NT%d WM%d WN%d BK%d NBUF%d PIPE%d : %8.1f us  %7.1f TF  %s\n", MT_, NT_, WM_, WN_, BK_, NB_, PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        TRY_GATE2(2, 2, 4, 2, 32, 3) TRY_GATE2(2, 2, 4, 2, 32, 2) 
+        TRY_GATE2(4, 2, 2, 4, 32, 3) TRY_GATE2(2, 4, 4, 2, 32, 3)
+        TRY_GATE3(2, 2, 4, 2, 32, 3, 1) TRY_GATE3(4, 2, 2, 4, 32, 3, 1) TRY_GATE3(2, 4, 4, 2, 32, 3, 1) TRY_GATE3(2, 2, 4, 2, 32, 2, 1)
+        for (int sg : {0, 4000, 16000}) { a2.stagger = sg; printf("  stagger %5d: ", sg); TRY_GATE2(2, 2, 4, 2, 32, 3) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 1) }
+        for (int sg : {0, 8000, 16000, 32000, 64000}) { a2.stagger = sg; printf("  stagger %5d: ", sg); TRY_GATE2(4, 2, 2, 4, 32, 3) printf("  stagger %5d: ", sg); TRY_GATE3(4, 2, 2, 4, 32, 3, 1) }
+#ifdef WN_EPI_ABLATE
+        for (int dbgf : {1, 2, 3, 4, 7}) { a2.stagger = -dbgf; printf("  probe flags %d (1 noDMA 2 noLDSread 4 nobarrier): ", dbgf); TRY_GATE3(2, 2, 4, 2, 32, 3, 1) }
+#endif
+        a2.stagger = 0;
     }
     {   // ---------------- out conv: M = 256, K = 256, residual add + dropout copy
         const int M = R, K = GH;
