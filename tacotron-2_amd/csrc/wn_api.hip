@@ -133,8 +133,6 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     if (cfg->upsample_type != WN_UP_NEAREST && cfg->upsample_type != WN_UP_2D && cfg->upsample_type != WN_UP_SUBPIXEL &&
         cfg->upsample_type != WN_UP_1D && cfg->upsample_type != WN_UP_RESIZE)
         WN_FAIL(z, WN_E_ARG, "bad upsample_type %d", cfg->upsample_type);
-    if (cfg->upsample_type == WN_UP_1D || cfg->upsample_type == WN_UP_RESIZE)
-        WN_FAIL(z, WN_E_UNSUPPORTED, "upsample_type '1D'/'Resize' not built yet (2D, SubPixel, NearestNeighbor are)");
     if (cfg->freq_axis_kernel_size % 2 == 0 || cfg->freq_axis_kernel_size > 9) WN_FAIL(z, WN_E_UNSUPPORTED, "freq_axis_kernel_size must be odd <= 9");
     if (cfg->max_batch <= 0 || cfg->max_time <= 0) WN_FAIL(z, WN_E_ARG, "max_batch/max_time must be positive");
     if (cfg->dropout < 0.f || cfg->dropout >= 1.f) WN_FAIL(z, WN_E_ARG, "dropout must be in [0,1)");

@@ -292,6 +292,114 @@ __global__ void wn_up_fwd(const float* __restrict__ in, float* __restrict__ out,
     if (cbt) cbt[((int64_t)b * Tout + to) * C + f] = f2bf(v);
 }
 
+// type 3 'Resize' (modules.py:657-695): nearest-neighbour resize x s along time, then Conv2D 1->1, kernel (fk, s), SAME
+//   (TF pads (k-1)/2 before and the rest after on each axis): out[f][to] = b + sum_{kf,kt} up[f+kf-pf][to+kt-pl] K[kf][kt],
+//   up[f'][tu] = in[f'][tu / s];
+// type 4 '1D' (modules.py:697-733): Conv2DTranspose C->C, kernel (1, s), stride (1, s), TF layout [1][s][out][in]:
+//   out[co][t*s+j] = b[co] + sum_ci in[ci][t] K[j][co][ci].
+// Both are off in the reference's two hparams files: one straightforward thread per output element.
+__global__ void wn_up_fwd_generic(const float* __restrict__ in, float* __restrict__ out, bf16_t* __restrict__ cbt,
+                                  const float* __restrict__ K, const float* __restrict__ bias, int B, int C, int Tin, int s,
+                                  int fk, int type, int act, float alpha) {
+    const int Tout = Tin * s;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * C * Tout) return;
+    const int to = (int)(idx % Tout); const int64_t bf = idx / Tout;
+    const int f = (int)(bf % C), b = (int)(bf / C);
+    const float* inb = in + (int64_t)b * C * Tin;
+    float v;
+    if (type == 3) {
+        const int pf = (fk - 1) / 2, pl = (s - 1) / 2;
+        v = bias[0];
+        for (int kf = 0; kf < fk; ++kf) {
+            const int fs = f + kf - pf; if (fs < 0 || fs >= C) continue;
+            for (int kt = 0; kt < s; ++kt) { const int tu = to + kt - pl; if (tu >= 0 && tu < Tout) v += inb[(int64_t)fs * Tin + tu / s] * K[kf * s + kt]; }
+        }
+    } else {
+        const int t = to / s, j = to - t * s;
+        v = bias[f];
+        const float* Kj = K + ((int64_t)j * C + f) * C;
+        for (int ci = 0; ci < C; ++ci) v += inb[(int64_t)ci * Tin + t] * Kj[ci];
+    }
+    v = act_fwd(v, act, alpha);
+    out[idx] = v;
+    if (cbt) cbt[((int64_t)b * Tout + to) * C + f] = f2bf(v);
+}
+
+// parameter gradients of types 3 / 4: one WAVE per (kernel or bias element, batch slice); lanes stride over time, shuffle
+// reduction, one atomic per wave.  blockIdx.y = slice: (b, f) row for 'Resize', b for '1D'.
+__global__ void wn_up_bwd_params_generic(const float* __restrict__ in, const float* __restrict__ out, const float* __restrict__ dout,
+                                         float* __restrict__ dK, float* __restrict__ dbias, int B, int C, int Tin, int s, int fk,
+                                         int type, int act, float alpha) {
+    const int Tout = Tin * s;
+    const int nk = (type == 3) ? fk * s : s * C * C, nb = (type == 3) ? 1 : C;
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (e >= nk + nb) return;
+    float a = 0.0f;
+    if (type == 3) {
+        const int b = blockIdx.y / C, f = blockIdx.y % C;
+        const int pf = (fk - 1) / 2, pl = (s - 1) / 2;
+        const int64_t ro = ((int64_t)b * C + f) * Tout;
+        if (e < nk) {
+            const int kf = e / s, kt = e % s;
+            const int fs = f + kf - pf;
+            if (fs >= 0 && fs < C) {
+                const float* inr = in + ((int64_t)b * C + fs) * Tin;
+                for (int to = lane; to < Tout; to += 64) {
+                    const int tu = to + kt - pl; if (tu < 0 || tu >= Tout) continue;
+                    a += dout[ro + to] * act_grad(out[ro + to], act, alpha) * inr[tu / s];
+                }
+            }
+        } else {
+            for (int to = lane; to < Tout; to += 64) a += dout[ro + to] * act_grad(out[ro + to], act, alpha);
+        }
+    } else {
+        const int b = blockIdx.y;
+        if (e < nk) {
+            const int ci = e % C, co = (e / C) % C, j = e / (C * C);
+            const int64_t ro = ((int64_t)b * C + co) * Tout; const float* inr = in + ((int64_t)b * C + ci) * Tin;
+            for (int t = lane; t < Tin; t += 64) { const int64_t o = ro + (int64_t)t * s + j; a += dout[o] * act_grad(out[o], act, alpha) * inr[t]; }
+        } else {
+            const int co = e - nk;
+            const int64_t ro = ((int64_t)b * C + co) * Tout;
+            for (int to = lane; to < Tout; to += 64) a += dout[ro + to] * act_grad(out[ro + to], act, alpha);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+    if (lane == 0 && a != 0.0f) unsafeAtomicAdd(e < nk ? &dK[e] : &dbias[e - nk], a);
+}
+
+__global__ void wn_up_bwd_input_generic(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ din,
+                                        const float* __restrict__ K, int B, int C, int Tin, int s, int fk, int type, int act, float alpha) {
+    const int Tout = Tin * s;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * C * Tin) return;
+    const int t = (int)(idx % Tin); const int64_t bf = idx / Tin;
+    const int f = (int)(bf % C), b = (int)(bf / C);
+    const float* ob = out + (int64_t)b * C * Tout; const float* db = dout + (int64_t)b * C * Tout;
+    float a = 0.0f;
+    if (type == 3) {
+        const int pf = (fk - 1) / 2, pl = (s - 1) / 2;
+        for (int kf = 0; kf < fk; ++kf) {
+            const int fo = f - kf + pf; if (fo < 0 || fo >= C) continue;       // output row whose tap kf reads input row f
+            for (int tu = t * s; tu < t * s + s; ++tu)
+                for (int kt = 0; kt < s; ++kt) {
+                    const int to = tu - kt + pl; if (to < 0 || to >= Tout) continue;
+                    const int64_t o = (int64_t)fo * Tout + to;
+                    a += K[kf * s + kt] * db[o] * act_grad(ob[o], act, alpha);
+                }
+        }
+    } else {
+        for (int j = 0; j < s; ++j)
+            for (int co = 0; co < C; ++co) {
+                const int64_t o = (int64_t)co * Tout + (int64_t)t * s + j;
+                a += K[((int64_t)j * C + co) * C + f] * db[o] * act_grad(ob[o], act, alpha);
+            }
+    }
+    din[idx] = a;
+}
+
 // dpre = dout * act'(out);  dK[kf][j], dbias.  One workgroup per (b, f) row; thread x owns phase j = x % s of the stride-s
 // output grid (to = j + s*q), so its kernel taps are fixed and accumulate in registers; one LDS atomic per thread and
 // tap at the end, one global atomic per workgroup and tap.  (The v0 kernel did an LDS atomic per ELEMENT and tap on ~30
@@ -378,7 +486,9 @@ __global__ void wn_up_bwd_input(const float* __restrict__ out, const float* __re
     din[idx] = a;
 }
 
-static int up_type_code(const wn_ctx* c) { return c->cfg.upsample_type == WN_UP_NEAREST ? 0 : c->cfg.upsample_type == WN_UP_2D ? 1 : 2; }
+static int up_type_code(const wn_ctx* c) {
+    switch (c->cfg.upsample_type) { case WN_UP_NEAREST: return 0; case WN_UP_2D: return 1; case WN_UP_SUBPIXEL: return 2; case WN_UP_RESIZE: return 3; default: return 4; }
+}
 
 // c_in [B,C,Tc] fp32 -> CUP[i] (fp32 per level), cbt (bf16 time-major)
 int wn_upsample_fwd(wn_ctx* c, const float*, const float* cin, int B, int Tc, hipStream_t st) {
@@ -395,6 +505,11 @@ int wn_upsample_fwd(wn_ctx* c, const float*, const float* cin, int B, int Tc, hi
         const int s = c->cfg.upsample_scales[i];
         const bool last = (i == c->cfg.n_upsample - 1);
         const int64_t n = (int64_t)B * C * Tin * s;
+        if (type >= 3)
+            hipLaunchKernelGGL(wn_up_fwd_generic, dim3(cdiv(n, 256)), dim3(256), 0, st, in, c->CUP[i], last ? c->cbt : nullptr,
+                               c->params_dev + c->up_k[i], c->params_dev + c->up_b[i], B, C, Tin, s, c->cfg.freq_axis_kernel_size,
+                               type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
+        else
         hipLaunchKernelGGL(wn_up_fwd, dim3(cdiv(n, 256)), dim3(256), 0, st, in, c->CUP[i], last ? c->cbt : nullptr,
                            c->params_dev + c->up_k[i], c->params_dev + c->up_b[i], B, C, Tin, s, c->cfg.freq_axis_kernel_size,
                            type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
@@ -416,6 +531,22 @@ int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t 
         const int Tin = Tout / s;
         const float* in = (i == 0) ? c->fc : c->CUP[i - 1];
         const int fk = c->cfg.freq_axis_kernel_size;
+        if (type >= 3) {
+            const int nkb = (type == 3) ? fk * s + 1 : s * C * C + C;
+            hipLaunchKernelGGL(wn_up_bwd_params_generic, dim3(cdiv(nkb, 4), type == 3 ? B * C : B), dim3(256), 0, st, in, c->CUP[i], dout,
+                               grads + c->up_k[i], grads + c->up_b[i], B, C, Tin, s, fk, type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
+            WN_LAUNCH_CHECK(c);
+            if (i > 0) {
+                float* din = c->DCUP[i & 1];
+                const int64_t ni = (int64_t)B * C * Tin;
+                hipLaunchKernelGGL(wn_up_bwd_input_generic, dim3(cdiv(ni, 256)), dim3(256), 0, st, c->CUP[i], dout, din, c->params_dev + c->up_k[i],
+                                   B, C, Tin, s, fk, type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
+                WN_LAUNCH_CHECK(c);
+                dout = din;
+            }
+            Tout = Tin;
+            continue;
+        }
         const int nk = (type == 1) ? fk * s : fk * 3 * s, nb = (type == 1) ? 1 : s;
         if ((size_t)(nk + nb) * 4 > 60000) WN_FAIL(c, WN_E_UNSUPPORTED, "upsample scale %d too large for the LDS partials", s);
         const int64_t n = (int64_t)B * C * Tout;

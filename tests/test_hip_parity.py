@@ -48,6 +48,10 @@ CONFIGS = {
                            log_scale_min_gauss=float(np.log(1e-7))),
     'gauss_cdf_nn': dict(out_channels=2, upsample_type='NearestNeighbor', cdf_loss=True,
                          log_scale_min_gauss=float(np.log(9.1188196e-4))),
+    # the two upsamplers that both reference hparams files leave off (modules.py:657-733); even and odd scales
+    'mol_resize': dict(upsample_type='Resize', upsample_scales=[2, 8], upsample_activation='LeakyRelu'),
+    'mol_resize_odd': dict(upsample_type='Resize', upsample_scales=[3, 5], hop_size=15),
+    'gauss_1d': dict(out_channels=2, upsample_type='1D', log_scale_min_gauss=float(np.log(1e-7))),
     'softmax_c1': dict(input_type='mulaw-quantize', out_channels=256, quantize_channels=256, layers=8, stacks=1,
                        upsample_activation='LeakyRelu'),
     'wide': dict(residual_channels=128, gate_channels=256, skip_out_channels=128, cin_channels=80, num_mels=80,
