@@ -115,7 +115,7 @@ int wn_build_packs(wn_ctx* c) {
     init_pack(c, c->wh1T, S, S, 0); c->wh1T.segs.push_back({c->fin1_k, 0, S, 1, S, 1.0f});
     if ((rc = finish_pack(c, c->wh1T))) return rc;
     // d_c: rows = cin channel, K = L*G;  W[cc][l*G+g] = cin_k_l[cc][g]
-    init_pack(c, c->wcT, C, L * G, 0, 128);      // M padded to the 128-row tile of the LDS-DMA main loop
+    init_pack(c, c->wcT, C, L * G, 0, C <= 96 ? 96 : 128);      // M padded to the 96- or 128-row tile of the LDS-DMA main loop (80 mels -> 96)
     for (int l = 0; l < L; ++l) c->wcT.segs.push_back({c->lay[l].cin_k, l * G, G, 1, G, 1.0f});
     if ((rc = finish_pack(c, c->wcT))) return rc;
 

@@ -49,6 +49,7 @@ struct GemmArgs {
     int32_t tiles_per_utt, ntiles;
     uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;   // dropout mask spec (row pitch of the dropped tensor)
     const bf16_t* zero;         // >= 16 B of zeros in device memory (source of out-of-range rows for the LDS-DMA kernel)
+    unsigned long long* trace;  // harness-only (WN_EPI_ABLATE builds): per-workgroup s_memtime stamps of the main loop
     int32_t stagger;            // shader cycles the second-resident workgroups of the first round wait before starting (0: off)
     EpiArgs e;
 };
@@ -351,6 +352,18 @@ __global__ __launch_bounds__(WM * WN * 64) void wn_gemm_tile_kernel(const GemmAr
 //     device zero page instead, so the number of DMAs per chunk is constant (counted vmcnt);
 //   * ring buffers are indexed at compile time (loop unrolled by NBUF): with a runtime index hipcc cannot
 //     prove the DMA destination and the ds_reads disjoint and drains vmcnt(0) before every read.
+// One wave-wide LDS-DMA: lane i's 16 B from `gsrc` land at LDS byte address lds_addr (wave-uniform) + 16*i.  Issued as inline
+// asm on purpose: hipcc models the builtin as a FLAT access, and while one is in flight (always, here) its waitcnt pass turns
+// every wait on an LDS read into lgkmcnt(0) -- i.e. it serialises "read fragments" and "multiply" -- and inserts vmcnt(0)
+// before LDS reads it cannot prove disjoint from the DMA target.  The ordering the DMA needs is enforced by hand in the main
+// loops (counted vmcnt + s_barrier before any read of the buffer); the "memory" clobber keeps LDS accesses on their side.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 constexpr int lds_gemm_bytes(int MT, int NT, int WM, int WN, int BK, int NBUF) {
     const int ring = NBUF * (WM * MT * 32 + WN * NT * 32) * BK * 2, epi = WN * 32 * (WM * MT * 32 * 4 + 16);
     return ring > epi ? ring : epi;
@@ -406,6 +419,9 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     const int t0 = (tile - b * a.tiles_per_utt) * Cfg::TTILE;
     const int T = a.T;
     const int64_t rowbase = (int64_t)b * T;
+#ifdef WN_EPI_ABLATE
+    const unsigned long long wg_t_start = __builtin_amdgcn_s_memtime();
+#endif
 
     f32x16_t acc[MT][NT];
 #pragma unroll
@@ -420,7 +436,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
 
     const int chunks_per_rep = [&] { int n = 0; for (int s = 0; s < a.nseg; ++s) n += (a.seg[s].nk + BK - 1) / BK; return n; }();
     const int nchunks = chunks_per_rep * a.nrep;
-#ifdef WN_EPI_ABLATE     // harness-only bottleneck probes: stagger < 0 carries flag bits (1: no DMA, 2: no LDS fragment reads, 4: no barrier)
+#ifdef WN_EPI_ABLATE     // harness-only bottleneck probes: stagger < 0 carries flag bits (1: no DMA, 2: no LDS fragment reads, 4: no barrier, 8: DMA sources L2-hot)
     const int dbg = a.stagger < 0 ? -a.stagger : 0;
 #else
     constexpr int dbg = 0;
@@ -432,18 +448,26 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     int s_rep = 0, s_sg = 0, s_left = a.seg[0].nk, s_kstep = 0;
     const bf16_t* s_ptr = a.seg[0].base + a.seg[0].col0;                // + rep offset + channels already staged (wave-uniform)
     // per-lane constants of the B image: piece g = wave + p*NW holds rows g*(1024/RB)...; LDS byte lane*16 -> (row, slot)
-    int b_c8[Cfg::B_PW], b_t[Cfg::B_PW], b_off[Cfg::B_PW];
+    // DMA issuers: all waves, or (PIPE 5) only waves [0, NW/2) -- one per SIMD and workgroup -- with twice the pieces each, so
+    // that after every barrier the other wave of the SIMD goes straight to the MFMA pipe while its partner queues on the TA.
+    constexpr int NWD = (PIPE == 5) ? Cfg::NW / 2 : Cfg::NW;
+    constexpr int APW = Cfg::A_INSTR / NWD, BPW = Cfg::B_INSTR / NWD;
+    const bool dma_wave = wave < NWD;
+    int b_c8[BPW], b_t[BPW], b_off[BPW];
     auto enter_segment = [&]() {          // per-lane element offsets inside the current segment (-1: reads the zero page)
         const int ld = a.seg[s_sg].ld, shift = a.seg[s_sg].shift;       // one s_load per SEGMENT, not per chunk
 #pragma unroll
-        for (int p = 0; p < Cfg::B_PW; ++p) {
+        for (int p = 0; p < BPW; ++p) {
             const int ts = b_t[p] + shift;
             b_off[p] = (b_t[p] < T && ts >= 0 && ts < T) ? (int)((rowbase + ts) * ld + b_c8[p]) : -1;
+#ifdef WN_EPI_ABLATE
+            if ((dbg & 8) && b_off[p] >= 0) b_off[p] = (int)(((b_t[p] - t0) & 127) * ld + b_c8[p]);     // probe: every workgroup DMAs the same 128 rows (L2-hot)
+#endif
         }
     };
 #pragma unroll
-    for (int p = 0; p < Cfg::B_PW; ++p) {
-        const int row = (wave + p * Cfg::NW) * (1024 / Cfg::RB) + (lane * 16) / Cfg::RB;
+    for (int p = 0; p < BPW; ++p) {
+        const int row = (wave + p * NWD) * (1024 / Cfg::RB) + (lane * 16) / Cfg::RB;
         b_c8[p] = ((lane % Cfg::SPR) ^ ((row / Cfg::RPL) % Cfg::SPR)) * 8;
         b_t[p] = t0 + row;
     }
@@ -453,22 +477,25 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         constexpr int BUF = decltype(bufc)::value;
         char* const abuf = lds + BUF * Cfg::BUF_BYTES;
         char* const bbuf = abuf + Cfg::A_BYTES;
-        const int kc = min(BK, s_left);
+        const int kc = (s_rep < a.nrep) ? min(BK, s_left) : 0;      // past the last chunk: an all-zero chunk (PIPE 2 pads the count)
         // A: fragment f = mt*KS + ks  <-  Apk[(mtile_wg + mt)][s_kstep + ks]; wave-uniform base + lane*16
-        if (!(dbg & 1)) {
+        if (!(dbg & 1) && dma_wave) {
 #pragma unroll
-        for (int p = 0; p < Cfg::A_PW; ++p) {
-            const int f = wave + p * Cfg::NW;
+        for (int p = 0; p < APW; ++p) {
+            const int f = wave + p * NWD;
+#ifdef WN_EPI_ABLATE
+            const int ksx = (dbg & 8) ? (s_kstep & 7) : s_kstep;
+            const bf16_t* base = a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + ksx + f % Cfg::KS) * 512;
+#else
             const bf16_t* base = a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512;
+#endif
             const bf16_t* src = ((f % Cfg::KS) * 16 < kc) ? base + lane * 8 : a.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(abuf + f * 1024), 16, 0, 0);
+            lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + f * 1024)));
         }
 #pragma unroll
-        for (int p = 0; p < Cfg::B_PW; ++p) {
+        for (int p = 0; p < BPW; ++p) {
             const bf16_t* src = (b_off[p] >= 0 && b_c8[p] < kc) ? s_ptr + b_off[p] : a.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(bbuf + (wave + p * Cfg::NW) * 1024), 16, 0, 0);
+            lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
         }
         }
         s_kstep += kc >> 4; s_left -= BK; s_ptr += BK;
@@ -557,8 +584,100 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
         }
     };
-    static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+    static_assert(NBUF == 2 || NBUF == 3 || (NBUF == 4 && PIPE >= 2), "ring depth");
 
+    if constexpr (PIPE >= 2) {
+        // PIPE 2: fragments are requested from LDS one k-step AHEAD of the MFMAs that use them (two register sets), across
+        // chunk boundaries too, so no MFMA ever waits on a read it has just issued.  Reading chunk ch+1 while chunk ch is still
+        // being multiplied needs chunk ch+1 landed one step early: the ring keeps {ch, ch+1, DMA target ch+2}, i.e. the DMA
+        // look-ahead is one chunk time (>= 1000 clk here, above the L2-hit DMA latency) instead of two.
+        static_assert(NBUF >= 3 && Cfg::KS % 2 == 0, "PIPE >= 2 needs a ring of 3 or 4 and an even number of k-steps per chunk");
+        // With NBUF == 4 the DMAs awaited at a step were issued TWO steps earlier (vmcnt leaves the youngest chunk in flight).
+        constexpr int INFL = (NBUF - 3) * (APW + BPW);
+        bf16x8_t fa[2][MT], fb[2][NT];
+        auto read_frags = [&](auto bufc, auto ksc, auto setc) {
+            constexpr int BUF = decltype(bufc)::value, ks = decltype(ksc)::value, SET = decltype(setc)::value;
+            const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[SET][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                fb[SET][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+        };
+        auto mfma_set = [&](auto setc) {
+            constexpr int SET = decltype(setc)::value;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);
+        };
+        const int npad = (nchunks + NBUF - 1) / NBUF * NBUF;          // zero chunks pad the count: no guards inside the unrolled body
+#ifdef WN_EPI_ABLATE
+        const bool tr_on = (dbg & 16) && a.trace && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 1024;
+        unsigned long long* const tr = a.trace + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 64 * 4;
+#define WN_TR(ch_, slot_) do { if (tr_on && (ch_) < 64) tr[(ch_) * 4 + (slot_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WN_TR(ch_, slot_) do { } while (0)
+#endif
+        auto step2 = [&](auto bufc, int ch) {
+            constexpr int BUF = decltype(bufc)::value;
+            // entry: set 0 holds (ch, k-step 0)
+            [&]<int... KSI>(std::integer_sequence<int, KSI...>) {
+                ([&] {
+                    constexpr int ks = KSI;
+                    if constexpr (ks + 1 < Cfg::KS) {
+                        read_frags(bufc, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, (ks + 1) & 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_set(std::integral_constant<int, ks & 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        // last k-step: synchronise on chunk ch+1 and issue the DMAs of chunk ch+2 FIRST (their address arithmetic,
+                        // incl. the occasional segment switch with its scalar loads, must not sit between LDS reads and their
+                        // consumers: any SMEM in flight, or any control-flow join, turns the later waits into lgkmcnt(0)), then
+                        // the MFMAs, then the reads of (ch+1, k-step 0), which fly during those MFMAs and the next read issue.
+                        WN_TR(ch, 0);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");   // my DMAs of chunk ch+1 have landed (younger chunks may fly)
+                        WN_TR(ch, 1);
+                        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();               // everyone's have landed; buffer of chunk ch-1 is free
+                        WN_TR(ch, 2);
+                        if constexpr (PIPE == 2) {
+                            stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});      // chunk ch+NBUF-1 (zero chunks past the end keep vmcnt uniform)
+                            WN_TR(ch, 3);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mfma_set(std::integral_constant<int, ks & 1>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            read_frags(std::integral_constant<int, (BUF + 1) % NBUF>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else {
+                            // PIPE 3 / 5: the (slow, wave-blocking) DMA issue goes LAST, behind MFMAs that are already in the pipe
+                            read_frags(std::integral_constant<int, (BUF + 1) % NBUF>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            mfma_set(std::integral_constant<int, ks & 1>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }(), ...);
+            }(std::make_integer_sequence<int, Cfg::KS>{});
+        };
+        stage(std::integral_constant<int, 0>{});
+        stage(std::integral_constant<int, 1>{});
+        if constexpr (NBUF == 4) stage(std::integral_constant<int, 2>{});
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (APW + BPW)) : "memory");      // chunk 0 landed (non-issuing waves: trivially true)
+        __builtin_amdgcn_s_barrier();
+        read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        for (int ch = 0; ch < npad; ch += NBUF) {
+            step2(std::integral_constant<int, 0>{}, ch);
+            step2(std::integral_constant<int, 1>{}, ch + 1);
+            step2(std::integral_constant<int, 2>{}, ch + 2);
+            if constexpr (NBUF == 4) step2(std::integral_constant<int, 3>{}, ch + 3);
+        }
+        // the trailing fragment reads (of a buffer nobody multiplies) must retire before the epilogue reuses the registers / LDS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(fa[0][0]), "v"(fb[0][0]) : "memory");
+    } else {
     // prologue: fill NBUF-1 buffers
     stage(std::integral_constant<int, 0>{});
     if constexpr (NBUF == 3) { if (nchunks > 1) stage(std::integral_constant<int, 1>{}); }
@@ -567,8 +686,15 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1);
         if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2); }
     }
+    }
 
 #ifdef WN_EPI_ABLATE
+    if ((dbg & 32) && a.trace && tid == 0) {
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[(size_t)blockIdx.x * 4 + 0] = wg_t_start; a.trace[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+        a.trace[(size_t)blockIdx.x * 4 + 2] = hwid; a.trace[(size_t)blockIdx.x * 4 + 3] = xcc;
+    }
     if (a.e.scale != -7777.0f) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -720,12 +846,24 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.ntiles = a.tiles_per_utt * a.B;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             a.stagger = grid >= 1024 ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
-            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
+            static const int pipe_override = [] { const char* e = getenv("WN_GEMM_PIPE"); return e ? atoi(e) : 1; }();   // A/B switch for measurements (PIPE 2/3 pad the chunk count: slower on the 8- and 16-chunk kernels)
+            if (pipe_override == 2) hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 2>), dim3(grid), dim3(512), 0, st, a);
+            else if (pipe_override == 3) hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 3>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
             return WN_OK;
         }
     }
     if constexpr (EPI == EPI_STORE_F32_BOT) {
+        if (M == 96 && a.zero) {           // d c_up with <= 96 conditioning channels: 96 channels x 192 time rows, 6 waves (32 x 96 each)
+            a.mblocks = 1;
+            a.tiles_per_utt = cdiv(a.T, 192);
+            a.ntiles = a.tiles_per_utt * a.B;
+            const int grid = cdiv(a.ntiles, 8) * 8;
+            hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 3, 3, 2, 32, 3, EPI>), dim3(grid), dim3(384), 0, st, a);
+            WN_LAUNCH_CHECK(ctx);
+            return WN_OK;
+        }
         if (M % 128 == 0 && a.zero) {      // d c_up: M = cin padded to 128, K = L*G: 128 channels x 256 time rows per workgroup
             a.mblocks = M / 128;
             a.tiles_per_utt = cdiv(a.T, 256);

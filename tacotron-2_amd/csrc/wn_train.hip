@@ -85,6 +85,20 @@ static void wgrad_out_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int
         q.out_off = c->lay[l].out_k; q.bias_off = c->lay[l].out_b; q.bias2_off = 0; q.has_bias2 = 0; q.scale = 1.0f;
     }
 }
+// d W_skip and d W_out share the A operand u_l: one launch, B = [d skip | rho dL/dh_{l+1}] side by side (N = S + R).  The top
+// layer's residual branch is dead: GXall[L] is zero-filled, so its W_out gradient comes out as exact zeros.
+static void wgrad_skipout_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int T) {
+    const int64_t NT = c->NT; const int GH = c->GH, S = c->S, R = c->R;
+    wgrad_common(c, w, ng, B, T);
+    w.nseg = 1; w.seg_base[0] = c->U + (size_t)l0 * NT * GH; w.seg_gstride[0] = NT * GH; w.seg_ld[0] = GH; w.seg_nk[0] = GH;
+    w.Bm = c->DSKIP; w.b_gstride = 0; w.ldb = S; w.N = S + R; w.ldw = S;
+    w.Bm_hi = c->GXall + (size_t)(l0 + 1) * NT * R; w.b_gstride_hi = NT * R; w.ldb_hi = R; w.split_n = S; w.ldw_hi = R;
+    for (int g = 0; g < ng; ++g) {
+        const int l = l0 + g; WgGroup& q = w.g[g];
+        q.out_off = c->lay[l].skip_k; q.bias_off = c->lay[l].skip_b; q.bias2_off = 0; q.has_bias2 = 0; q.scale = c->skip_scale[l];
+        q.out_off_hi = c->lay[l].out_k; q.bias_off_hi = c->lay[l].out_b; q.scale_hi = 1.0f;
+    }
+}
 // bytes of split-K partials the grouped launches can need for any batch <= max_batch at max_time
 size_t wn_wgrad_partial_need(wn_ctx* c) {
     size_t need = 0;
@@ -94,6 +108,7 @@ size_t wn_wgrad_partial_need(wn_ctx* c) {
         wgrad_w1_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
         wgrad_skip_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
         wgrad_out_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
+        wgrad_skipout_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
     }
     return need + (1 << 20);
 }
@@ -237,14 +252,20 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
             WgBatchArgs w; wgrad_w1_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
             if ((rc = launch_wgrad_batch(c, w, st))) return rc;
         }
-        {   // d W_skip (scaled by the legacy factor c_l), d skip bias:  A = u_l,  B = d skip (shared by all layers)
-            WgBatchArgs w; wgrad_skip_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
+        if (c->S % 256 == 0 && c->R % 256 == 0) {
+            // d W_skip (scaled by the legacy factor c_l) and d W_out with their biases in ONE launch: A = u_l, B = [d skip | rho dL/dh_{l+1}]
+            WgBatchArgs w; wgrad_skipout_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
             if ((rc = launch_wgrad_batch(c, w, st))) return rc;
-        }
-        const int ngo = min(ng, L - 1 - l0);      // the top layer's residual branch is dead: zero gradient
-        if (ngo > 0) {   // d W_out, d out bias:  A = u_l,  B = rho * dL/dh_{l+1}
-            WgBatchArgs w; wgrad_out_args(c, w, l0, ngo, c->fB, c->fT); w.grads = grads;
-            if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+        } else {
+            {   // d W_skip (scaled by the legacy factor c_l), d skip bias:  A = u_l,  B = d skip (shared by all layers)
+                WgBatchArgs w; wgrad_skip_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
+                if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+            }
+            const int ngo = min(ng, L - 1 - l0);      // the top layer's residual branch is dead: zero gradient
+            if (ngo > 0) {   // d W_out, d out bias:  A = u_l,  B = rho * dL/dh_{l+1}
+                WgBatchArgs w; wgrad_out_args(c, w, l0, ngo, c->fB, c->fT); w.grads = grads;
+                if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+            }
         }
     }
     for (int l = L - 1; !grouped && l >= 0; --l) {      // narrow channel counts (N % 256 != 0): per-layer v1 kernels

@@ -177,12 +177,20 @@ __global__ __launch_bounds__(256) void wn_wgrad_kernel(const WgArgs a) {
 //     once and shared through that XCD's L2;
 //   * no atomics (512 workgroups adding into the same 128-KiB tile serialise in L2: measured 3-40x slower):
 //     every workgroup stores its fp32 tile to a partial buffer and wn_wgrad_reduce_kernel sums the units.
+// LDS-DMA as inline asm (see lds_dma16 in wn_tile.h: keeps hipcc's waitcnt pass from turning every LDS-read wait into
+// lgkmcnt(0) / vmcnt(0) while DMAs are in flight; ordering is enforced by the counted vmcnt + barrier of the ring).
+__device__ __forceinline__ void wg_lds_dma16(const void* gsrc, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
+}
 #define WN_MAX_GROUPS 32
-struct WgGroup { int64_t out_off, bias_off, bias2_off; int32_t shift[4]; float scale; int32_t has_bias2; };
+struct WgGroup { int64_t out_off, bias_off, bias2_off; int32_t shift[4]; float scale; int32_t has_bias2;
+                 int64_t out_off_hi, bias_off_hi; float scale_hi; int32_t pad_; };   // targets of the columns >= split_n (fused launches)
 struct WgBatchArgs {
     int32_t ngroups, nseg;
     const bf16_t* seg_base[4]; int64_t seg_gstride[4]; int32_t seg_ld[4], seg_nk[4];
     const bf16_t* Bm; int64_t b_gstride; int32_t ldb, N;
+    // fused launch (same A operand, two B operands side by side): columns [split_n, N) come from Bm_hi and go to *_hi targets
+    const bf16_t* Bm_hi; int64_t b_gstride_hi; int32_t ldb_hi, split_n, ldw_hi, pad0_;
     float* grads; int32_t ldw;
     float* partial;                     // [unit][mtiles*128 + 8][N] fp32; row mtiles*128 = bias partial
     int32_t B, T, slab, spu, Mrows, mtiles, ntiles, nunits;
@@ -227,7 +235,9 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
         }
     }
     const int n0 = nblk * 256;
-    const bf16_t* b_base = a.Bm + (int64_t)grp * a.b_gstride + n0;
+    const bool hi = a.split_n > 0 && n0 >= a.split_n;
+    const bf16_t* b_base = hi ? a.Bm_hi + (int64_t)grp * a.b_gstride_hi + (n0 - a.split_n) : a.Bm + (int64_t)grp * a.b_gstride + n0;
+    const int b_ld = hi ? a.ldb_hi : a.ldb;
 
     f32x16_t acc[2][2];
 #pragma unroll
@@ -252,8 +262,7 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
             const int t = tc + row, ts = t + a_shift;
             const bool ok = (c * 8 < a_valid) && (t < ts1) && (ts >= 0) && (ts < T);
             const bf16_t* src = ok ? a_base + (rowbase + ts) * a_ld + c * 8 : a.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(abuf + wave * 1024), 16, 0, 0);
+            wg_lds_dma16(src, __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(abuf + wave * 1024)));
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {   // B: piece g = rows g*2, g*2+1, 32 slots each
@@ -262,9 +271,8 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
             const int c = (lane & 31) ^ ((row & 3) << 2);
             const int t = tc + row;
             const bool ok = (t < ts1) && (n0 + c * 8 < a.N);
-            const bf16_t* src = ok ? b_base + (rowbase + t) * a.ldb + c * 8 : a.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(bbuf + g * 1024), 16, 0, 0);
+            const bf16_t* src = ok ? b_base + (rowbase + t) * b_ld + c * 8 : a.zero;
+            wg_lds_dma16(src, __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(bbuf + g * 1024)));
         }
     };
     // per-lane constants of the transposing reads: lane -> (row within a 4-row block, 8-B piece within the 16 channels)
@@ -402,12 +410,17 @@ __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(const WgBatchArgs 
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     const WgGroup& g = a.g[grp];
-    s.x *= g.scale; s.y *= g.scale; s.z *= g.scale; s.w *= g.scale;
+    const bool hi = a.split_n > 0 && c4 * 4 >= a.split_n;
+    const float sc = hi ? g.scale_hi : g.scale;
+    const int col = hi ? c4 * 4 - a.split_n : c4 * 4;
+    s.x *= sc; s.y *= sc; s.z *= sc; s.w *= sc;
     auto add4 = [&](float* dst) { float4 o = *reinterpret_cast<float4*>(dst); o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w; *reinterpret_cast<float4*>(dst) = o; };
-    if (!is_bias) add4(a.grads + g.out_off + (int64_t)m * a.ldw + c4 * 4);
-    else {
-        if (g.bias_off >= 0) add4(a.grads + g.bias_off + c4 * 4);
-        if (g.has_bias2) add4(a.grads + g.bias2_off + c4 * 4);
+    if (!is_bias) add4(a.grads + (hi ? g.out_off_hi : g.out_off) + (int64_t)m * (hi ? a.ldw_hi : a.ldw) + col);
+    else if (hi) {
+        if (g.bias_off_hi >= 0) add4(a.grads + g.bias_off_hi + col);
+    } else {
+        if (g.bias_off >= 0) add4(a.grads + g.bias_off + col);
+        if (g.has_bias2) add4(a.grads + g.bias2_off + col);
     }
 }
 

@@ -1,11 +1,13 @@
 // Stand-alone check + timing of the tile-engine main loops (run on the GPU box):
 //   v1 = wn_gemm_tile_kernel (A fragments straight from L2), v2 = wn_gemm_lds_kernel (LDS-DMA ring).
 // Same GemmArgs, same accumulation order => outputs must be BITWISE identical.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tacotron-2_amd/csrc tools/gemm_harness.hip -o tools/gemm_harness
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc tools/gemm_harness.hip -o tools/gemm_harness
 #include "wn_tile.h"
 #include <vector>
 #include <random>
 #include <functional>
+#include <map>
+#include <algorithm>
 
 std::string g_create_err;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -75,6 +77,15 @@ int main(int argc, char** argv) {
     };
     auto mkseg = [](const bf16_t* b, int ld, int col0, int nk, int shift) { SrcSeg s; s.base = b; s.ld = ld; s.col0 = col0; s.nk = nk; s.shift = shift; s.dropout = 0; return s; };
 
+    {
+        int nb = -1; hipFuncAttributes fa;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI_GATE, 1>, 512, 0));
+        CK(hipFuncGetAttributes(&fa, (const void*)wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI_GATE, 1>));
+        printf("occupancy gate<2,2,4,2,32,3,PIPE1>: %d blocks/CU, %d regs, %zu B static LDS, maxThreads %d\n", nb, fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock);
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI_DX, 1>, 512, 0));
+        CK(hipFuncGetAttributes(&fa, (const void*)wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI_DX, 1>));
+        printf("occupancy dx<2,2,4,2,32,3,PIPE1>: %d blocks/CU, %d regs, %zu B static LDS\n", nb, fa.numRegs, fa.sharedSizeBytes);
+    }
     {   // ---------------- gate GEMM: M = 512, K = 3*256 + 80 = 848
         const int M = G, K = 3 * R + C, d = 64;
         bf16_t* Apk = dev_bf16_random((size_t)M * K, 0.05f);
@@ -98,11 +109,61 @@ int main(int argc, char** argv) {
         printf("gate   v2 MT%d NT%d WM%d WN%d BK%d NBUF%d PIPE%d : %8.1f us  %7.1f TF  %s\n", MT_, NT_, WM_, WN_, BK_, NB_, PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
         TRY_GATE2(2, 2, 4, 2, 32, 3) TRY_GATE2(2, 2, 4, 2, 32, 2) 
         TRY_GATE2(4, 2, 2, 4, 32, 3) TRY_GATE2(2, 4, 4, 2, 32, 3)
-        TRY_GATE3(2, 2, 4, 2, 32, 3, 1) TRY_GATE3(4, 2, 2, 4, 32, 3, 1) TRY_GATE3(2, 4, 4, 2, 32, 3, 1) TRY_GATE3(2, 2, 4, 2, 32, 2, 1)
-        for (int sg : {0, 4000, 16000}) { a2.stagger = sg; printf("  stagger %5d: ", sg); TRY_GATE2(2, 2, 4, 2, 32, 3) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 1) }
-        for (int sg : {0, 8000, 16000, 32000, 64000}) { a2.stagger = sg; printf("  stagger %5d: ", sg); TRY_GATE2(4, 2, 2, 4, 32, 3) printf("  stagger %5d: ", sg); TRY_GATE3(4, 2, 2, 4, 32, 3, 1) }
+        TRY_GATE3(2, 2, 4, 2, 32, 3, 1) TRY_GATE3(2, 2, 4, 2, 32, 3, 2) TRY_GATE3(4, 2, 2, 4, 32, 3, 2) TRY_GATE3(2, 4, 4, 2, 32, 3, 2) TRY_GATE3(2, 2, 4, 2, 64, 3, 2)
+        for (int sg : {0, 16000, 0}) { a2.stagger = sg; printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 4, 32, 4, 3) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 4, 32, 4, 2) printf("  stagger %5d: ", sg); TRY_GATE3(4, 2, 2, 4, 32, 4, 3) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 1) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 2) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 3) printf("  stagger %5d: ", sg); TRY_GATE3(4, 2, 2, 4, 32, 3, 3) }
 #ifdef WN_EPI_ABLATE
-        for (int dbgf : {1, 2, 3, 4, 7}) { a2.stagger = -dbgf; printf("  probe flags %d (1 noDMA 2 noLDSread 4 nobarrier): ", dbgf); TRY_GATE3(2, 2, 4, 2, 32, 3, 1) }
+        {   // main-loop timeline of the first workgroups (wave 0 and wave 5): stamps [before vmcnt wait, after it, after barrier, after DMA issue]
+            unsigned long long* tr; const size_t trn = (size_t)1024 * 2 * 64 * 4;
+            CK(hipMalloc(&tr, trn * 8)); CK(hipMemset(tr, 0, trn * 8));
+            a2.trace = tr; a2.stagger = -16;
+            launch_v2<2, 2, 4, 2, 32, 3, EPI_GATE, 2>(a2, M, 0); CK(hipDeviceSynchronize());
+            CK(hipMemset(tr, 0, trn * 8));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            CK(hipEventRecord(e0, 0));
+            launch_v2<2, 2, 4, 2, 32, 3, EPI_GATE, 2>(a2, M, 0);
+            CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+            float kms; CK(hipEventElapsedTime(&kms, e0, e1));
+            std::vector<unsigned long long> h(trn); CK(hipMemcpy(h.data(), tr, trn * 8, hipMemcpyDeviceToHost));
+            {
+                unsigned long long tmin = ~0ull, tmax = 0;
+                for (int wg = 0; wg < 1024; ++wg) { const unsigned long long* t = h.data() + ((size_t)wg * 2) * 64 * 4; if (t[0]) { tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[26 * 4 + 3]); } }
+                printf("trace span of the first 1024 workgroups: %llu ticks; kernel %.1f us by hipEvent => >= %.0f MHz tick rate if they span the kernel\n", tmax - tmin, kms * 1e3, (tmax - tmin) / (kms * 1e3));
+            }
+            for (int wg : {0, 512}) for (int wv = 0; wv < 1; ++wv) {
+                const unsigned long long* t = h.data() + ((size_t)wg * 2 + wv) * 64 * 4;
+                printf("trace wg %4d wave %d: start %llu\n   chunk: [mfma0+reads -> vmwait -> barrier -> dma-issue -> (mfma1+reads)]\n", wg, wv ? 5 : 0, t[0]);
+                for (int ch = 0; ch < 27; ++ch) {
+                    const unsigned long long prev = ch ? t[(ch - 1) * 4 + 3] : t[0];
+                    printf("   %2d: +%5llu | vm %5llu | bar %5llu | dma %5llu   (t=%llu)\n", ch, t[ch * 4] - prev, t[ch * 4 + 1] - t[ch * 4], t[ch * 4 + 2] - t[ch * 4 + 1], t[ch * 4 + 3] - t[ch * 4 + 2], t[ch * 4 + 3] - t[0]);
+                }
+            }
+            // per-CU kernel duration in shader ticks vs wall time => the clock the kernel actually ran at
+            for (int dbgf : {32, 33}) {
+                CK(hipMemset(tr, 0, trn * 8));
+                a2.stagger = -dbgf;
+                launch_v2<2, 2, 4, 2, 32, 3, EPI_GATE, 3>(a2, M, 0); CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, 0));
+                launch_v2<2, 2, 4, 2, 32, 3, EPI_GATE, 3>(a2, M, 0);
+                CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+                CK(hipEventElapsedTime(&kms, e0, e1));
+                CK(hipMemcpy(h.data(), tr, trn * 8, hipMemcpyDeviceToHost));
+                std::map<unsigned long long, std::pair<unsigned long long, unsigned long long>> cu;   // (xcc, se, cu) -> (min start, max end)
+                double wgsum = 0; int nwg = 0;
+                for (int wg = 0; wg < 1376; ++wg) {
+                    const unsigned long long* t = h.data() + (size_t)wg * 4;
+                    if (!t[0]) continue;
+                    const unsigned long long key = (t[3] << 32) | (t[2] & 0xff00);      // xcc | se/sh/cu bits
+                    auto it = cu.find(key);
+                    if (it == cu.end()) cu[key] = {t[0], t[1]}; else { it->second.first = std::min(it->second.first, t[0]); it->second.second = std::max(it->second.second, t[1]); }
+                    wgsum += (double)(t[1] - t[0]); ++nwg;
+                }
+                double mx = 0, av = 0; for (auto& kv : cu) { const double d = (double)(kv.second.second - kv.second.first); mx = std::max(mx, d); av += d; }
+                printf("clock probe (flags %d): %zu CUs seen, per-CU span avg %.0f max %.0f ticks, kernel %.1f us => %.0f MHz (by max span); mean WG duration %.0f ticks over %d WGs\n",
+                       dbgf, cu.size(), av / cu.size(), mx, kms * 1e3, mx / (kms * 1e3), wgsum / nwg, nwg);
+            }
+            a2.trace = nullptr; a2.stagger = 0;
+        }
+        for (int dbgf : {0, 1, 2, 3, 7}) { a2.stagger = dbgf ? -dbgf : 0; printf("  probe flags %d (1 noDMA 2 noLDSread 4 nobarrier 8 hotDMA): ", dbgf); TRY_GATE3(2, 2, 4, 2, 32, 3, 2) }
 #endif
         a2.stagger = 0;
     }
