@@ -15,7 +15,7 @@ MoL, raw 16-bit scalar input, 80-mel local conditioning through the '2D' upsampl
 dropout 0.05, batch 8 x 11 000 samples per GPU, bf16 MFMA operands with fp32 accumulation.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (gate GEMM `wn_gemm_tile_kernel<2,2,2,2,EPI_GATE>`, one launch per
+  roofline     -- the dominant kernel (gate GEMM `wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1>`, one launch per
                   layer and step) timed live with HIP events on its launch stream inside the timed region;
   cpu_baseline -- the oracle (CPU restatement of the reference arithmetic, torch-CPU fp32 on all host
                   cores) running the same training step on a bounded sample of the same workload.
@@ -63,6 +63,17 @@ def mac_per_sample(hp):
     R, G, S, O, C, L = hp.residual_channels, hp.gate_channels, hp.skip_out_channels, hp.out_channels, hp.cin_channels, hp.layers
     cin = 1 if hp.input_type != 'mulaw-quantize' else hp.quantize_channels
     return cin * R + L * (3 * R * G + C * G + (G // 2) * S + (G // 2) * R) + S * S + S * O
+
+
+def alg_bytes_per_sample(hp, e=2):
+    """bytes_train = 3 * e * [L (2R + C + 2S) + Cin + O] + 2 e L (G + G/2)."""
+    R, G, S, O, C, L = hp.residual_channels, hp.gate_channels, hp.skip_out_channels, hp.out_channels, hp.cin_channels, hp.layers
+    cin = 1 if hp.input_type != 'mulaw-quantize' else hp.quantize_channels
+    return 3 * e * (L * (2 * R + C + 2 * S) + cin + O) + 2 * e * L * (G + G // 2)
+
+
+# measured HBM-side traffic of ONE gate-GEMM launch at C2 (B=8, T=11000): 2 x 59.59e3 KiB fetched + 132.0e3 KiB written
+GATE_TRAFFIC_BYTES = (2 * 59.59e3 + 132.0e3) * 1024.0
 
 
 def synthetic_batch(hp, B, T, seed, device):
@@ -264,10 +275,15 @@ def main():
             'samples_per_sec_per_gpu': value / world,
             'train_tflops_algorithmic': 6.0 * mac * value / 1e12,
             'final_loss': final_loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_tile_kernel<2,2,2,2,EPI_GATE> (dilated conv + cond GEMM + gate, fwd)',
+            'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1> (dilated conv + cond GEMM + gate, fwd)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                         'traffic': None, 'launches_timed': int(prof_n), 'avg_launch_ms': avg_s * 1e3 if prof_n else None,
-                         'alg_flops_per_launch': flops_launch},
+                         'traffic': GATE_TRAFFIC_BYTES if args.workload == 'c2' and B == 8 and T == 11000 else None,
+                         'traffic_source': 'profiles/r1b_c2_train_pmc_{fetch,write}_size.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC, gfx950 correction)',
+                         'launches_timed': int(prof_n), 'avg_launch_ms': avg_s * 1e3 if prof_n else None,
+                         'alg_flops_per_launch': flops_launch, 'alg_bytes_per_launch': float(B * T) * (2 * R + 2 * C + 2 * G + G)},
+            # whole-step view asked for by the north star: SURVEY 8d algorithmic HBM bytes per audio sample (bf16) x samples/s vs 8 TB/s
+            'hbm_roofline_whole_step': {'alg_bytes_per_sample': alg_bytes_per_sample(hp), 'achieved_GBps': alg_bytes_per_sample(hp) * value / world / 1e9,
+                                        'peak_GBps': 8000.0, 'frac': alg_bytes_per_sample(hp) * value / world / 8e12},
         }
         if not args.no_synth:
             _log('synthesis measurement ...')

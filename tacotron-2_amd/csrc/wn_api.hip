@@ -201,7 +201,7 @@ extern "C" int wn_tensor_info(const wn_ctx* c, int i, char* name, int32_t* shape
     return WN_OK;
 }
 extern "C" int64_t wn_workspace_bytes(const wn_ctx* c) { return (int64_t)(c->ws_bytes + c->wg_partial_bytes); }
-extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_tile_kernel"; }
+extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, 0, 1>"; }
 
 extern "C" int wn_pack_weights(wn_ctx* c, const float* params, void* stream) {
     if (!c || !params) return WN_E_ARG;
