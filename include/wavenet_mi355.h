@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 1
+#define WN_ABI_VERSION 2
 
 enum wn_status {
     WN_OK = 0,
@@ -78,6 +78,11 @@ typedef struct wn_config {
     /* capacity: workspace is sized once for these (288 GB HBM: be generous) */
     int32_t max_batch;              /* utterances per call                       */
     int32_t max_time;               /* samples per utterance (train or synth)    */
+    /* global conditioning (hparams.py:228-230; wavenet.py:152-158, 669-678; modules.py:10-21, 426-432, 499-508) */
+    int32_t gin_channels;           /* <= 0 disables                                                          */
+    int32_t use_speaker_embedding;  /* 1: g = speaker ids looked up in the [n_speakers, gin_channels] table    */
+    int32_t n_speakers;
+    int32_t reserved0;
 } wn_config;
 
 typedef struct wn_ctx wn_ctx;
@@ -97,6 +102,11 @@ int     wn_tensor_info(const wn_ctx* ctx, int index, char* name, int32_t* shape,
 /* Re-pack the flat fp32 parameters into the bf16 MFMA-fragment-ordered copies the kernels read
  * (ctx-owned).  Call after every change of the parameters (i.e. after wn_optim_step). */
 int wn_pack_weights(wn_ctx* ctx, const float* params, void* stream);
+
+/* Global conditioning of the NEXT forward / synthesis call (wavenet.py:669-678 / :766-777): g = int32 speaker ids [B]
+ * when cfg.use_speaker_embedding, else float [B, gin_channels].  Copied into the context (pointer borrowed for the call).
+ * Required before wn_train_fwd / wn_synthesize when cfg.gin_channels > 0 ("g" must match the batch size). */
+int wn_set_global_condition(wn_ctx* ctx, const void* g, int32_t B, void* stream);
 
 /* ---- training: replaces WaveNet.step + add_loss (wavenet.py:650-721, 476-495) ----------------- */
 /* x        scalar input: float [B,1,T]; mulaw-quantize: int32 class ids [B,T] (== the reference's one-hot

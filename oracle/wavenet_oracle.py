@@ -60,6 +60,9 @@ class OracleConfig:
     NN_init: bool = True
     NN_scaler: float = 0.1
     wavenet_dropout: float = 0.05
+    gin_channels: int = -1                 # hparams.py:228: <= 0 disables global conditioning
+    use_speaker_embedding: bool = True     # hparams.py:229
+    n_speakers: int = 5                    # hparams.py:230
 
     @property
     def scalar_input(self):
@@ -105,19 +108,30 @@ def param_shapes(cfg: OracleConfig):
     sh['input_convolution/bias'] = (R,)
     for l in range(cfg.layers):
         p = 'ResidualConv1DGLU_%d/' % l
+        ub = cfg.use_bias                     # hparams.py:189: only the convolutions inside ResidualConv1DGLU (modules.py:399-446)
         sh[p + 'residual_block_causal_conv/kernel'] = (k, R, G)
-        sh[p + 'residual_block_causal_conv/bias'] = (G,)
+        if ub:
+            sh[p + 'residual_block_causal_conv/bias'] = (G,)
         if C > 0:
             sh[p + 'residual_block_cin_conv/kernel'] = (1, C, G)
-            sh[p + 'residual_block_cin_conv/bias'] = (G,)
+            if ub:
+                sh[p + 'residual_block_cin_conv/bias'] = (G,)
+        if cfg.gin_channels > 0:              # modules.py:426-432
+            sh[p + 'residual_block_gin_conv/kernel'] = (1, cfg.gin_channels, G)
+            if ub:
+                sh[p + 'residual_block_gin_conv/bias'] = (G,)
         sh[p + 'residual_block_skip_conv/kernel'] = (1, G // 2, S)
-        sh[p + 'residual_block_skip_conv/bias'] = (S,)
+        if ub:
+            sh[p + 'residual_block_skip_conv/bias'] = (S,)
         sh[p + 'residual_block_out_conv/kernel'] = (1, G // 2, R)
-        sh[p + 'residual_block_out_conv/bias'] = (R,)
+        if ub:
+            sh[p + 'residual_block_out_conv/bias'] = (R,)
     sh['final_convolution_1/kernel'] = (1, S, S)
     sh['final_convolution_1/bias'] = (S,)
     sh['final_convolution_2/kernel'] = (1, S, O)
     sh['final_convolution_2/bias'] = (O,)
+    if cfg.gin_channels > 0 and cfg.use_speaker_embedding:          # modules.py:13-17, wavenet.py:152-158
+        sh['gc_embedding'] = (cfg.n_speakers, cfg.gin_channels)
     if C > 0 and cfg.upsample_type != 'NearestNeighbor':
         fk = cfg.freq_axis_kernel_size
         for i, s in enumerate(cfg.upsample_scales):
@@ -187,6 +201,8 @@ def init_params(cfg: OracleConfig, seed=5339, bias_scale=0.0):
             t = torch.zeros(shape)
             if bias_scale > 0:
                 t = (torch.rand(shape, generator=g) * 2 - 1) * bias_scale
+        elif name == 'gc_embedding':                      # tf.truncated_normal_initializer(0, 0.1), modules.py:16-17
+            t = torch.fmod(torch.randn(shape, generator=g), 2.0) * 0.1
         elif name.startswith('local_conditioning_upsampling') and cfg.NN_init:
             i = int(name.split('/')[0].rsplit('_', 1)[1]) - 1
             t = torch.from_numpy(np.ascontiguousarray(_nn_init_kernel(cfg, i, cfg.upsample_scales[i])))
@@ -260,13 +276,22 @@ def upsample(params, cfg: OracleConfig, c):
 
 
 # ----------------------------------------------------------------------------- batch forward
+def global_features(params, cfg, g):
+    """wavenet.py:669-678: speaker ids [B] -> embedding rows (modules.py:19-21), or the given [B, gin] features."""
+    if cfg.gin_channels <= 0 or g is None:
+        return None
+    if cfg.use_speaker_embedding:
+        return params['gc_embedding'][torch.as_tensor(g).long().reshape(-1)]
+    return torch.as_tensor(g).float().reshape(-1, cfg.gin_channels)
+
+
 def _conv1x1(x, K, b):
     """x [B,Cin,T], K TF [1,Cin,Cout]."""
     y = torch.einsum('bit,io->bot', x, K[0])
     return y if b is None else y + b[None, :, None]
 
 
-def step(params, cfg: OracleConfig, x, c, dropout_masks=None, emulate_bf16=False, return_aux=False):
+def step(params, cfg: OracleConfig, x, c, dropout_masks=None, emulate_bf16=False, return_aux=False, g=None):
     """Teacher-forced parallel forward.  wavenet.py:650-721.
 
     x [B, Cin, T] fp32, c [B, C, Tc] fp32 -> y_hat [B, O, T].
@@ -277,8 +302,9 @@ def step(params, cfg: OracleConfig, x, c, dropout_masks=None, emulate_bf16=False
     q = bf16_round if emulate_bf16 else (lambda t: t)
     # HIP path: bf16 MFMA operands for every conv except the (fp32, K=Cin) input conv and the
     # (fp32) upsample kernels
-    P = {k: (q(v) if k.endswith('kernel') and not k.startswith(('local_conditioning', 'input_convolution')) else v)
+    P = {k: (q(v) if k.endswith('kernel') and not k.startswith(('local_conditioning', 'input_convolution')) and 'gin_conv' not in k else v)
          for k, v in params.items()}
+    gvec = global_features(params, cfg, g)                                   # [B, gin] or None (wavenet.py:669-678)
     k = cfg.kernel_size
     aux = {}
     cu = None
@@ -301,15 +327,19 @@ def step(params, cfg: OracleConfig, x, c, dropout_masks=None, emulate_bf16=False
         aux['layer_in'].append(h)
         W = P[p + 'residual_block_causal_conv/kernel']                       # [k,R,G]
         z = F.conv1d(F.pad(xin, ((k - 1) * d, 0)), W.permute(2, 1, 0).contiguous(),
-                     params[p + 'residual_block_causal_conv/bias'], dilation=d)   # modules.py:306-320
+                     params.get(p + 'residual_block_causal_conv/bias'), dilation=d)   # modules.py:306-320
         if cu is not None:                                                   # modules.py:497-501
             z = z + _conv1x1(cu, P[p + 'residual_block_cin_conv/kernel'],
-                             params[p + 'residual_block_cin_conv/bias'])
+                             params.get(p + 'residual_block_cin_conv/bias'))
+        if gvec is not None:                                                 # modules.py:503-508: g broadcast over time
+            zg = gvec @ params[p + 'residual_block_gin_conv/kernel'][0]
+            bg = params.get(p + 'residual_block_gin_conv/bias')
+            z = z + (zg if bg is None else zg + bg)[:, :, None]
         a, b = z.chunk(2, dim=1)                                             # modules.py:494
         u = q(torch.tanh(a) * torch.sigmoid(b))                              # modules.py:510
         aux['u'].append(u)
-        s = _conv1x1(u, P[p + 'residual_block_skip_conv/kernel'], params[p + 'residual_block_skip_conv/bias'])
-        o = _conv1x1(u, P[p + 'residual_block_out_conv/kernel'], params[p + 'residual_block_out_conv/bias'])
+        s = _conv1x1(u, P[p + 'residual_block_skip_conv/kernel'], params.get(p + 'residual_block_skip_conv/bias'))
+        o = _conv1x1(u, P[p + 'residual_block_out_conv/kernel'], params.get(p + 'residual_block_out_conv/bias'))
         h = (o + residual) * SQRT_HALF if cfg.residual_legacy else (o + residual)   # modules.py:517-520
         h = q(h)
         if skips is None:                                                    # wavenet.py:706-715
@@ -468,7 +498,7 @@ def initial_input(cfg: OracleConfig, B):
 
 
 def incremental(params, cfg: OracleConfig, c, T=None, noise=None, test_inputs=None,
-                formulation='reference'):
+                formulation='reference', g=None):
     """Fast-WaveNet autoregressive generation.  wavenet.py:724-911, modules.py:273-303.
 
     c [B,C,Tc] (already transposed as :427).  noise: dict with
@@ -494,10 +524,13 @@ def incremental(params, cfg: OracleConfig, c, T=None, noise=None, test_inputs=No
         p = 'ResidualConv1DGLU_%d/' % l
         lw.append(dict(
             Wlin=params[p + 'residual_block_causal_conv/kernel'].reshape(-1, cfg.gate_channels),  # modules.py:251
-            b=params[p + 'residual_block_causal_conv/bias'],
-            Wc=params[p + 'residual_block_cin_conv/kernel'][0], bc=params[p + 'residual_block_cin_conv/bias'],
-            Ws=params[p + 'residual_block_skip_conv/kernel'][0], bs=params[p + 'residual_block_skip_conv/bias'],
-            Wo=params[p + 'residual_block_out_conv/kernel'][0], bo=params[p + 'residual_block_out_conv/bias']))
+            b=params.get(p + 'residual_block_causal_conv/bias', 0.0),
+            Wc=params[p + 'residual_block_cin_conv/kernel'][0], bc=params.get(p + 'residual_block_cin_conv/bias', 0.0),
+            Wg=params[p + 'residual_block_gin_conv/kernel'][0] if cfg.gin_channels > 0 else None,
+            bg=params.get(p + 'residual_block_gin_conv/bias', 0.0),
+            Ws=params[p + 'residual_block_skip_conv/kernel'][0], bs=params.get(p + 'residual_block_skip_conv/bias', 0.0),
+            Wo=params[p + 'residual_block_out_conv/kernel'][0], bo=params.get(p + 'residual_block_out_conv/bias', 0.0)))
+    gvec = global_features(params, cfg, g)                                     # wavenet.py:766-777
     W1, b1 = params['final_convolution_1/kernel'][0], params['final_convolution_1/bias']
     W2, b2 = params['final_convolution_2/kernel'][0], params['final_convolution_2/bias']
     if formulation == 'reference':
@@ -522,6 +555,8 @@ def incremental(params, cfg: OracleConfig, c, T=None, noise=None, test_inputs=No
                 taps = torch.stack([rings[l][:, (t - 2 * d) % n, :], rings[l][:, (t - d) % n, :], x], dim=1)
             z = taps.reshape(B, -1) @ w['Wlin'] + w['b']                        # modules.py:295-297
             z = z + (ct @ w['Wc'] + w['bc'])
+            if gvec is not None:
+                z = z + (gvec @ w['Wg'] + w['bg'])                              # modules.py:503-508
             a, b = z.chunk(2, dim=-1)
             u = torch.tanh(a) * torch.sigmoid(b)
             s = u @ w['Ws'] + w['bs']

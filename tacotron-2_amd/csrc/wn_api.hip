@@ -29,18 +29,28 @@ static void build_layout(wn_ctx* c) {
         auto nm = [&](const char* s) { snprintf(buf, sizeof buf, "ResidualConv1DGLU_%d/%s", l, s); return std::string(buf); };
         add_tensor(c, nm("residual_block_causal_conv/kernel"), {3, c->R, c->G}, &o.dil_k);
         add_tensor(c, nm("residual_block_cin_conv/kernel"), {1, c->C, c->G}, &o.cin_k);
-        add_tensor(c, nm("residual_block_causal_conv/bias"), {c->G}, &o.dil_b);
-        add_tensor(c, nm("residual_block_cin_conv/bias"), {c->G}, &o.cin_b);
+        o.dil_b = o.cin_b = o.skip_b = o.out_b = -1;
+        if (c->lbias) {          // use_bias (hparams.py:189) governs only the convolutions inside ResidualConv1DGLU (modules.py:399-446)
+            add_tensor(c, nm("residual_block_causal_conv/bias"), {c->G}, &o.dil_b);
+            add_tensor(c, nm("residual_block_cin_conv/bias"), {c->G}, &o.cin_b);
+        }
+        if (c->gin > 0) {
+            add_tensor(c, nm("residual_block_gin_conv/kernel"), {1, c->gin, c->G}, &o.gin_k);
+            if (c->lbias) add_tensor(c, nm("residual_block_gin_conv/bias"), {c->G}, &o.gin_b);
+        }
         add_tensor(c, nm("residual_block_skip_conv/kernel"), {1, c->GH, c->S}, &o.skip_k);
         add_tensor(c, nm("residual_block_out_conv/kernel"), {1, c->GH, c->R}, &o.out_k);
-        add_tensor(c, nm("residual_block_skip_conv/bias"), {c->S}, &o.skip_b);
-        add_tensor(c, nm("residual_block_out_conv/bias"), {c->R}, &o.out_b);
+        if (c->lbias) {
+            add_tensor(c, nm("residual_block_skip_conv/bias"), {c->S}, &o.skip_b);
+            add_tensor(c, nm("residual_block_out_conv/bias"), {c->R}, &o.out_b);
+        }
     }
     add_tensor(c, "final_convolution_1/kernel", {1, c->S, c->S}, &c->fin1_k);
     add_tensor(c, "final_convolution_1/bias", {c->S}, &c->fin1_b);
     add_tensor(c, "final_convolution_2/kernel", {1, c->S, c->O}, &c->fin2_k);
     add_tensor(c, "final_convolution_2/bias", {c->O}, &c->fin2_b);
     const wn_config& g = c->cfg;
+    if (c->gin > 0 && g.use_speaker_embedding) add_tensor(c, "gc_embedding", {g.n_speakers, c->gin}, &c->emb_off);   // modules.py:13-17
     if (g.upsample_type != WN_UP_NEAREST) {
         for (int i = 0; i < g.n_upsample; ++i) {
             int s = g.upsample_scales[i], fk = g.freq_axis_kernel_size;
@@ -55,6 +65,10 @@ static void build_layout(wn_ctx* c) {
             else { add_tensor(c, kn, {1, s, c->C, c->C}, &ko); add_tensor(c, bn, {c->C}, &bo); }
             c->up_k.push_back(ko); c->up_b.push_back(bo);
         }
+    }
+    if (!c->lbias) {      // absent layer biases READ from the zero tail behind the ctx-owned parameter copy
+        c->zpad = (int)align_up(std::max(std::max(c->G, c->S), c->R), 8);
+        for (auto& o : c->lay) { o.dil_b = o.cin_b = o.skip_b = o.out_b = c->n_params; if (c->gin > 0) o.gin_b = c->n_params; }
     }
 }
 
@@ -128,7 +142,9 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
                 cfg->residual_channels, cfg->gate_channels, cfg->skip_out_channels);
     if (cfg->cin_channels <= 0 || cfg->cin_channels % 16)
         WN_FAIL(z, WN_E_UNSUPPORTED, "cin_channels (%d) must be a positive multiple of 16 (local conditioning is required)", cfg->cin_channels);
-    if (!cfg->use_bias) WN_FAIL(z, WN_E_UNSUPPORTED, "use_bias=False is not built");
+    if (cfg->gin_channels > 0 && cfg->use_speaker_embedding && cfg->n_speakers <= 0)
+        WN_FAIL(z, WN_E_ARG, "n_speakers must be positive when use_speaker_embedding [wavenet.py:154]");
+    if (cfg->gin_channels > 256) WN_FAIL(z, WN_E_UNSUPPORTED, "gin_channels > 256");
     if (cfg->n_upsample < 0 || cfg->n_upsample > WN_MAX_UPSAMPLE) WN_FAIL(z, WN_E_ARG, "bad n_upsample");
     if (cfg->upsample_type != WN_UP_NEAREST && cfg->upsample_type != WN_UP_2D && cfg->upsample_type != WN_UP_SUBPIXEL &&
         cfg->upsample_type != WN_UP_1D && cfg->upsample_type != WN_UP_RESIZE)
@@ -144,6 +160,8 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     c->S = cfg->skip_out_channels; c->O = cfg->out_channels; c->C = cfg->cin_channels;
     c->Cin = (cfg->input_type == WN_INPUT_MULAW_QUANTIZE) ? cfg->quantize_channels : 1;
     c->hop = hop;
+    c->lbias = cfg->use_bias != 0;
+    c->gin = cfg->gin_channels > 0 ? cfg->gin_channels : 0;
     c->OP = (int)align_up(c->O, 32); c->CP = (int)align_up(c->C, 32);
     const int per = c->L / cfg->stacks;
     for (int l = 0; l < c->L; ++l) c->dil.push_back(1 << (l % per));             // wavenet.py:125
@@ -182,6 +200,10 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->tensor_offsets_dev) hipFree(c->tensor_offsets_dev);
     if (c->norm2_dev) hipFree(c->norm2_dev);
     if (c->params_dev) hipFree(c->params_dev);
+    if (c->gvec) hipFree(c->gvec);
+    if (c->gids) hipFree(c->gids);
+    if (c->gbias) hipFree(c->gbias);
+    if (c->colsum) hipFree(c->colsum);
     if (c->ws) hipFree(c->ws);
     if (c->wg_partial) hipFree(c->wg_partial);
     delete c;
@@ -218,12 +240,24 @@ extern "C" float wn_learning_rate(int32_t schedule, float init_lr, int64_t step,
     return (float)(init_lr * pow((double)decay_rate, (double)step / (double)decay_steps));   // wavenet.py:620-629
 }
 
+extern "C" int wn_set_global_condition(wn_ctx* c, const void* g, int32_t B, void* stream) {
+    if (!c || !g) return WN_E_ARG;
+    if (c->gin <= 0) WN_FAIL(c, WN_E_STATE, "wn_set_global_condition: the model has no global conditioning (gin_channels <= 0)");
+    if (B <= 0 || B > c->maxB) WN_FAIL(c, WN_E_SHAPE, "batch %d outside (0, max_batch=%d]", B, c->maxB);
+    if (c->cfg.use_speaker_embedding) WN_HIP(c, hipMemcpyAsync(c->gids, g, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else WN_HIP(c, hipMemcpyAsync(c->gvec, g, (size_t)B * c->gin * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    c->gB = B; c->have_g = true;
+    return WN_OK;
+}
+
 static int check_fwd_args(wn_ctx* c, const void* x, const float* cc, const void* y, const int32_t* len, int B, int T, int Tc) {
     if (!x || !cc || !y || !len) WN_FAIL(c, WN_E_ARG, "wn_train_fwd: null pointer (Please provide either lengths or mask [modules.py:782-783])");
     if (B <= 0 || B > c->maxB) WN_FAIL(c, WN_E_SHAPE, "batch %d outside (0, max_batch=%d]", B, c->maxB);
     if (T <= 1 || T > c->maxT) WN_FAIL(c, WN_E_SHAPE, "time %d outside (1, max_time=%d]", T, c->maxT);
     if (Tc * c->hop != T) WN_FAIL(c, WN_E_SHAPE, "upsampled conditioning length Tc*hop = %d*%d != T = %d [wavenet.py:699]", Tc, c->hop, T);
     if (!c->packed) WN_FAIL(c, WN_E_STATE, "wn_pack_weights must be called before wn_train_fwd");
+    if (c->gin > 0 && (!c->have_g || c->gB != B))
+        WN_FAIL(c, WN_E_STATE, "global conditioning is enabled: call wn_set_global_condition with this batch (B=%d) first [wavenet.py:669-678]", B);
     return WN_OK;
 }
 

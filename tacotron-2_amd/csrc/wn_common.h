@@ -57,6 +57,7 @@ struct WnTensor {
 
 struct WnLayerOffsets {   // offsets (floats) into the flat parameter buffer
     int64_t dil_k, cin_k, dil_b, cin_b, skip_k, out_k, skip_b, out_b;
+    int64_t gin_k = -1, gin_b = -1;      // global-conditioning 1x1 conv [1, gin, G] (+ bias); -1 when gin_channels <= 0
 };
 
 // A-operand pack descriptor: Wpk[m][k] = scale * params[base + (k - k0) * stride_k + perm(m) * stride_m]
@@ -98,6 +99,14 @@ struct wn_ctx {
     void* pack_jobs_dev = nullptr; int pack_njobs = 0, pack_nblocks = 0;   // table of the single pack launch
     float* b1sum = nullptr;               // [L][G] dil bias + cin bias
     float* skip_bias_total = nullptr;     // [S]
+    // use_bias=False (hparams.py:189): the residual layers have no bias variables.  Forward READS then go to a zero tail
+    // behind the ctx-owned parameter copy (offset n_params .. n_params + zpad); gradient WRITES are skipped (lbias == false).
+    bool lbias = true; int zpad = 0;
+    // global conditioning: gin > 0.  gvec [maxB][gin] (embedded or given g), gids [maxB], gbias [L][maxB][G] =
+    // b1sum + W_g^T g + b_g per utterance (the gate epilogue's bias then has an utterance stride), colsum [L][maxB][G] =
+    // sum_t dz per utterance (backward), emb_off = embedding table [n_speakers][gin] or -1.
+    int gin = 0; int64_t emb_off = -1; float* gvec = nullptr; int32_t* gids = nullptr; float* gbias = nullptr; float* colsum = nullptr;
+    int gB = 0; bool have_g = false;
     int32_t* tensor_offsets_dev = nullptr; // [ntensors+1] for the optimiser
     float* norm2_dev = nullptr;           // [ntensors]
     // workspace
@@ -146,5 +155,7 @@ int wn_pipe_synthesize(wn_ctx* ctx, const float* c, int B, int Tc, const float* 
                        void* out_samples, float* out_raw, hipStream_t st);
 extern "C" int wn_noise_per_step(const wn_ctx* c);
 int wn_upsample_fwd(wn_ctx* ctx, const float* params_unused, const float* c, int B, int Tc, hipStream_t st);
+int wn_gbias_fwd(wn_ctx* ctx, int B, hipStream_t st);                 // global-conditioning bias table of this batch
+int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st);           // d W_g, d b_g, d embedding
 size_t wn_wgrad_partial_need(wn_ctx* ctx);
 int wn_sample_impl(wn_ctx* ctx, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st);

@@ -121,7 +121,14 @@ int wn_build_packs(wn_ctx* c) {
 
     WN_HIP(c, hipMalloc((void**)&c->b1sum, (size_t)L * G * 4));
     WN_HIP(c, hipMalloc((void**)&c->skip_bias_total, (size_t)S * 4));
-    WN_HIP(c, hipMalloc((void**)&c->params_dev, (size_t)c->n_params * 4));
+    WN_HIP(c, hipMalloc((void**)&c->params_dev, (size_t)(c->n_params + c->zpad) * 4));
+    WN_HIP(c, hipMemset(c->params_dev, 0, (size_t)(c->n_params + c->zpad) * 4));       // incl. the zero tail that absent biases read
+    if (c->gin > 0) {
+        WN_HIP(c, hipMalloc((void**)&c->gvec, (size_t)c->maxB * c->gin * 4));
+        WN_HIP(c, hipMalloc((void**)&c->gids, (size_t)c->maxB * 4));
+        WN_HIP(c, hipMalloc((void**)&c->gbias, (size_t)L * c->maxB * G * 4));
+        WN_HIP(c, hipMalloc((void**)&c->colsum, (size_t)L * c->maxB * G * 4));
+    }
     const int nt = (int)c->tensors.size();
     std::vector<int32_t> offs(nt + 1);
     for (int i = 0; i < nt; ++i) offs[i] = (int32_t)c->tensors[i].offset;
@@ -565,6 +572,91 @@ int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t 
         }
         Tout = Tin;
     }
+    return WN_OK;
+}
+
+// =================================================================================== global conditioning
+// wavenet.py:669-678 (embedding lookup + broadcast over time), modules.py:499-508 (z += W_g^T g + b_g).  g is constant over
+// time, so its contribution is a per-utterance bias of the gate pre-activation: gbias[l][b][:] = b1sum[l] + W_g[l]^T g_b + b_g[l].
+__global__ void wn_gvec_kernel(const float* __restrict__ params, int64_t emb_off, const int32_t* __restrict__ ids, float* __restrict__ gvec,
+                               int B, int gin, int n_speakers) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * gin) return;
+    const int b = i / gin, k = i - b * gin;
+    int id = ids[b]; id = id < 0 ? 0 : (id >= n_speakers ? n_speakers - 1 : id);
+    gvec[i] = params[emb_off + (int64_t)id * gin + k];
+}
+struct GinOff { int64_t k[32], b[32]; };
+__global__ void wn_gbias_kernel(const float* __restrict__ params, const float* __restrict__ b1sum, const float* __restrict__ gvec,
+                                float* __restrict__ gbias, int B, int G, int gin, GinOff o) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, l = blockIdx.z;
+    if (g >= G) return;
+    float a = b1sum[(size_t)l * G + g] + params[o.b[l] + g];
+    const float* W = params + o.k[l];
+    for (int k = 0; k < gin; ++k) a += gvec[b * gin + k] * W[(int64_t)k * G + g];
+    gbias[((size_t)l * B + b) * G + g] = a;
+}
+int wn_gbias_fwd(wn_ctx* c, int B, hipStream_t st) {
+    if (c->gin <= 0) return WN_OK;
+    if (c->cfg.use_speaker_embedding)
+        hipLaunchKernelGGL(wn_gvec_kernel, dim3(cdiv(B * c->gin, 256)), dim3(256), 0, st, c->params_dev, c->emb_off, c->gids, c->gvec, B, c->gin, c->cfg.n_speakers);
+    GinOff o; for (int l = 0; l < c->L; ++l) { o.k[l] = c->lay[l].gin_k; o.b[l] = c->lay[l].gin_b; }
+    hipLaunchKernelGGL(wn_gbias_kernel, dim3(cdiv(c->G, 256), B, c->L), dim3(256), 0, st, c->params_dev, c->b1sum, c->gvec, c->gbias, B, c->G, c->gin, o);
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+// backward: colsum[l][b][g] = sum_t dz_l[b,t,g];  d b_g[l] = sum_b colsum;  d W_g[l][k][g] = sum_b g_b[k] colsum[l][b][g];
+// d g_b[k] = sum_l sum_g W_g[l][k][g] colsum[l][b][g]  (scattered into the embedding row of the utterance's speaker).
+__global__ __launch_bounds__(256) void wn_colsum_kernel(const bf16_t* __restrict__ DZ, float* __restrict__ colsum, int64_t NT, int B, int T, int G) {
+    // block = (8-channel group, utterance, layer); threads stride over time, LDS tree at the end
+    const int c8 = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
+    const bf16_t* base = DZ + ((size_t)l * NT + (size_t)b * T) * G + c8 * 8;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * G);
+        a[0] += bf2f((bf16_t)(v.x & 0xffff)); a[1] += bf2f((bf16_t)(v.x >> 16)); a[2] += bf2f((bf16_t)(v.y & 0xffff)); a[3] += bf2f((bf16_t)(v.y >> 16));
+        a[4] += bf2f((bf16_t)(v.z & 0xffff)); a[5] += bf2f((bf16_t)(v.z >> 16)); a[6] += bf2f((bf16_t)(v.w & 0xffff)); a[7] += bf2f((bf16_t)(v.w >> 16));
+    }
+    __shared__ float red[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { float s = a[e]; for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = s; }
+    __syncthreads();
+    if (threadIdx.x < 8) colsum[((size_t)l * B + b) * G + c8 * 8 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void wn_gin_wgrad_kernel(const float* __restrict__ colsum, const float* __restrict__ gvec, float* __restrict__ grads, int B, int G, int gin, GinOff o, int has_bias) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.z;
+    const int k = blockIdx.y;          // k == gin: the bias row
+    if (g >= G) return;
+    float a = 0.0f;
+    for (int b = 0; b < B; ++b) a += (k < gin ? gvec[b * gin + k] : 1.0f) * colsum[((size_t)l * B + b) * G + g];
+    if (k < gin) grads[o.k[l] + (int64_t)k * G + g] = a;
+    else if (has_bias) grads[o.b[l] + g] = a;
+}
+__global__ void wn_gin_dg_kernel(const float* __restrict__ params, const float* __restrict__ colsum, const int32_t* __restrict__ ids,
+                                 float* __restrict__ grads, int64_t emb_off, int B, int G, int gin, int L, int n_speakers, GinOff o) {
+    // one wave per (utterance, k): sum over layers and gate channels, then one atomic into the speaker's embedding row
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= B * gin) return;
+    const int b = w / gin, k = w - b * gin;
+    float a = 0.0f;
+    for (int l = 0; l < L; ++l) {
+        const float* W = params + o.k[l] + (int64_t)k * G;
+        const float* cs = colsum + ((size_t)l * B + b) * G;
+        for (int g = lane; g < G; g += 64) a += W[g] * cs[g];
+    }
+    for (int s = 32; s > 0; s >>= 1) a += __shfl_down(a, s);
+    if (lane == 0) { int id = ids[b]; id = id < 0 ? 0 : (id >= n_speakers ? n_speakers - 1 : id); unsafeAtomicAdd(&grads[emb_off + (int64_t)id * gin + k], a); }
+}
+int wn_gin_bwd(wn_ctx* c, float* grads, hipStream_t st) {
+    if (c->gin <= 0) return WN_OK;
+    const int B = c->fB, G = c->G, L = c->L;
+    hipLaunchKernelGGL(wn_colsum_kernel, dim3(G / 8, B, L), dim3(256), 0, st, c->DZ, c->colsum, c->NT, B, c->fT, G);
+    GinOff o; for (int l = 0; l < L; ++l) { o.k[l] = c->lay[l].gin_k; o.b[l] = c->lay[l].gin_b; }
+    hipLaunchKernelGGL(wn_gin_wgrad_kernel, dim3(cdiv(G, 256), c->gin + 1, L), dim3(256), 0, st, c->colsum, c->gvec, grads, B, G, c->gin, o, c->lbias ? 1 : 0);
+    if (c->cfg.use_speaker_embedding)
+        hipLaunchKernelGGL(wn_gin_dg_kernel, dim3(cdiv(B * c->gin, 4)), dim3(256), 0, st, c->params_dev, c->colsum, c->gids, grads, c->emb_off, B, G, c->gin, L, c->cfg.n_speakers, o);
+    WN_LAUNCH_CHECK(c);
     return WN_OK;
 }
 

@@ -40,7 +40,7 @@ __device__ __forceinline__ float acc_at(const float* red, int wave_stride, int n
 // ---- stage A: z = [W_dil | W_cin] [x(t-2d); x(t-d); x(t); c_t] + b  -> tanh * sigmoid -> u    (modules.py:273-303, 494-510)
 __global__ __launch_bounds__(256) void wn_synth_gate(const bf16_t* __restrict__ Apk, int ksteps, const bf16_t* __restrict__ ring, int mask,
                                                      int d, int R, const bf16_t* __restrict__ cbt, int C, int T, int B,
-                                                     const float* __restrict__ bias, int GH, bf16_t* __restrict__ ucur,
+                                                     const float* __restrict__ bias, int bias_bstride, int GH, bf16_t* __restrict__ ucur,
                                                      const int32_t* __restrict__ t_dev) {
     __shared__ float red[4 * 2 * 64 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256) void wn_synth_gate(const bf16_t* __restrict__ 
         const int nn = o & 31, ch = o >> 5;
         if (nn >= B) continue;
         const int g = blk * 32 + ch;
-        const float za = acc_at(red, 2 * 64 * 16, 4, 0, ch, nn) + bias[g];
-        const float zb = acc_at(red, 2 * 64 * 16, 4, 1, ch, nn) + bias[GH + g];
+        const float* const gb = bias + (size_t)nn * bias_bstride;          // per-stream bias under global conditioning (wavenet.py:766-777)
+        const float za = acc_at(red, 2 * 64 * 16, 4, 0, ch, nn) + gb[g];
+        const float zb = acc_at(red, 2 * 64 * 16, 4, 1, ch, nn) + gb[GH + g];
         const float e = __expf(2.0f * za);
         const float u = (1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zb)));
         ucur[(size_t)nn * GH + g] = f2bf(u);
@@ -261,7 +262,7 @@ static int enqueue_step(wn_ctx* c, Synth* s, const float* noise, const void* tes
     const int L = c->L, R = c->R, GH = c->GH, S = c->S, C = c->C, B = s->B, T = s->T;
     for (int l = 0; l < L; ++l) {
         hipLaunchKernelGGL(wn_synth_gate, dim3(GH / 32), dim3(256), 0, st, c->packs[l].w1.dev, c->packs[l].w1.K >> 4, s->ring[l], s->mask[l],
-                           c->dil[l], R, c->cbt, C, T, B, c->b1sum + (size_t)l * c->G, GH, s->ucur, s->t_dev);
+                           c->dil[l], R, c->cbt, C, T, B, c->gin > 0 ? c->gbias + (size_t)l * B * c->G : c->b1sum + (size_t)l * c->G, c->gin > 0 ? c->G : 0, GH, s->ucur, s->t_dev);
         const bool top = (l == L - 1);
         hipLaunchKernelGGL(wn_synth_out, dim3(R / 32 + S / 32), dim3(256), 0, st, c->packs[l].wo.dev, c->packs[l].ws.dev, GH >> 4, R, S, s->ucur, GH,
                            c->params_dev + c->lay[l].out_b, c->res_scale, s->ring[l], s->mask[l], top ? nullptr : s->ring[l + 1], top ? 0 : s->mask[l + 1],
@@ -281,6 +282,8 @@ int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise
                   void* out_samples, float* out_raw, int steps_per_graph, hipStream_t caller_st) {
     const int T = Tc * c->hop;
     if ((int64_t)B * T > c->NT) WN_FAIL(c, WN_E_SHAPE, "synthesis B*T = %d*%d exceeds the workspace (max_batch*max_time = %lld)", B, T, (long long)c->NT);
+    if (c->gin > 0 && (!c->have_g || c->gB != B))
+        WN_FAIL(c, WN_E_STATE, "global conditioning is enabled: call wn_set_global_condition with this batch (B=%d) first [wavenet.py:766-777]", B);
     {   // steps_per_graph <= 0 selects the persistent dataflow pipeline (wn_synth_pipe.hip) when the model fits it;
         // WN_SYNTH_MODE=graph|pipe overrides
         const char* m = getenv("WN_SYNTH_MODE");
@@ -316,6 +319,7 @@ int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise
     // upsample the conditioning once for the whole utterance (wavenet.py:781-803); cbt[b*T+t][C]
     int rc = wn_upsample_fwd(c, nullptr, cin, B, Tc, st);
     if (rc) return rc;
+    if ((rc = wn_gbias_fwd(c, B, st))) return rc;            // global conditioning of this batch (wavenet.py:766-777)
     for (int l = 0; l < L; ++l) WN_HIP(c, hipMemsetAsync(s->ring[l], 0, (size_t)(s->mask[l] + 1) * 32 * R * 2, st));
     const int mode = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE ? 2 : (c->O == 2 ? 1 : 0);
     hipLaunchKernelGGL(wn_synth_init, dim3(1), dim3(256), 0, st, c->params_dev + c->first.dil_k, c->params_dev + c->first.dil_b, R, mode, 127,

@@ -590,6 +590,7 @@ void wn_pipe_free(wn_ctx* c) {
 // can this model run on the persistent pipeline?  (one CU per 32 gate pairs, all of a CU's weights in 160 KiB of LDS)
 bool wn_pipe_eligible(const wn_ctx* c, int B) {
     const int R = c->R, S = c->S, C = c->C, GH = c->GH, L = c->L;
+    if (c->gin > 0) return false;                       // per-stream gate bias (global conditioning): the graph path handles it
     if (GH % 32 || R % 8 || S % 8 || C % 8 || R > 512) return false;
     const int P = GH / 32;
     if (P > 8 || L > 32 || B > 16 || R > 384 || S > 384 || c->OP > 256) return false;

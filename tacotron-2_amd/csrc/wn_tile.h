@@ -32,6 +32,7 @@ struct EpiArgs {
     void* out0; void* out1;
     const void* in0; const void* in1;
     const float* bias;
+    int32_t bias_bstride;       // floats between the bias vectors of consecutive utterances (0: one vector; > 0: global conditioning)
     int32_t ld_out0, ld_out1, ld_in0;
     float scale;
     int32_t M_valid;
@@ -113,6 +114,7 @@ __device__ __forceinline__ void wn_tile_epilogue(const GemmArgs& a, f32x16_t (&a
         if constexpr (EPI == EPI_GATE) {
             static_assert(EPI != EPI_GATE || MT == 2, "gate epilogue pairs m-tiles");
             const int gblk = (mtile0 >> 1) * 32;
+            const float* const gb = e.bias + (int64_t)b * e.bias_bstride;
             bf16_t* TS = (bf16_t*)e.out0; bf16_t* U = (bf16_t*)e.out1;
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
@@ -120,8 +122,8 @@ __device__ __forceinline__ void wn_tile_epilogue(const GemmArgs& a, f32x16_t (&a
                 float ta[4], sgm[4], u[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float za = acc[0][j][qd * 4 + r] + e.bias[g + r];
-                    float zb = acc[MT - 1][j][qd * 4 + r] + e.bias[e.GH + g + r];
+                    float za = acc[0][j][qd * 4 + r] + gb[g + r];
+                    float zb = acc[MT - 1][j][qd * 4 + r] + gb[e.GH + g + r];
                     ta[r] = fast_tanh(za); sgm[r] = fast_sigmoid(zb); u[r] = ta[r] * sgm[r];
                 }
                 *reinterpret_cast<uint2*>(TS + row * e.ld_out0 + g) = make_uint2(pack_bf2(ta[0], ta[1]), pack_bf2(ta[2], ta[3]));
@@ -729,6 +731,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
             __syncthreads();
             if constexpr (EPI == EPI_GATE) {
                 constexpr int GT = Cfg::MTILE / 2, C8 = GT / 8, ITEMS = PROWS * C8;
+                const float* const gb = e.bias + (int64_t)b * e.bias_bstride;
                 bf16_t* TS = (bf16_t*)e.out0; bf16_t* U = (bf16_t*)e.out1;
                 for (int it = tid; it < ITEMS; it += Cfg::NW * 64) {
                     const int rl = it / C8, c8 = it % C8;
@@ -742,8 +745,8 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                     uint32_t pt[4], ps[4], pu[4];
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        const float t0_ = fast_tanh(za[2 * p] + e.bias[g + 2 * p]), t1_ = fast_tanh(za[2 * p + 1] + e.bias[g + 2 * p + 1]);
-                        const float s0_ = fast_sigmoid(zb[2 * p] + e.bias[e.GH + g + 2 * p]), s1_ = fast_sigmoid(zb[2 * p + 1] + e.bias[e.GH + g + 2 * p + 1]);
+                        const float t0_ = fast_tanh(za[2 * p] + gb[g + 2 * p]), t1_ = fast_tanh(za[2 * p + 1] + gb[g + 2 * p + 1]);
+                        const float s0_ = fast_sigmoid(zb[2 * p] + gb[e.GH + g + 2 * p]), s1_ = fast_sigmoid(zb[2 * p + 1] + gb[e.GH + g + 2 * p + 1]);
                         pt[p] = pack_bf2(t0_, t1_); ps[p] = pack_bf2(s0_, s1_); pu[p] = pack_bf2(t0_ * s0_, t1_ * s1_);
                     }
                     const int64_t row = rowbase + t;

@@ -61,7 +61,7 @@ static void wgrad_w1_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int 
     for (int g = 0; g < ng; ++g) {
         const int l = l0 + g, d = c->dil[l];
         WgGroup& q = w.g[g];
-        q.out_off = c->lay[l].dil_k; q.bias_off = c->lay[l].dil_b; q.bias2_off = c->lay[l].cin_b; q.has_bias2 = 1;
+        q.out_off = c->lay[l].dil_k; q.bias_off = c->lbias ? c->lay[l].dil_b : -1; q.bias2_off = c->lbias ? c->lay[l].cin_b : 0; q.has_bias2 = c->lbias ? 1 : 0;
         q.shift[0] = -2 * d; q.shift[1] = -d; q.shift[2] = 0; q.shift[3] = 0; q.scale = 1.0f;
     }
 }
@@ -72,7 +72,7 @@ static void wgrad_skip_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, in
     w.Bm = c->DSKIP; w.b_gstride = 0; w.ldb = S; w.N = S; w.ldw = S;
     for (int g = 0; g < ng; ++g) {
         const int l = l0 + g; WgGroup& q = w.g[g];
-        q.out_off = c->lay[l].skip_k; q.bias_off = c->lay[l].skip_b; q.bias2_off = 0; q.has_bias2 = 0; q.scale = c->skip_scale[l];
+        q.out_off = c->lay[l].skip_k; q.bias_off = c->lbias ? c->lay[l].skip_b : -1; q.bias2_off = 0; q.has_bias2 = 0; q.scale = c->skip_scale[l];
     }
 }
 static void wgrad_out_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int T) {
@@ -82,7 +82,7 @@ static void wgrad_out_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int
     w.Bm = c->GXall + (size_t)(l0 + 1) * NT * R; w.b_gstride = NT * R; w.ldb = R; w.N = R; w.ldw = R;
     for (int g = 0; g < ng; ++g) {
         const int l = l0 + g; WgGroup& q = w.g[g];
-        q.out_off = c->lay[l].out_k; q.bias_off = c->lay[l].out_b; q.bias2_off = 0; q.has_bias2 = 0; q.scale = 1.0f;
+        q.out_off = c->lay[l].out_k; q.bias_off = c->lbias ? c->lay[l].out_b : -1; q.bias2_off = 0; q.has_bias2 = 0; q.scale = 1.0f;
     }
 }
 // d W_skip and d W_out share the A operand u_l: one launch, B = [d skip | rho dL/dh_{l+1}] side by side (N = S + R).  The top
@@ -95,8 +95,8 @@ static void wgrad_skipout_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B,
     w.Bm_hi = c->GXall + (size_t)(l0 + 1) * NT * R; w.b_gstride_hi = NT * R; w.ldb_hi = R; w.split_n = S; w.ldw_hi = R;
     for (int g = 0; g < ng; ++g) {
         const int l = l0 + g; WgGroup& q = w.g[g];
-        q.out_off = c->lay[l].skip_k; q.bias_off = c->lay[l].skip_b; q.bias2_off = 0; q.has_bias2 = 0; q.scale = c->skip_scale[l];
-        q.out_off_hi = c->lay[l].out_k; q.bias_off_hi = c->lay[l].out_b; q.scale_hi = 1.0f;
+        q.out_off = c->lay[l].skip_k; q.bias_off = c->lbias ? c->lay[l].skip_b : -1; q.bias2_off = 0; q.has_bias2 = 0; q.scale = c->skip_scale[l];
+        q.out_off_hi = c->lay[l].out_k; q.bias_off_hi = c->lbias ? c->lay[l].out_b : -1; q.scale_hi = 1.0f;
     }
 }
 // bytes of split-K partials the grouped launches can need for any batch <= max_batch at max_time
@@ -119,6 +119,7 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
     int rc;
     if ((rc = wn_upsample_fwd(c, nullptr, c->fc, c->fB, c->fTc, st))) return rc;     // wavenet.py:680-702
     if ((rc = wn_first_conv(c, st))) return rc;                                      // wavenet.py:705
+    if ((rc = wn_gbias_fwd(c, c->fB, st))) return rc;                                // wavenet.py:669-678
     const int drop = c->cfg.dropout > 0.0f ? 1 : 0;
     for (int l = 0; l < L; ++l) {                                                    // wavenet.py:706-715 / modules.py:471-521
         const int d = c->dil[l];
@@ -130,7 +131,8 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
         a.seg[1] = seg(XDl, R, 0, R, -d, 0);
         a.seg[2] = seg(XDl, R, 0, R, 0, 0);
         a.seg[3] = seg(c->cbt, C, 0, C, 0, 0);
-        a.e.bias = c->b1sum + (size_t)l * G;
+        if (c->gin > 0) { a.e.bias = c->gbias + (size_t)l * c->fB * G; a.e.bias_bstride = G; }      // + W_g^T g + b_g per utterance
+        else a.e.bias = c->b1sum + (size_t)l * G;
         a.e.out0 = c->TS + (size_t)l * NT * G; a.e.ld_out0 = G;
         a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
         if (c->prof) prof_mark(c, st);
@@ -280,7 +282,7 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
             w.seg[3] = seg(c->cbt, C, 0, C, 0, 0);
             w.ones_row = 1;
             w.Bm = c->DZ + (size_t)l * NT * G; w.ldb = G; w.N = G;
-            w.out = grads + c->lay[l].dil_k; w.ldw = G; w.bias_out = grads + c->lay[l].dil_b; w.bias_out2 = grads + c->lay[l].cin_b;
+            w.out = grads + c->lay[l].dil_k; w.ldw = G; w.bias_out = c->lbias ? grads + c->lay[l].dil_b : nullptr; w.bias_out2 = c->lbias ? grads + c->lay[l].cin_b : nullptr;
             w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
             if ((rc = launch_wgrad(c, w, st))) return rc;
         }
@@ -288,7 +290,7 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
             WgArgs w; memset(&w, 0, sizeof w);
             w.nseg = 1; w.seg[0] = seg(Ul, GH, 0, GH, 0, 0); w.ones_row = 1;
             w.Bm = c->DSKIP; w.ldb = S; w.N = S;
-            w.out = grads + c->lay[l].skip_k; w.ldw = S; w.bias_out = grads + c->lay[l].skip_b;
+            w.out = grads + c->lay[l].skip_k; w.ldw = S; w.bias_out = c->lbias ? grads + c->lay[l].skip_b : nullptr;
             w.scale = c->skip_scale[l]; w.B = c->fB; w.T = c->fT;
             if ((rc = launch_wgrad(c, w, st))) return rc;
         }
@@ -296,11 +298,12 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
             WgArgs w; memset(&w, 0, sizeof w);
             w.nseg = 1; w.seg[0] = seg(Ul, GH, 0, GH, 0, 0); w.ones_row = 1;
             w.Bm = gxu; w.ldb = R; w.N = R;
-            w.out = grads + c->lay[l].out_k; w.ldw = R; w.bias_out = grads + c->lay[l].out_b;
+            w.out = grads + c->lay[l].out_k; w.ldw = R; w.bias_out = c->lbias ? grads + c->lay[l].out_b : nullptr;
             w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
             if ((rc = launch_wgrad(c, w, st))) return rc;
         }
     }
+    if ((rc = wn_gin_bwd(c, grads, st))) return rc;     // d W_g, d b_g, d embedding table (modules.py:499-508)
     const bf16_t* gx_up = c->GXall;
     // gx_up now holds dL/dh_0
     if ((rc = wn_first_conv_grad(c, gx_up, grads, st))) return rc;

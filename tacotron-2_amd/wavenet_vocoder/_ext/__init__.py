@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'csrc', 'libwavenet_mi355.so'))
 
-WN_ABI_VERSION = 1
+WN_ABI_VERSION = 2
 WN_MAX_UPSAMPLE = 8
 INPUT_TYPES = {'raw': 0, 'mulaw': 1, 'mulaw-quantize': 2}
 UPSAMPLE_TYPES = {'NearestNeighbor': 0, '2D': 1, 'SubPixel': 2, '1D': 3, 'Resize': 4}
@@ -41,6 +41,8 @@ class WnConfig(ctypes.Structure):
         ('adam_beta1', ctypes.c_float), ('adam_beta2', ctypes.c_float),
         ('adam_epsilon', ctypes.c_float), ('ema_decay', ctypes.c_float),
         ('max_batch', ctypes.c_int32), ('max_time', ctypes.c_int32),
+        ('gin_channels', ctypes.c_int32), ('use_speaker_embedding', ctypes.c_int32), ('n_speakers', ctypes.c_int32),
+        ('reserved0', ctypes.c_int32),
     ]
 
 
@@ -89,6 +91,7 @@ def load_library():
         'wn_profile': (ctypes.c_int, [vp, i32]),
         'wn_profile_result': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]),
         'wn_debug_copy': (ctypes.c_int, [vp, ctypes.c_char_p, i32, vp, i64, vp]),
+        'wn_set_global_condition': (ctypes.c_int, [vp, vp, i32, vp]),
         'wn_workspace_bytes': (i64, [vp]),
         'wn_dominant_kernel_name': (ctypes.c_char_p, []),
     }
@@ -143,6 +146,9 @@ def config_from_hparams(hp, max_batch, max_time):
     cfg.ema_decay = float(hp.wavenet_ema_decay)
     cfg.max_batch = int(max_batch)
     cfg.max_time = int(max_time)
+    cfg.gin_channels = int(getattr(hp, 'gin_channels', -1))                       # hparams.py:228-230
+    cfg.use_speaker_embedding = int(bool(getattr(hp, 'use_speaker_embedding', True))) if cfg.gin_channels > 0 else 0
+    cfg.n_speakers = int(getattr(hp, 'n_speakers', 0) or 0)
     return cfg
 
 
@@ -187,6 +193,15 @@ class Engine:
         for i in range(self.lib.wn_num_tensors(self.h)):
             self._ok(self.lib.wn_tensor_info(self.h, i, name, shape, ctypes.byref(ndim), ctypes.byref(off)))
             self.layout[name.value.decode()] = (tuple(shape[k] for k in range(ndim.value)), int(off.value))
+
+    def set_global_condition(self, g):
+        """g: int32 speaker ids [B] (use_speaker_embedding) or float32 [B, gin_channels]; applies to the next forward / synthesis
+        (wavenet.py:669-678, 766-777)."""
+        import torch
+        g = g.contiguous()
+        want = torch.int32 if self.cfg.use_speaker_embedding else torch.float32
+        _check(g, want, 'g')
+        self._ok(self.lib.wn_set_global_condition(self.h, _ptr(g), int(g.shape[0]), _stream()))
 
     def close(self):
         if getattr(self, 'h', None):

@@ -67,7 +67,9 @@ def initialize_parameters(hparams, layout, seed=None):
         n = int(np.prod(shape))
         if name.endswith('/bias'):
             continue
-        if name.startswith('local_conditioning_upsampling_'):
+        if name == 'gc_embedding':                           # tf.truncated_normal_initializer(0, 0.1) (reference modules.py:13-17)
+            t = torch.fmod(torch.randn(shape, generator=gen), 2.0) * 0.1
+        elif name.startswith('local_conditioning_upsampling_'):
             i = int(name.split('/')[0].rsplit('_', 1)[1]) - 1
             if hparams.NN_init:
                 t = nn_upsample_kernel(hparams.upsample_type, shape, hparams.upsample_scales[i],

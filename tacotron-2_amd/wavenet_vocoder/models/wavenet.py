@@ -27,13 +27,13 @@ class WaveNet(object):
         if self.local_conditioning_enabled():
             assert hparams.num_mels == hparams.cin_channels
         assert hparams.layers % hparams.stacks == 0
-        if hparams.gin_channels > 0:
-            raise NotImplementedError('global conditioning (gin_channels > 0) is not built in this tree yet')
+        if hparams.gin_channels > 0 and hparams.use_speaker_embedding:
+            assert hparams.n_speakers is not None                                    # wavenet.py:154
         if hparams.wavenet_weight_normalization:
             raise NotImplementedError('wavenet_weight_normalization=True is not built in this tree yet')
         self.scalar_input = is_scalar_input(hparams.input_type)
         self.receptive_field = receptive_field_size(hparams.layers, hparams.stacks, hparams.kernel_size)
-        self.embed_speakers = None
+        self.embed_speakers = 'gc_embedding' if (hparams.gin_channels > 0 and hparams.use_speaker_embedding) else None
         self.engine = None
         self.is_training = False
         self.is_evaluating = False
@@ -100,6 +100,7 @@ class WaveNet(object):
             self._seed = int(hp.wavenet_random_seed) * 1000003 + self.global_step
             self.tower_y, self.tower_input_lengths, self.tower_c = [y], [input_lengths], [c]
             self._y_hat_train = None
+            self._set_global(g, B)
             self.engine.train_fwd(x.contiguous(), c.contiguous(), y.contiguous(), input_lengths, self._seed, self._loss_dev)
             self._have_fwd = True
             return
@@ -112,7 +113,8 @@ class WaveNet(object):
             y0 = y[idx].reshape(-1)[:length]
             c0 = c[idx:idx + 1, :, :length // hop].contiguous()
             ti = None if hp.wavenet_natural_eval else y0.reshape(1, -1).contiguous()
-            out, raw = self.incremental(None, c=c0, time_length=length, test_inputs=ti, return_raw=True)
+            g0 = None if g is None else torch.as_tensor(g)[idx:idx + 1]
+            out, raw = self.incremental(None, c=c0, g=g0, time_length=length, test_inputs=ti, return_raw=True)
             tgt = y0.reshape(1, -1)
             ln = torch.tensor([length], dtype=torch.int32, device=raw.device)
             self.engine.loss(raw, tgt.contiguous(), ln, 0, self._loss_dev)          # no shift: wavenet.py:497-506
@@ -134,7 +136,7 @@ class WaveNet(object):
             raise ValueError('Expected 3 dimension shape [batch_size(1), time_length, {}] for local condition features but found {}'.format(
                 hp.cin_channels, tuple(c.shape)))
         cT = c.transpose(1, 2).contiguous()
-        out = self.incremental(None, c=cT, time_length=None, test_inputs=test_inputs)
+        out = self.incremental(None, c=cT, g=g, time_length=None, test_inputs=test_inputs)
         if is_mulaw_quantize(hp.input_type):
             y_hat = util.inv_mulaw_quantize(out)
         elif is_mulaw(hp.input_type):
@@ -185,6 +187,24 @@ class WaveNet(object):
         mask = util.sequence_mask(input_lengths, max_len=maxlen, expand=expand)
         return mask[:, 1:] if not expand else mask[:, 1:, :]
 
+    def _set_global(self, g, B):
+        """Hand the global conditioning of this batch to the engine (wavenet.py:669-678): speaker ids [B] / [B,1] when the
+        model owns an embedding table, else features [B, gin_channels]."""
+        if not self.global_conditioning_enabled():
+            return
+        if g is None:
+            raise ValueError('global conditioning is enabled (gin_channels > 0) but no g was given')
+        g = torch.as_tensor(g, device=self.device)
+        if self.embed_speakers is not None:
+            g = g.reshape(B).to(torch.int32)
+        else:
+            g = g.reshape(B, self._hparams.gin_channels).to(torch.float32)
+        self.engine.set_global_condition(g.contiguous())
+
+    @property
+    def embedding_table(self):
+        return self.variables['gc_embedding'] if self.embed_speakers is not None else None
+
     def has_speaker_embedding(self):
         return self.embed_speakers is not None
 
@@ -203,6 +223,7 @@ class WaveNet(object):
         y_hat = torch.empty(B, self._hparams.out_channels, T, device=x.device)
         lengths = torch.full((B,), T, dtype=torch.int32, device=x.device)
         dummy_y = x.reshape(B, T).contiguous() if not self.scalar_input else x.reshape(B, T, 1).contiguous()
+        self._set_global(g, B)
         self.engine.train_fwd(x.contiguous(), c.contiguous(), dummy_y, lengths, 0, None, y_hat)
         self._have_fwd = False
         return torch.softmax(y_hat, dim=1) if softmax else y_hat
@@ -236,6 +257,7 @@ class WaveNet(object):
             ti = test_inputs.reshape(B, -1)[:, :T]
             ti = (ti.float() if self.scalar_input else ti.to(torch.int32)).contiguous()
             assert ti.shape[1] == T, 'teacher-forcing inputs must cover the whole synthesis length'
+        self._set_global(g, B)                                                         # wavenet.py:766-777
         self.engine.synthesize(c.contiguous().float(), noise.contiguous(), out, raw, ti,
                                steps_per_graph=int(getattr(hp, 'mi355_steps_per_graph', 16)))
         feats = torch.empty(B, hp.cin_channels, T, device=dev)

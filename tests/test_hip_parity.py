@@ -52,6 +52,14 @@ CONFIGS = {
     'mol_resize': dict(upsample_type='Resize', upsample_scales=[2, 8], upsample_activation='LeakyRelu'),
     'mol_resize_odd': dict(upsample_type='Resize', upsample_scales=[3, 5], hop_size=15),
     'gauss_1d': dict(out_channels=2, upsample_type='1D', log_scale_min_gauss=float(np.log(1e-7))),
+    # hparam-gated options that both reference hparams files leave off: bias-free residual layers (hparams.py:189) and global
+    # conditioning with / without the speaker-embedding table (hparams.py:228-230)
+    'mol_nobias': dict(use_bias=False),
+    'mol_gin_embed': dict(gin_channels=16, use_speaker_embedding=True, n_speakers=5, wavenet_dropout=0.05),
+    'gauss_gin_raw_nobias': dict(out_channels=2, gin_channels=8, use_speaker_embedding=False, use_bias=False,
+                                 log_scale_min_gauss=float(np.log(1e-7))),
+    'paper_width_gin': dict(residual_channels=256, gate_channels=512, skip_out_channels=256, cin_channels=80, num_mels=80,
+                            layers=4, stacks=2, gin_channels=16, use_speaker_embedding=True, n_speakers=3),
     'softmax_c1': dict(input_type='mulaw-quantize', out_channels=256, quantize_channels=256, layers=8, stacks=1,
                        upsample_activation='LeakyRelu'),
     'wide': dict(residual_channels=128, gate_channels=256, skip_out_channels=128, cin_channels=80, num_mels=80,
@@ -81,6 +89,12 @@ def _run_fwd(name, B=2, T=400, lengths=None, with_bwd=False):
     flat = upload_params(eng, params)
     eng.pack_weights(flat)
     x_dev, y_dev, x_or, y_or, c = _inputs(cfg, hp, B, T)
+    g = None
+    if cfg.gin_channels > 0:       # global conditioning of this batch: speaker ids or raw features
+        gg = torch.Generator().manual_seed(11)
+        g = (torch.randint(0, cfg.n_speakers, (B,), generator=gg).int() if cfg.use_speaker_embedding
+             else torch.randn(B, cfg.gin_channels, generator=gg))
+        eng.set_global_condition(g.cuda())
     lengths = lengths or [T] * B
     len_dev = torch.tensor(lengths, dtype=torch.int32).cuda()
     loss_dev = torch.zeros(1, device='cuda')
@@ -89,7 +103,7 @@ def _run_fwd(name, B=2, T=400, lengths=None, with_bwd=False):
     eng.train_fwd(x_dev, c.cuda(), y_dev, len_dev, seed, loss_dev, yhat_dev)
     torch.cuda.synchronize()
     masks = oracle_masks(seed, cfg, B, T) if cfg.wavenet_dropout > 0 else None
-    return dict(hp=hp, cfg=cfg, eng=eng, params=params, flat=flat, x_or=x_or, y_or=y_or, c=c, lengths=lengths,
+    return dict(hp=hp, cfg=cfg, eng=eng, params=params, flat=flat, x_or=x_or, y_or=y_or, c=c, lengths=lengths, g=g,
                 loss_dev=loss_dev, yhat_dev=yhat_dev, masks=masks, B=B, T=T, seed=seed)
 
 
@@ -97,8 +111,8 @@ def _run_fwd(name, B=2, T=400, lengths=None, with_bwd=False):
 def test_train_forward(name):
     r = _run_fwd(name)
     cfg, eng, B, T = r['cfg'], r['eng'], r['B'], r['T']
-    y_em, aux = O.step(r['params'], cfg, r['x_or'], r['c'], dropout_masks=r['masks'], emulate_bf16=True, return_aux=True)
-    y_fp = O.step(r['params'], cfg, r['x_or'], r['c'], dropout_masks=r['masks'])
+    y_em, aux = O.step(r['params'], cfg, r['x_or'], r['c'], dropout_masks=r['masks'], emulate_bf16=True, return_aux=True, g=r['g'])
+    y_fp = O.step(r['params'], cfg, r['x_or'], r['c'], dropout_masks=r['masks'], g=r['g'])
     rows = B * T
     rep = []
     cup = eng.debug_copy('CUP', eng.cfg.n_upsample - 1 if cfg.upsample_type != 'NearestNeighbor' else 0, B * cfg.cin_channels, T).cpu()
@@ -145,7 +159,7 @@ def test_train_backward(name):
     torch.cuda.synchronize()
     g_dev = download_grads(eng, grads_dev)
     leaf = {k: v.clone().requires_grad_(True) for k, v in r['params'].items()}
-    y = O.step(leaf, cfg, r['x_or'], r['c'], dropout_masks=r['masks'], emulate_bf16=True)
+    y = O.step(leaf, cfg, r['x_or'], r['c'], dropout_masks=r['masks'], emulate_bf16=True, g=r['g'])
     loss = O.training_loss(cfg, y, r['y_or'], r['lengths'])
     gs = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
     g_or = {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(leaf, gs)}

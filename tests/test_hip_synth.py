@@ -39,11 +39,19 @@ def _noise(cfg, T, B, seed=0):
 
 
 @pytest.mark.parametrize('kw', [dict(), dict(out_channels=2, legacy=True, residual_legacy=True, upsample_type='SubPixel'),
-                                dict(input_type='mulaw-quantize', out_channels=256, quantize_channels=256)])
+                                dict(input_type='mulaw-quantize', out_channels=256, quantize_channels=256),
+                                dict(gin_channels=16, use_speaker_embedding=True, n_speakers=4),          # per-stream gate bias
+                                dict(gin_channels=8, use_speaker_embedding=False, use_bias=False, upsample_type='1D')])
 def test_teacher_forced_matches_oracle(kw):
     B, Tc = 3, 6
     hp, cfg, eng, params, wav, c, T = _setup(B, Tc, **kw)
     nz_dev, nz_or = _noise(cfg, T, B)
+    g = None
+    if cfg.gin_channels > 0:
+        gg = torch.Generator().manual_seed(5)
+        g = (torch.randint(0, cfg.n_speakers, (B,), generator=gg).int() if cfg.use_speaker_embedding
+             else torch.randn(B, cfg.gin_channels, generator=gg))
+        eng.set_global_condition(g.cuda())
     if cfg.input_type == 'mulaw-quantize':
         ids = torch.from_numpy(M.mulaw_quantize(wav.numpy())).int()
         ti_dev = ids.cuda(); ti_or = torch.nn.functional.one_hot(ids.long(), 256).float()
@@ -54,7 +62,7 @@ def test_teacher_forced_matches_oracle(kw):
     raw = torch.empty(B, cfg.out_channels, T, device='cuda')
     eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, ti_dev, steps_per_graph=1)
     torch.cuda.synchronize()
-    o_or, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=ti_or, formulation='reference')
+    o_or, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=ti_or, formulation='reference', g=g)
     e = rel_err(raw.cpu(), r_or)
     print('\nteacher-forced raw rel err %.3e' % e)
     assert e < 3e-2

@@ -145,3 +145,29 @@ def test_tf_adam_and_clip_semantics():
     assert abs(float(e) - (1.0 - 1e-4 * (1.0 - exp_p))) < 1e-7
     assert abs(O.learning_rate(200000) - 5e-4) < 1e-12
     assert O.learning_rate(0, schedule='noam') == max(1e-3 * 4000 ** 0.5 * 4000 ** -1.5, 1e-4)
+
+
+def test_global_conditioning_and_bias_free_layers_batch_equals_incremental():
+    """The design invariant of the reference (batch step == teacher-forced incremental) must also hold with the
+    hparam-gated options: global conditioning (embedding table or raw features) and use_bias=False."""
+    for kw in (dict(gin_channels=8, use_speaker_embedding=True, n_speakers=3), dict(gin_channels=4, use_speaker_embedding=False, use_bias=False)):
+        cfg = O.OracleConfig(layers=4, stacks=2, residual_channels=16, gate_channels=32, skip_out_channels=16, out_channels=6,
+                             cin_channels=8, upsample_scales=[2, 2], wavenet_dropout=0.0, **kw)
+        P = O.init_params(cfg, seed=3, bias_scale=0.1)
+        assert ('gc_embedding' in P) == bool(kw.get('use_speaker_embedding'))
+        assert any('gin_conv/kernel' in k for k in P)
+        assert kw.get('use_bias', True) == any(k.endswith('residual_block_out_conv/bias') for k in P)
+        B, Tc = 2, 5
+        T = Tc * cfg.hop
+        gen = torch.Generator().manual_seed(0)
+        wav = torch.rand(B, T, generator=gen) * 1.6 - 0.8
+        c = torch.rand(B, cfg.cin_channels, Tc, generator=gen)
+        g = torch.tensor([2, 0]) if cfg.use_speaker_embedding else torch.randn(B, cfg.gin_channels, generator=gen)
+        x_shift = torch.cat([torch.zeros(B, 1), wav[:, :-1]], 1).view(B, 1, T)
+        yb = O.step(P, cfg, x_shift, c, g=g)
+        noise = {'u1': torch.rand(T, B, 2, generator=gen) * 0.9 + 0.05, 'u2': torch.rand(T, B, generator=gen) * 0.9 + 0.05}
+        _, raw = O.incremental(P, cfg, c, noise=noise, test_inputs=wav.unsqueeze(-1), g=g)
+        assert torch.allclose(raw, yb, atol=2e-5), float((raw - yb).abs().max())
+        # g matters: another speaker / feature vector changes the output
+        g2 = torch.tensor([1, 1]) if cfg.use_speaker_embedding else g + 1.0
+        assert float((O.step(P, cfg, x_shift, c, g=g2) - yb).abs().max()) > 1e-4
