@@ -247,7 +247,17 @@ def main():
     dt = time.time() - t0
     _log('timed region done: %.1f ms/step' % (dt / args.steps * 1e3))
     prof_ms, prof_n = eng.profile_result()
+    rows_launch = eng.profile_rows_per_launch()
+    # untimed extra: the same kernel with the GPU to itself (whole batch on one stream), for the kernel-quality view
+    eng.set_batch_parts(1)
+    one_step(args.warmup + args.steps)
+    eng.profile(True)
+    for i in range(2):
+        one_step(args.warmup + args.steps + 1 + i)
+    excl_ms, excl_n = eng.profile_result()
+    excl_rows = eng.profile_rows_per_launch()
     eng.profile(False)
+    eng.set_batch_parts(0)
     final_loss = float(loss.item())
     if world > 1:
         tmax = torch.tensor([dt], device=device)
@@ -260,7 +270,8 @@ def main():
         mac = mac_per_sample(hp)
         # dominant kernel: gate GEMM.  Algorithmic flops per launch = 2 * G * (3R + C) * B*T  (SURVEY 8d per-sample x units/launch)
         R, G, C = hp.residual_channels, hp.gate_channels, hp.cin_channels
-        flops_launch = 2.0 * G * (3 * R + C) * B * T
+        rows_launch = rows_launch or B * T       # the layer chain runs per half-batch on two streams
+        flops_launch = 2.0 * G * (3 * R + C) * rows_launch
         avg_s = (prof_ms / max(prof_n, 1)) * 1e-3
         achieved = flops_launch / avg_s / 1e12 if prof_n else None
         peak = 2500.0
@@ -277,10 +288,16 @@ def main():
             'final_loss': final_loss,
             'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1> (dilated conv + cond GEMM + gate, fwd)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                         'traffic': GATE_TRAFFIC_BYTES if args.workload == 'c2' and B == 8 and T == 11000 else None,
+                         'traffic': GATE_TRAFFIC_BYTES * rows_launch / (8 * 11000.0) if args.workload == 'c2' and T == 11000 else None,
                          'traffic_source': 'profiles/r1b_c2_train_pmc_{fetch,write}_size.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC, gfx950 correction)',
                          'launches_timed': int(prof_n), 'avg_launch_ms': avg_s * 1e3 if prof_n else None,
-                         'alg_flops_per_launch': flops_launch, 'alg_bytes_per_launch': float(B * T) * (2 * R + 2 * C + 2 * G + G)},
+                         'alg_flops_per_launch': flops_launch, 'alg_bytes_per_launch': float(rows_launch) * (2 * R + 2 * C + 2 * G + G),
+                         'rows_per_launch': rows_launch,
+                         'note': 'each launch covers one half-batch; its duration includes time shared with the HBM-bound out-conv launches of the other half-batch running concurrently on a second stream'},
+            'roofline_exclusive': {'what': 'same kernel, whole batch on one stream (no concurrent kernels), 2 untimed steps after the timed region',
+                                   'avg_launch_ms': excl_ms / max(excl_n, 1), 'rows_per_launch': excl_rows,
+                                   'achieved': (2.0 * G * (3 * R + C) * excl_rows / (excl_ms / max(excl_n, 1) * 1e-3) / 1e12) if excl_n else None,
+                                   'frac': (2.0 * G * (3 * R + C) * excl_rows / (excl_ms / max(excl_n, 1) * 1e-3) / 1e12 / peak) if excl_n else None},
             # whole-step view asked for by the north star: SURVEY 8d algorithmic HBM bytes per audio sample (bf16) x samples/s vs 8 TB/s
             'hbm_roofline_whole_step': {'alg_bytes_per_sample': alg_bytes_per_sample(hp), 'achieved_GBps': alg_bytes_per_sample(hp) * value / world / 1e9,
                                         'peak_GBps': 8000.0, 'frac': alg_bytes_per_sample(hp) * value / world / 8e12},

@@ -181,6 +181,10 @@ int64_t wn_workspace_bytes(const wn_ctx* ctx);
  * recorded on the launch stream between wn_profile(ctx,1) and wn_profile_result (which synchronises). */
 int wn_profile(wn_ctx* ctx, int32_t enable);
 int wn_profile_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
+/* time rows (utterances x samples) one timed launch processed: the layer chain runs per half-batch on two streams */
+int64_t wn_profile_rows_per_launch(const wn_ctx* ctx);
+/* 0: default (2 when the batch has >= 2 utterances), 1: whole batch on the caller's stream, 2: two half-batches on two streams */
+int wn_set_batch_parts(wn_ctx* ctx, int32_t parts);
 /* name of the kernel that dominates training time + its algorithmic bytes/flops per audio sample */
 const char* wn_dominant_kernel_name(void);
 

@@ -200,6 +200,9 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->tensor_offsets_dev) hipFree(c->tensor_offsets_dev);
     if (c->norm2_dev) hipFree(c->norm2_dev);
     if (c->params_dev) hipFree(c->params_dev);
+    if (c->st2) hipStreamDestroy(c->st2);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->gvec) hipFree(c->gvec);
     if (c->gids) hipFree(c->gids);
     if (c->gbias) hipFree(c->gbias);

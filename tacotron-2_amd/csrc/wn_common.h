@@ -125,6 +125,9 @@ struct wn_ctx {
     const void* fx = nullptr; const void* fy = nullptr; const int32_t* flen = nullptr; const float* fc = nullptr;
     // live profiling of the dominant kernel (bench.py roofline): event pairs around every gate-GEMM launch
     bool prof = false; std::vector<hipEvent_t> pev; size_t pev_used = 0;
+    // batch parts: the serial layer chain of the two half-batches runs on two streams so that the MFMA/power-bound GEMMs of
+    // one half overlap the HBM-bound kernels of the other (fwd: gate | out conv, bwd: dx | dgate); joined before the loss / wgrads
+    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int parts = 1; int parts_req = 0; int prof_rows = 0;
     // synthesis state (lazy)
     struct Synth* synth = nullptr;
     void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)

@@ -46,7 +46,8 @@ struct GemmArgs {
     int32_t mblocks;            // grid decode
     int32_t nseg; SrcSeg seg[4];
     int32_t nrep; int64_t rep_stride;     // segment list repeated nrep times, bases advanced by rep_stride elements
-    int32_t B, T;
+    int32_t B, T;               // utterances of THIS launch (a part of the batch) and samples per utterance
+    int32_t b0;                 // first utterance of the part: rows, bias vectors and dropout indices are absolute (b0 + local b)
     int32_t tiles_per_utt, ntiles;
     uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;   // dropout mask spec (row pitch of the dropped tensor)
     const bf16_t* zero;         // >= 16 B of zeros in device memory (source of out-of-range rows for the LDS-DMA kernel)
@@ -239,8 +240,9 @@ __global__ __launch_bounds__(WM * WN * 64) void wn_gemm_tile_kernel(const GemmAr
     const int mblk = q % a.mblocks;
     const int tile = (q / a.mblocks) * 8 + xcd;
     if (tile >= a.ntiles) return;
-    const int b = tile / a.tiles_per_utt;
-    const int t0 = (tile - b * a.tiles_per_utt) * NROWS;
+    const int bl = tile / a.tiles_per_utt;
+    const int b = bl + a.b0;
+    const int t0 = (tile - bl * a.tiles_per_utt) * NROWS;
     const int T = a.T;
     const int64_t rowbase = (int64_t)b * T;
 
@@ -417,8 +419,9 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
             while (__builtin_amdgcn_s_memtime() - t_start < (uint64_t)delay) __builtin_amdgcn_s_sleep(16);
         }
     }
-    const int b = tile / a.tiles_per_utt;
-    const int t0 = (tile - b * a.tiles_per_utt) * Cfg::TTILE;
+    const int bl = tile / a.tiles_per_utt;
+    const int b = bl + a.b0;
+    const int t0 = (tile - bl * a.tiles_per_utt) * Cfg::TTILE;
     const int T = a.T;
     const int64_t rowbase = (int64_t)b * T;
 #ifdef WN_EPI_ABLATE

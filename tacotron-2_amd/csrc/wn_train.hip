@@ -16,11 +16,11 @@ static void set_dropout(wn_ctx* c, int layer, uint32_t& klo, uint32_t& khi, uint
     ld = c->R;
 }
 
-static void base_args(wn_ctx* c, GemmArgs& a, const PackedW& w) {
+static void base_args(wn_ctx* c, GemmArgs& a, const PackedW& w, int b0 = 0, int nb = -1) {
     memset(&a, 0, sizeof a);
     a.Apk = w.dev; a.ksteps_total = w.K >> 4;
     a.nrep = 1; a.rep_stride = 0;
-    a.B = c->fB; a.T = c->fT; a.zero = c->zero_page;
+    a.B = nb < 0 ? c->fB : nb; a.b0 = b0; a.T = c->fT; a.zero = c->zero_page;
     a.e.scale = 1.0f; a.e.GH = c->GH; a.e.M_valid = w.M_valid;
 }
 
@@ -34,6 +34,8 @@ static void prof_mark(wn_ctx* c, hipStream_t st) {
 }
 extern "C" int wn_profile(wn_ctx* c, int32_t enable) { if (!c) return WN_E_ARG; c->prof = enable != 0; c->pev_used = 0; return WN_OK; }
 // total milliseconds and number of launches of the dominant kernel (gate GEMM) since wn_profile(ctx, 1); synchronises.
+// rows (b*T) one timed gate-GEMM launch processed in the last forward (half the batch when the two-stream split is on)
+extern "C" int64_t wn_profile_rows_per_launch(const wn_ctx* c) { return c ? c->prof_rows : 0; }
 extern "C" int wn_profile_result(wn_ctx* c, double* total_ms, int64_t* launches) {
     if (!c || !total_ms || !launches) return WN_E_ARG;
     double tot = 0.0; int64_t n = 0;
@@ -113,19 +115,33 @@ size_t wn_wgrad_partial_need(wn_ctx* c) {
     return need + (1 << 20);
 }
 
-int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
+// ---- batch parts on two streams ---------------------------------------------------------------------------------------
+static int parts_setup(wn_ctx* c) {
+    if (!c->st2) {
+        WN_HIP(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+        WN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        WN_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    return WN_OK;
+}
+static int n_parts(wn_ctx* c) {
+    static const int env = [] { const char* e = getenv("WN_BATCH_PARTS"); return e ? atoi(e) : 2; }();   // 1 disables the overlap (A/B switch)
+    const int want = c->parts_req > 0 ? c->parts_req : env;
+    return (want >= 2 && c->fB >= 2) ? 2 : 1;
+}
+extern "C" int wn_set_batch_parts(wn_ctx* c, int32_t parts) { if (!c || parts < 0 || parts > 2) return WN_E_ARG; c->parts_req = parts; return WN_OK; }
+
+// layers + skip sum + head of the utterances [b0, b0 + nb) on stream st (wavenet.py:706-721)
+static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
     const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C;
     const int64_t NT = c->NT;
     int rc;
-    if ((rc = wn_upsample_fwd(c, nullptr, c->fc, c->fB, c->fTc, st))) return rc;     // wavenet.py:680-702
-    if ((rc = wn_first_conv(c, st))) return rc;                                      // wavenet.py:705
-    if ((rc = wn_gbias_fwd(c, c->fB, st))) return rc;                                // wavenet.py:669-678
     const int drop = c->cfg.dropout > 0.0f ? 1 : 0;
     for (int l = 0; l < L; ++l) {                                                    // wavenet.py:706-715 / modules.py:471-521
         const int d = c->dil[l];
         const bf16_t* Xl = c->X + (size_t)l * NT * R;
         const bf16_t* XDl = c->XD + (size_t)l * NT * R;      // dropout already applied by the producer
-        GemmArgs a; base_args(c, a, c->packs[l].w1);
+        GemmArgs a; base_args(c, a, c->packs[l].w1, b0, nb);
         a.nseg = 4;
         a.seg[0] = seg(XDl, R, 0, R, -2 * d, 0);
         a.seg[1] = seg(XDl, R, 0, R, -d, 0);
@@ -135,11 +151,11 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
         else a.e.bias = c->b1sum + (size_t)l * G;
         a.e.out0 = c->TS + (size_t)l * NT * G; a.e.ld_out0 = G;
         a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
-        if (c->prof) prof_mark(c, st);
+        if (prof) prof_mark(c, st);
         if ((rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st))) return rc;
-        if (c->prof) prof_mark(c, st);
+        if (prof) prof_mark(c, st);
         if (l + 1 < L) {      // the residual output of the last layer is never consumed (wavenet.py:716)
-            GemmArgs o; base_args(c, o, c->packs[l].wo);
+            GemmArgs o; base_args(c, o, c->packs[l].wo, b0, nb);
             o.nseg = 1; o.seg[0] = seg(c->U + (size_t)l * NT * GH, GH, 0, GH, 0, 0);
             o.e.bias = c->params_dev + c->lay[l].out_b;
             o.e.in0 = Xl; o.e.ld_in0 = R;
@@ -153,67 +169,80 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
         }
     }
     {   // skip sum over all layers as one contraction, + ReLU (wavenet.py:716-719 first activation)
-        GemmArgs a; base_args(c, a, c->wskip);
+        GemmArgs a; base_args(c, a, c->wskip, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->U, GH, 0, GH, 0, 0); a.nrep = L; a.rep_stride = NT * GH;
         a.e.bias = c->skip_bias_total; a.e.relu = 1; a.e.out0 = c->R1; a.e.ld_out0 = S;
         if ((rc = wn_launch_gemm<EPI_STORE_BF16>(c, a, c->wskip.M, st))) return rc;
     }
     {   // final_convolution_1 + ReLU
-        GemmArgs a; base_args(c, a, c->wh1);
+        GemmArgs a; base_args(c, a, c->wh1, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->R1, S, 0, S, 0, 0);
         a.e.bias = c->params_dev + c->fin1_b; a.e.relu = 1; a.e.out0 = c->H2; a.e.ld_out0 = S;
         if ((rc = wn_launch_gemm<EPI_STORE_BF16>(c, a, c->wh1.M, st))) return rc;
     }
     {   // final_convolution_2 -> y_hat [B,O,T] fp32
-        GemmArgs a; base_args(c, a, c->wh2);
+        GemmArgs a; base_args(c, a, c->wh2, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->H2, S, 0, S, 0, 0);
         a.e.bias = c->params_dev + c->fin2_b; a.e.out0 = c->YHAT; a.e.M_valid = c->O;
         if ((rc = wn_launch_gemm<EPI_STORE_F32_BOT>(c, a, c->wh2.M, st))) return rc;
     }
+    return WN_OK;
+}
+
+// run f(b0, nb, stream, is_first_part) for every batch part: part 0 on the caller's stream, part 1 on the ctx-owned one, both
+// ordered after everything already enqueued on `st`, and `st` ordered after both when this returns
+template <class F> static int for_each_part(wn_ctx* c, hipStream_t st, F f) {
+    const int np = n_parts(c);
+    c->parts = np;
+    if (np == 1) return f(0, c->fB, st, true);
+    int rc = parts_setup(c);
+    if (rc) return rc;
+    const int nb0 = (c->fB + 1) / 2;
+    WN_HIP(c, hipEventRecord(c->ev_fork, st));
+    WN_HIP(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+    if ((rc = f(nb0, c->fB - nb0, c->st2, false))) return rc;
+    WN_HIP(c, hipEventRecord(c->ev_join, c->st2));
+    if ((rc = f(0, nb0, st, true))) return rc;
+    WN_HIP(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    return WN_OK;
+}
+
+int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
+    int rc;
+    if ((rc = wn_upsample_fwd(c, nullptr, c->fc, c->fB, c->fTc, st))) return rc;     // wavenet.py:680-702
+    if ((rc = wn_first_conv(c, st))) return rc;                                      // wavenet.py:705
+    if ((rc = wn_gbias_fwd(c, c->fB, st))) return rc;                                // wavenet.py:669-678
+    rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first) {
+        if (first) c->prof_rows = nb * c->fT;      // rows of one timed gate-GEMM launch (wn_profile_result)
+        return fwd_part(c, b0, nb, s, c->prof && first);
+    });
+    if (rc) return rc;
     if (y_hat_out) WN_HIP(c, hipMemcpyAsync(y_hat_out, c->YHAT, (size_t)c->fB * c->O * c->fT * 4, hipMemcpyDeviceToDevice, st));
     if (loss_out) { if ((rc = wn_loss_fwd_bwd(c, loss_out, st))) return rc; c->have_loss = true; }
     else c->have_loss = false;
     return WN_OK;
 }
 
-int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
-    if (!c->have_loss) WN_FAIL(c, WN_E_STATE, "wn_train_bwd needs a forward that computed the loss (loss_out != NULL)");
-    const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C, O = c->O;
+// backward serial chain of the utterances [b0, b0 + nb): head dgrads, then d z / d h of every layer, top to bottom.
+// GXall[l] = rho * dL/dh_l is kept for every layer (rho = sqrt(.5) if residual_legacy), so that all weight gradients can be
+// contracted afterwards over the whole batch.
+static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st) {
+    const int L = c->L, R = c->R, G = c->G, S = c->S, O = c->O;
     const int64_t NT = c->NT;
     const int ldDY = (O + 15) / 16 * 16;
     int rc;
-    WN_HIP(c, hipMemsetAsync(grads, 0, (size_t)c->n_params * 4, st));
-    const int64_t rows = (int64_t)c->fB * c->fT;
-    // ---- head (wavenet.py:136-149)
-    {   // d final_convolution_2 = H2^T dY
-        WgArgs w; memset(&w, 0, sizeof w);
-        w.nseg = 1; w.seg[0] = seg(c->H2, S, 0, S, 0, 0); w.ones_row = 1;
-        w.Bm = c->DY; w.ldb = ldDY; w.colb0 = 0; w.N = O;
-        w.out = grads + c->fin2_k; w.ldw = O; w.bias_out = grads + c->fin2_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-        if ((rc = launch_wgrad(c, w, st))) return rc;
-    }
     {   // d pre1 = (W2 dY) * (H2 > 0)
-        GemmArgs a; base_args(c, a, c->wh2T);
+        GemmArgs a; base_args(c, a, c->wh2T, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->DY, ldDY, 0, c->wh2T.K, 0, 0);
         a.e.in0 = c->H2; a.e.ld_in0 = S; a.e.out0 = c->DPRE1; a.e.ld_out0 = S;
         if ((rc = wn_launch_gemm<EPI_MASK_STORE>(c, a, c->wh2T.M, st))) return rc;
     }
-    {   // d final_convolution_1 = R1^T dpre1
-        WgArgs w; memset(&w, 0, sizeof w);
-        w.nseg = 1; w.seg[0] = seg(c->R1, S, 0, S, 0, 0); w.ones_row = 1;
-        w.Bm = c->DPRE1; w.ldb = S; w.N = S;
-        w.out = grads + c->fin1_k; w.ldw = S; w.bias_out = grads + c->fin1_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-        if ((rc = launch_wgrad(c, w, st))) return rc;
-    }
     {   // d skip = (W1 dpre1) * (skips > 0)
-        GemmArgs a; base_args(c, a, c->wh1T);
+        GemmArgs a; base_args(c, a, c->wh1T, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->DPRE1, S, 0, S, 0, 0);
         a.e.in0 = c->R1; a.e.ld_in0 = S; a.e.out0 = c->DSKIP; a.e.ld_out0 = S;
         if ((rc = wn_launch_gemm<EPI_MASK_STORE>(c, a, c->wh1T.M, st))) return rc;
     }
-    // ---- residual stack, top to bottom: only the serial chain (d z, d h) runs here; GXall[l] = rho * dL/dh_l is kept
-    // for every layer (rho = sqrt(.5) if residual_legacy), so that all weight gradients can be contracted afterwards.
-    WN_HIP(c, hipMemsetAsync(c->GXall + (size_t)L * NT * R, 0, (size_t)rows * R * 2, st));   // top layer: residual branch is dead
     const int drop = c->cfg.dropout > 0.0f ? 1 : 0;
     for (int l = L - 1; l >= 0; --l) {
         const int d = c->dil[l];
@@ -222,7 +251,7 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
         bf16_t* gx_dn = c->GXall + (size_t)l * NT * R;
         const bool top = (l == L - 1);
         {   // d z: through the 1x1 convs and the gate (modules.py:510-515)
-            GemmArgs a; base_args(c, a, c->packs[l].w2T);
+            GemmArgs a; base_args(c, a, c->packs[l].w2T, b0, nb);
             a.nseg = 2;
             a.seg[0] = seg(gx_up, R, 0, R, 0, 0);
             a.seg[1] = seg(c->DSKIP, S, 0, S, 0, 0);
@@ -230,7 +259,7 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
             if ((rc = wn_launch_gemm<EPI_DGATE>(c, a, c->packs[l].w2T.M, st))) return rc;
         }
         {   // d h_l = dropout-mask * conv^T(dz) + residual path   (modules.py:484, 517-520)
-            GemmArgs a; base_args(c, a, c->packs[l].w1T);
+            GemmArgs a; base_args(c, a, c->packs[l].w1T, b0, nb);
             a.nseg = 3;
             a.seg[0] = seg(DZl, G, 0, G, 2 * d, 0);
             a.seg[1] = seg(DZl, G, 0, G, d, 0);
@@ -242,6 +271,35 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
             a.e.out0 = gx_dn; a.e.ld_out0 = R;
             if ((rc = wn_launch_gemm<EPI_DX>(c, a, c->packs[l].w1T.M, st))) return rc;
         }
+    }
+    return WN_OK;
+}
+
+int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
+    if (!c->have_loss) WN_FAIL(c, WN_E_STATE, "wn_train_bwd needs a forward that computed the loss (loss_out != NULL)");
+    const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C, O = c->O;
+    const int64_t NT = c->NT;
+    const int ldDY = (O + 15) / 16 * 16;
+    int rc;
+    WN_HIP(c, hipMemsetAsync(grads, 0, (size_t)c->n_params * 4, st));
+    const int64_t rows = (int64_t)c->fB * c->fT;
+    WN_HIP(c, hipMemsetAsync(c->GXall + (size_t)L * NT * R, 0, (size_t)rows * R * 2, st));   // top layer: residual branch is dead
+    // ---- the serial chain, per batch part (two streams)
+    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool) { return bwd_part(c, b0, nb, s); }))) return rc;
+    // ---- head weight gradients over the whole batch (wavenet.py:136-149)
+    {   // d final_convolution_2 = H2^T dY
+        WgArgs w; memset(&w, 0, sizeof w);
+        w.nseg = 1; w.seg[0] = seg(c->H2, S, 0, S, 0, 0); w.ones_row = 1;
+        w.Bm = c->DY; w.ldb = ldDY; w.colb0 = 0; w.N = O;
+        w.out = grads + c->fin2_k; w.ldw = O; w.bias_out = grads + c->fin2_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
+        if ((rc = launch_wgrad(c, w, st))) return rc;
+    }
+    {   // d final_convolution_1 = R1^T dpre1
+        WgArgs w; memset(&w, 0, sizeof w);
+        w.nseg = 1; w.seg[0] = seg(c->R1, S, 0, S, 0, 0); w.ones_row = 1;
+        w.Bm = c->DPRE1; w.ldb = S; w.N = S;
+        w.out = grads + c->fin1_k; w.ldw = S; w.bias_out = grads + c->fin1_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
+        if ((rc = launch_wgrad(c, w, st))) return rc;
     }
     // ---- weight gradients of the stack, each kind for ALL layers in one grouped launch (wn_wgrad.h)
     bool grouped;
