@@ -286,20 +286,29 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
     WN_HIP(c, hipMemsetAsync(c->GXall + (size_t)L * NT * R, 0, (size_t)rows * R * 2, st));   // top layer: residual branch is dead
     // ---- the serial chain, per batch part (two streams)
     if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool) { return bwd_part(c, b0, nb, s); }))) return rc;
+    // ---- everything that is NOT a weight gradient of the stack (head weight gradients, global-conditioning / input-conv /
+    // upsample-net gradients: small or latency-bound kernels, ~1 ms in sum) goes to the second stream and runs under the
+    // MFMA-bound grouped weight gradients of the stack; all of them write disjoint regions of `grads`.
+    hipStream_t side = st;
+    if (c->parts == 2) {
+        WN_HIP(c, hipEventRecord(c->ev_fork, st));
+        WN_HIP(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+        side = c->st2;
+    }
     // ---- head weight gradients over the whole batch (wavenet.py:136-149)
     {   // d final_convolution_2 = H2^T dY
         WgArgs w; memset(&w, 0, sizeof w);
         w.nseg = 1; w.seg[0] = seg(c->H2, S, 0, S, 0, 0); w.ones_row = 1;
         w.Bm = c->DY; w.ldb = ldDY; w.colb0 = 0; w.N = O;
         w.out = grads + c->fin2_k; w.ldw = O; w.bias_out = grads + c->fin2_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-        if ((rc = launch_wgrad(c, w, st))) return rc;
+        if ((rc = launch_wgrad(c, w, side))) return rc;
     }
     {   // d final_convolution_1 = R1^T dpre1
         WgArgs w; memset(&w, 0, sizeof w);
         w.nseg = 1; w.seg[0] = seg(c->R1, S, 0, S, 0, 0); w.ones_row = 1;
         w.Bm = c->DPRE1; w.ldb = S; w.N = S;
         w.out = grads + c->fin1_k; w.ldw = S; w.bias_out = grads + c->fin1_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-        if ((rc = launch_wgrad(c, w, st))) return rc;
+        if ((rc = launch_wgrad(c, w, side))) return rc;
     }
     // ---- weight gradients of the stack, each kind for ALL layers in one grouped launch (wn_wgrad.h)
     bool grouped;
@@ -361,17 +370,21 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
             if ((rc = launch_wgrad(c, w, st))) return rc;
         }
     }
-    if ((rc = wn_gin_bwd(c, grads, st))) return rc;     // d W_g, d b_g, d embedding table (modules.py:499-508)
+    if ((rc = wn_gin_bwd(c, grads, side))) return rc;     // d W_g, d b_g, d embedding table (modules.py:499-508)
     const bf16_t* gx_up = c->GXall;
     // gx_up now holds dL/dh_0
-    if ((rc = wn_first_conv_grad(c, gx_up, grads, st))) return rc;
+    if ((rc = wn_first_conv_grad(c, gx_up, grads, side))) return rc;
     if (c->cfg.upsample_type != WN_UP_NEAREST) {
         // d c_up[b][cc][t] = sum_l W_cin_l dz_l  as one contraction over all layers
         GemmArgs a; base_args(c, a, c->wcT);
         a.nseg = 1; a.seg[0] = seg(c->DZ, G, 0, G, 0, 0); a.nrep = L; a.rep_stride = NT * G;
         a.e.out0 = c->DC; a.e.M_valid = C;
-        if ((rc = wn_launch_gemm<EPI_STORE_F32_BOT>(c, a, c->wcT.M, st))) return rc;
-        if ((rc = wn_upsample_bwd(c, c->DC, grads, st))) return rc;
+        if ((rc = wn_launch_gemm<EPI_STORE_F32_BOT>(c, a, c->wcT.M, side))) return rc;
+        if ((rc = wn_upsample_bwd(c, c->DC, grads, side))) return rc;
+    }
+    if (side != st) {
+        WN_HIP(c, hipEventRecord(c->ev_join, side));
+        WN_HIP(c, hipStreamWaitEvent(st, c->ev_join, 0));
     }
     return WN_OK;
 }
