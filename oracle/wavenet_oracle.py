@@ -19,8 +19,9 @@ activations); the contraction itself stays fp32 like an MFMA with fp32 accumulat
 That variant is used for tight kernel-logic checks; the plain fp32 variant is the
 reference arithmetic.
 
-parity unpinned for this file's conv/upsample/incremental/optimiser rows (no TF here,
-no reference golden vectors) -- see oracle/__init__.py.
+Pinned (see oracle/__init__.py): step / upsample / training_loss / incremental reproduce, to fp32 round-off, the outputs
+of the reference's own wavenet.py + modules.py executed on the eager TF-1 stand-in (tests/golden/stack_*.npz); the
+optimiser row (TF library semantics) is parity unpinned.
 """
 import math
 from collections import OrderedDict

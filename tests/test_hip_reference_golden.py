@@ -1,0 +1,80 @@
+"""HIP path vs golden vectors produced by executing the REFERENCE's own wavenet.py / modules.py (oracle/gen_golden_stack.py,
+eager TF-1 stand-in): the device results are compared with the reference's outputs directly, not via the oracle.
+
+Tolerances (bf16 MFMA operands, fp32 accumulation -- DESIGN.md section 5): y_hat rel-L2 <= 5e-2, loss rtol 2e-2,
+upsampled conditioning (fp32 kernels) rtol 1e-4; synthesis raw outputs rel-L2 <= 5e-2 teacher-forced."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hip_util import make_hp, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stack_hip_*.npz')))
+DEFAULTS = dict(layers=4, stacks=2, kernel_size=3, gin_channels=-1, use_speaker_embedding=True, n_speakers=3, input_type='raw',
+                quantize_channels=65536, use_bias=True, legacy=False, residual_legacy=False, wavenet_dropout=0.0, upsample_type='2D',
+                upsample_activation='Relu', leaky_alpha=0.4, freq_axis_kernel_size=3, NN_init=True, NN_scaler=0.3,
+                log_scale_min=float(np.log(1e-14)), log_scale_min_gauss=float(np.log(1e-7)), cdf_loss=False)
+
+
+def _load(path):
+    g = np.load(path)
+    kw = dict(DEFAULTS); kw.update(json.loads(str(g['hparams_json'])))
+    kw['hop_size'] = int(np.prod(kw['upsample_scales']))
+    hp = make_hp(**kw)
+    return g, hp
+
+
+@pytest.mark.parametrize('path', GOLD, ids=[os.path.basename(p)[10:-4] for p in GOLD])
+def test_device_matches_reference_execution(path):
+    from wavenet_vocoder import _ext
+    g, hp = _load(path)
+    B, T = g['wav'].shape
+    eng = _ext.Engine(hp, B, T)
+    # the engine's parameter table == the variables the reference model created
+    ref_params = {k[len('params/'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('params/')}
+    assert set(eng.layout) == set(ref_params), sorted(set(eng.layout) ^ set(ref_params))
+    flat = torch.zeros(eng.n_params)
+    for name, (shape, off) in eng.layout.items():
+        assert tuple(ref_params[name].shape) == tuple(shape), (name, ref_params[name].shape, shape)
+        flat[off:off + ref_params[name].numel()] = ref_params[name].reshape(-1)
+    eng.pack_weights(flat.cuda())
+    scalar = hp.input_type != 'mulaw-quantize'
+    c = torch.from_numpy(g['c']).cuda()
+    lengths = torch.from_numpy(g['lengths']).int().cuda()
+    if scalar:
+        wav = torch.from_numpy(g['wav'])
+        x = wav.view(B, 1, T).contiguous().cuda(); y = wav.view(B, T, 1).contiguous().cuda()
+    else:
+        ids = torch.from_numpy(g['ids']).int()
+        x = ids.cuda(); y = ids.cuda()
+    if 'g' in g.files:
+        gg = torch.from_numpy(g['g'])
+        eng.set_global_condition((gg.reshape(B).int() if hp.use_speaker_embedding else gg.reshape(B, -1).float()).cuda())
+    loss = torch.zeros(1, device='cuda'); y_hat = torch.empty(B, hp.out_channels, T, device='cuda')
+    eng.train_fwd(x, c, y, lengths, 0, loss, y_hat)
+    cup = eng.debug_copy('CUP', eng.cfg.n_upsample - 1, B * hp.cin_channels, T).cpu().view(B, hp.cin_channels, T)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(cup.numpy(), g['c_up'], rtol=1e-4, atol=1e-5)                   # wavenet.py:680-702
+    e = rel_err(y_hat.cpu(), torch.from_numpy(g['y_hat']))
+    print('\n[%s] y_hat rel-L2 vs reference execution %.3e; loss dev %.6f ref %.6f' % (os.path.basename(path), e, float(loss), float(g['loss'][0])))
+    assert e < 5e-2
+    assert abs(float(loss) - float(g['loss'][0])) <= 2e-2 * max(1.0, abs(float(g['loss'][0])))
+    if 'inc_tf_raw' not in g.files:
+        return
+    # synthesis, teacher-forced with the reference's own sampler noise: raw network outputs per step (wavenet.py:724-911)
+    if hp.out_channels == 2:
+        noise = torch.from_numpy(g['eps_tf']).unsqueeze(-1)                                     # [T, B, 1]
+    else:
+        noise = torch.cat([torch.from_numpy(g['u1_tf']), torch.from_numpy(g['u2_tf']).unsqueeze(-1)], -1)   # [T, B, M+1]
+    out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, hp.out_channels, T, device='cuda')
+    eng.synthesize(c, noise.contiguous().cuda(), out, raw, torch.from_numpy(g['wav']).contiguous().cuda(), steps_per_graph=8)
+    torch.cuda.synchronize()
+    e2 = rel_err(raw.cpu(), torch.from_numpy(g['inc_tf_raw']))
+    print('[%s] incremental raw rel-L2 vs reference execution %.3e' % (os.path.basename(path), e2))
+    assert e2 < 5e-2

@@ -55,3 +55,110 @@ def test_gaussian_loss_and_sampler(golden_dir):
             np.testing.assert_allclose(l.numpy(), g['loss_cdf%d_%s' % (int(cdf), tag)], rtol=1e-6, atol=1e-6)
     s = O.sample_from_gaussian(y_hat, torch.from_numpy(g['eps']), float(np.log(1e-7)))
     np.testing.assert_allclose(s.numpy(), g['sample'], rtol=0, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Conv stack / upsample net / incremental loop: golden vectors produced by executing the reference's own wavenet.py and
+# modules.py on the eager TF-1 stand-in (oracle/tf1_shim.py, oracle/gen_golden_stack.py).  The oracle must reproduce the
+# reference's COMPOSITION of ops to fp32 round-off.
+import glob
+import json
+
+import pytest
+
+_STACK_DEFAULTS = dict(layers=4, stacks=2, residual_channels=16, gate_channels=32, skip_out_channels=16, out_channels=6, kernel_size=3,
+                       cin_channels=8, gin_channels=-1, use_speaker_embedding=True, n_speakers=3, input_type='raw', quantize_channels=65536,
+                       use_bias=True, legacy=False, residual_legacy=False, wavenet_dropout=0.0, upsample_type='2D', upsample_scales=[2, 3],
+                       upsample_activation='Relu', leaky_alpha=0.4, freq_axis_kernel_size=3, NN_init=True, NN_scaler=0.3,
+                       log_scale_min=float(np.log(1e-14)), log_scale_min_gauss=float(np.log(1e-7)), cdf_loss=False)
+_STACK_FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stack_*.npz')))
+
+
+def _load_stack(path):
+    g = np.load(path)
+    kw = dict(_STACK_DEFAULTS); kw.update(json.loads(str(g['hparams_json'])))
+    cfg = O.OracleConfig(**{k: v for k, v in kw.items() if k in O.OracleConfig.__dataclass_fields__})
+    params = {k[len('params/'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('params/')}
+    return g, cfg, params
+
+
+def test_reference_executed_goldens_exist():
+    assert len(_STACK_FILES) >= 11, 'run oracle/gen_golden_stack.py in the container that has /root/reference'
+
+
+@pytest.mark.parametrize('path', _STACK_FILES, ids=[os.path.basename(p)[6:-4] for p in _STACK_FILES])
+def test_stack_matches_reference_execution(path):
+    g, cfg, params = _load_stack(path)
+    # the oracle's parameter table has exactly the variables the reference model created (names and TF shapes)
+    sh = O.param_shapes(cfg)
+    assert set(sh) == set(params), (sorted(set(sh) ^ set(params)))
+    for k in sh:
+        assert tuple(params[k].shape) == tuple(sh[k]), (k, params[k].shape, sh[k])
+    x, c = torch.from_numpy(g['x']), torch.from_numpy(g['c'])
+    gg = None
+    if 'g' in g.files:
+        gg = torch.from_numpy(g['g'])
+        gg = gg.reshape(-1) if cfg.use_speaker_embedding else gg.reshape(gg.shape[0], -1)
+    c_up = O.upsample(params, cfg, c)
+    np.testing.assert_allclose(c_up.numpy(), g['c_up'], rtol=1e-5, atol=1e-6)                 # wavenet.py:680-702
+    y = O.step(params, cfg, x, c, g=gg)
+    np.testing.assert_allclose(y.numpy(), g['y_hat'], rtol=2e-5, atol=2e-6)                   # wavenet.py:650-721
+    # masked training loss as WaveNet.add_loss wires it (wavenet.py:476-495, 632-638; modules.py:781-836), ragged lengths
+    y_t = torch.from_numpy(g['ids']).long() if 'ids' in g.files else torch.from_numpy(g['wav']).unsqueeze(-1)
+    loss = O.training_loss(cfg, torch.from_numpy(g['y_hat']), y_t, [int(v) for v in g['lengths']])
+    np.testing.assert_allclose(float(loss), float(g['loss'][0]), rtol=2e-6)
+    if 'inc_tf_raw' not in g.files:
+        return
+    B, T = g['wav'].shape
+    wav = torch.from_numpy(g['wav'])
+    def noise(tag):
+        if cfg.out_channels == 2:
+            return {'eps': torch.from_numpy(g['eps_' + tag])}
+        return {'u1': torch.from_numpy(g['u1_' + tag]), 'u2': torch.from_numpy(g['u2_' + tag])}
+    for form in ('reference', 'ring'):
+        # teacher-forced (wavenet.py:752-768, 877-878): raw outputs and the samples drawn from them
+        out, raw = O.incremental(params, cfg, c, noise=noise('tf'), test_inputs=wav.unsqueeze(-1), formulation=form, g=gg)
+        np.testing.assert_allclose(raw.numpy(), g['inc_tf_raw'], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(out.numpy(), g['inc_tf_out'], rtol=0, atol=2e-5)
+        # free-running: the sample feeds back (wavenet.py:853-880), so this also pins the recurrence
+        out, raw = O.incremental(params, cfg, c, noise=noise('free'), test_inputs=None, formulation=form, g=gg)
+        np.testing.assert_allclose(out.numpy(), g['inc_free_out'], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(raw.numpy(), g['inc_free_raw'], rtol=1e-4, atol=1e-4)
+
+
+def test_shim_convolutions_against_naive_loops():
+    """The TF stand-in's convolution primitives (the part of the golden pipeline that is ours, not the reference's) against
+    direct index arithmetic written from the TensorFlow documentation."""
+    from oracle import tf1_shim as S
+    gen = torch.Generator().manual_seed(0)
+    # Conv1D valid, dilation 2, channels_first: y[o,t] = b[o] + sum_{j,i} K[j,i,o] x[i, t + j*d]
+    L = S.Conv1D(3, 3, dilation_rate=2, data_format='channels_first', name='t_c1'); S.reset()
+    x = torch.randn(1, 2, 9, generator=gen); y = L(x); K, b = L.kernel, L.bias
+    ref = torch.zeros(1, 3, 5)
+    for o in range(3):
+        for t in range(5):
+            ref[0, o, t] = b[o] + sum(K[j, i, o] * x[0, i, t + 2 * j] for j in range(3) for i in range(2))
+    assert torch.allclose(y, ref, atol=1e-5)
+    # Conv2DTranspose SAME, stride (1,s), kernel (3,s), NCHW, kernel layout [kh,kw,out,in]: out[f', t*s+j] = sum_kf x[f'-kf+1, t] K[kf,j]
+    s = 3
+    L = S.Conv2DTranspose(1, (3, s), strides=(1, s), padding='same', data_format='channels_first', name='t_ct'); S.reset()
+    x = torch.randn(1, 1, 4, 5, generator=gen); y = L(x); K = L.kernel[:, :, 0, 0]
+    assert y.shape == (1, 1, 4, 5 * s)
+    ref = torch.zeros(4, 5 * s)
+    for f in range(4):
+        for t in range(5):
+            for j in range(s):
+                ref[f, t * s + j] = sum(x[0, 0, f - kf + 1, t] * K[kf, j] for kf in range(3) if 0 <= f - kf + 1 < 4)
+    assert torch.allclose(y[0, 0], ref, atol=1e-5)
+    # Conv2D SAME with an EVEN kernel width (Resize upsampler): TF pads (k-1)//2 before, the rest after
+    L = S.Conv2D(1, (3, 4), padding='same', data_format='channels_last', name='t_c2'); S.reset()
+    x = torch.randn(1, 3, 6, 1, generator=gen); y = L(x); K = L.kernel[:, :, 0, 0]
+    ref = torch.zeros(3, 6)
+    for f in range(3):
+        for t in range(6):
+            ref[f, t] = sum(x[0, f + kf - 1, t + kt - 1, 0] * K[kf, kt] for kf in range(3) for kt in range(4)
+                            if 0 <= f + kf - 1 < 3 and 0 <= t + kt - 1 < 6)
+    assert torch.allclose(y[0, :, :, 0], ref, atol=1e-5)
+    # batch_to_space_nd: out[b', i*r + j] = in[j*n + b', i]
+    x = torch.arange(2 * 3 * 4).float().reshape(6, 4); y = S.batch_to_space_nd(x, [3], [[0, 0]])
+    assert y.shape == (2, 12) and all(float(y[bp, i * 3 + j]) == float(x[j * 2 + bp, i]) for bp in range(2) for i in range(4) for j in range(3))
