@@ -55,8 +55,6 @@ class Feeder(object):
         self._data_dir = os.path.dirname(metadata_filename)
         with open(metadata_filename, 'r', encoding='utf-8') as f:
             self._metadata = [line.strip().split('|') for line in f if line.strip()]
-        if hparams.gin_channels > 0:
-            raise NotImplementedError('global conditioning is not built')
         from sklearn.model_selection import train_test_split
         indices = np.arange(len(self._metadata))
         test_size = hparams.wavenet_test_size if hparams.wavenet_test_size is not None else hparams.wavenet_test_batches * hparams.wavenet_batch_size
@@ -72,7 +70,7 @@ class Feeder(object):
         if hparams.wavenet_test_size is None:
             assert hparams.wavenet_test_batches == self.test_steps
         self.local_condition = hparams.cin_channels > 0
-        self.global_condition = False
+        self.global_condition = hparams.gin_channels > 0                     # reference feeder.py:353
         self._train_q = queue.Queue(maxsize=8)
         self._eval_q = queue.Queue(maxsize=1)
         self._threads = []
@@ -139,7 +137,12 @@ class Feeder(object):
         input_data = np.load(self._resolve(audio_file))
         local_feats = np.load(self._resolve(mel_file)) if self.local_condition else None
         assert len(input_data) == len(local_feats) * audio.get_hop_size(hp), 'audio / mel length mismatch in %s' % audio_file
-        return input_data, local_feats, None, len(input_data)
+        g = None
+        if self.global_condition:                                      # reference feeder.py:254-257: speaker id column of map.txt
+            g = meta[3]
+            if g == '<no_g>':
+                raise RuntimeError('Please redo the wavenet preprocessing (or GTA synthesis) to assign global condition features!')
+        return input_data, local_feats, g, len(input_data)
 
     def _rng_shared_shuffle(self, meta_list):
         # every rank shuffles identically so that the per-rank slices of a batch stay disjoint
@@ -179,7 +182,9 @@ class Feeder(object):
         if hp.normalize_for_wavenet:
             c = _interp(c, T2)
         c = np.ascontiguousarray(c.transpose(0, 2, 1)).astype(np.float32)   # [B, num_mels, Tc]
-        return (np.ascontiguousarray(inputs), np.ascontiguousarray(targets), input_lengths, c, None)
+        # global conditions: int32 speaker ids [B, 1] (reference feeder.py:342-349)
+        g = np.array([b[2] for b in batch]).astype(np.int32).reshape(-1, 1) if self.global_condition else None
+        return (np.ascontiguousarray(inputs), np.ascontiguousarray(targets), input_lengths, c, g)
 
 
 def _limit_time(batch, hparams, rng):

@@ -59,8 +59,12 @@ class Synthesizer(object):
         c_batch = np.stack([_pad_inputs(x, maxlen, _pad=T2_output_range[0]) for x in mel_spectrograms]).astype(np.float32)
         if hparams.normalize_for_wavenet:
             c_batch = _interp(c_batch, T2_output_range).astype(np.float32)
-        if speaker_ids is not None and self.global_conditions:
-            raise NotImplementedError('global conditioning is not built')
+        # global condition: int32 speaker ids [B, 1] (reference synthesizer.py:72)
+        g = None
+        if self.global_conditions:
+            if speaker_ids is None:
+                raise RuntimeError('Please provide speaker ids (--speaker_id) to a globally conditioned WaveNet')
+            g = torch.from_numpy(np.asarray(speaker_ids, dtype=np.int32).reshape(len(c_batch), 1))
         self._ensure_capacity(len(c_batch), maxlen * hop)
         dev = self.model.device
         test_inputs = None
@@ -69,7 +73,7 @@ class Synthesizer(object):
             T = maxlen * hop
             test_inputs = torch.from_numpy(np.stack([np.pad(w[:T], (0, max(0, T - len(w)))) for w in test_wavs]).astype(np.float32)).to(dev)
         # c: [B, Tc, num_mels] like the reference's placeholder; the model transposes it (wavenet.py:427)
-        self.model.initialize(None, torch.from_numpy(c_batch).to(dev), None, None, test_inputs=test_inputs)
+        self.model.initialize(None, torch.from_numpy(c_batch).to(dev), None if g is None else g.to(dev), None, test_inputs=test_inputs)
         torch.cuda.synchronize()
         generated = self.model.tower_y_hat[0].float().cpu().numpy()
         feats = self.model.tower_synth_upsampled_local_features[0].cpu().numpy()

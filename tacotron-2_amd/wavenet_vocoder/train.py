@@ -115,10 +115,10 @@ def _scalars_writer(tensorboard_dir):
 def save_log(model, batch, step, plot_dir, wav_dir, hparams, model_name):
     """Predicted-vs-target wav + plots for item 0 of the current batch (reference train.py:128-162)."""
     log('\nSaving intermediate states at step {}'.format(step))
-    x, y, lengths, c, _ = batch
+    x, y, lengths, c, g = batch
     idx = 0
     length = int(lengths[idx])
-    y_hat = model.step(x[idx:idx + 1], c[idx:idx + 1])
+    y_hat = model.step(x[idx:idx + 1], c[idx:idx + 1], g=None if g is None else g[idx:idx + 1])
     T = y_hat.shape[-1]
     nps = model.engine.noise_per_step
     if util.is_mulaw_quantize(hparams.input_type):
@@ -150,8 +150,8 @@ def eval_step(model, batch, step, plot_dir, wav_dir, scalars, hparams, model_nam
     """Full-utterance autoregressive generation of item 0, teacher-forced unless wavenet_natural_eval
     (reference train.py:89-126, wavenet.py:342-405)."""
     start_time = time.time()
-    x, y, lengths, c, _ = batch
-    model.initialize(y, c, None, lengths)
+    x, y, lengths, c, g = batch
+    model.initialize(y, c, g, lengths)
     torch.cuda.synchronize()
     y_hat = model.tower_y_hat[0].cpu().numpy()
     y_target = model.tower_y_target[0].float().cpu().numpy()

@@ -1,0 +1,81 @@
+"""End-to-end run of the reference-shaped drivers on the device: wavenet_train on a small on-disk dataset in the reference's
+formats (map.txt + audio-*.npy + mel-*.npy, feeder.py:241-257), checkpoint + restore, then wavenet_synthesize from the
+checkpoint (train.py:345, synthesize.py:69, synthesizer.py:46) -- same directories and file names as the reference."""
+import glob
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(root, n=24, hop=16, mels=16, speakers=None):
+    os.makedirs(os.path.join(root, 'audio'), exist_ok=True); os.makedirs(os.path.join(root, 'mels'), exist_ok=True)
+    rng = np.random.RandomState(0)
+    lines = []
+    for i in range(n):
+        frames = int(rng.randint(24, 48))
+        t = np.arange(frames * hop)
+        wav = (0.4 * np.sin(2 * np.pi * (100 + 7 * i) * t / 22050.0) + 0.02 * rng.randn(frames * hop)).astype(np.float32)
+        mel = rng.uniform(-4, 4, size=(frames, mels)).astype(np.float32)
+        np.save(os.path.join(root, 'audio', 'audio-%03d.npy' % i), wav)
+        np.save(os.path.join(root, 'mels', 'mel-%03d.npy' % i), mel)
+        sp = '<no_g>' if speakers is None else str(i % speakers)
+        lines.append('audio/audio-%03d.npy|mels/mel-%03d.npy|mels/mel-%03d.npy|%s|%d|%d|text' % (i, i, i, sp, len(wav), frames))
+    with open(os.path.join(root, 'map.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    return 'map.txt'
+
+
+@pytest.mark.parametrize('gin', [False, True])
+def test_train_checkpoint_restore_synthesize(tmp_path, gin):
+    import hparams as H
+    from wavenet_vocoder.train import wavenet_train, get_checkpoint_state
+    from wavenet_vocoder.synthesize import wavenet_synthesize
+    root = str(tmp_path)
+    meta = _dataset(root, speakers=3 if gin else None)
+    hp = H._build()
+    hp.parse('layers=4,stacks=2,residual_channels=64,gate_channels=128,skip_out_channels=64,cin_channels=16,num_mels=16,out_channels=30,'
+             'hop_size=16,upsample_scales=[4,4],max_time_steps=512,wavenet_batch_size=4,wavenet_test_batches=1,wavenet_synthesis_batch_size=2,'
+             'wavenet_learning_rate=1e-3,wavenet_dropout=0.05' + (',gin_channels=8,n_speakers=3,use_speaker_embedding=True' if gin else ''))
+    log_dir = os.path.join(root, 'logs-WaveNet')
+    os.makedirs(log_dir, exist_ok=True)
+    args = types.SimpleNamespace(base_dir=root, model='WaveNet', restore=False, wavenet_train_steps=6, checkpoint_interval=3,
+                                 summary_interval=2, eval_interval=6, embedding_interval=100, eval_max_time=0)
+    save_dir = wavenet_train(args, log_dir, hp, meta)
+    assert save_dir is not None and os.path.isdir(save_dir), 'the driver returns None when training raised'
+    ckpt = get_checkpoint_state(save_dir)
+    assert ckpt.endswith('wavenet_model.ckpt-6.pt') and os.path.exists(ckpt)
+    for f in ('wavs/step-3-pred.wav', 'wavs/step-3-real.wav', 'wavs/step-6-pred.wav', 'eval-dir/wavs/step-6-pred.wav', 'wavenet_events/scalars.jsonl'):
+        assert os.path.exists(os.path.join(log_dir, f)), f
+    rows = [json.loads(l) for l in open(os.path.join(log_dir, 'wavenet_events', 'scalars.jsonl'))]
+    losses = [r['wavenet_loss'] for r in rows if 'wavenet_loss' in r]
+    assert len(losses) == 3 and all(np.isfinite(losses))
+    assert any('Wavenet_eval_model/eval_stats/wavenet_eval_loss' in r for r in rows)
+    # restore and continue: the step counter and the optimiser state come back
+    args.restore = True; args.wavenet_train_steps = 8
+    assert wavenet_train(args, log_dir, hp, meta) == save_dir
+    assert get_checkpoint_state(save_dir).endswith('wavenet_model.ckpt-8.pt')
+    sd = torch.load(get_checkpoint_state(save_dir), map_location='cpu')
+    assert int(sd['global_step']) == 8 and float(sd['adam_v'].abs().sum()) > 0 and not torch.equal(sd['params'], sd['ema'])
+    # synthesis from mel .npy files (synthesize.py:69): wavs + map.txt in wavenet_<output_dir>
+    mels_dir = os.path.join(root, 'mels_in'); os.makedirs(mels_dir)
+    for i in range(3):
+        np.save(os.path.join(mels_dir, 'mel-%d.npy' % i), np.load(os.path.join(root, 'mels', 'mel-%03d.npy' % i))[:6])
+    cwd = os.getcwd(); os.chdir(root)
+    try:
+        sargs = types.SimpleNamespace(model='WaveNet', mels_dir=mels_dir, output_dir='output/', speaker_id='0,1,2' if gin else None)
+        wavenet_synthesize(sargs, hp, save_dir)
+    finally:
+        os.chdir(cwd)
+    wavs = sorted(glob.glob(os.path.join(root, 'wavenet_output', 'wavs', '*.wav')))
+    assert len(wavs) == 3
+    lines = open(os.path.join(root, 'wavenet_output', 'wavs', 'map.txt')).read().strip().split('\n')
+    assert len(lines) == 3 and all(len(l.split('|')) == 3 for l in lines)
+    from scipy.io import wavfile
+    sr, data = wavfile.read(wavs[0])
+    assert sr == hp.sample_rate and len(data) == 6 * 16 and np.abs(data).max() > 0
