@@ -184,6 +184,7 @@ def main():
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-synth', action='store_true')
+    ap.add_argument('--no-exclusive', action='store_true', help='skip the untimed single-stream pass (keeps a rocprofv3 trace to the timed configuration)')
     ap.add_argument('--batch', type=int, default=None, help='override per-GPU batch (debug)')
     ap.add_argument('--time', type=int, default=None, help='override T (debug)')
     args = ap.parse_args()
@@ -249,15 +250,17 @@ def main():
     prof_ms, prof_n = eng.profile_result()
     rows_launch = eng.profile_rows_per_launch()
     # untimed extra: the same kernel with the GPU to itself (whole batch on one stream), for the kernel-quality view
-    eng.set_batch_parts(1)
-    one_step(args.warmup + args.steps)
-    eng.profile(True)
-    for i in range(2):
-        one_step(args.warmup + args.steps + 1 + i)
-    excl_ms, excl_n = eng.profile_result()
-    excl_rows = eng.profile_rows_per_launch()
-    eng.profile(False)
-    eng.set_batch_parts(0)
+    excl_ms, excl_n, excl_rows = 0.0, 0, 0
+    if not args.no_exclusive:
+        eng.set_batch_parts(1)
+        one_step(args.warmup + args.steps)
+        eng.profile(True)
+        for i in range(2):
+            one_step(args.warmup + args.steps + 1 + i)
+        excl_ms, excl_n = eng.profile_result()
+        excl_rows = eng.profile_rows_per_launch()
+        eng.profile(False)
+        eng.set_batch_parts(0)
     final_loss = float(loss.item())
     if world > 1:
         tmax = torch.tensor([dt], device=device)

@@ -8,11 +8,12 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 ( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -25; echo "rc=${PIPESTATUS[0]}" ) > $OUT/pytest_gpu.log
+( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) > $OUT/smoke.log
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "rc=$?" >> $OUT/bench.err
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o c2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-synth > $OUT/kt.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c2 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-synth > $OUT/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c2 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-synth > $OUT/pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o c2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-synth --no-exclusive > $OUT/kt.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c2 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-synth --no-exclusive > $OUT/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c2 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-synth --no-exclusive > $OUT/pmc_write.log 2>&1
 cd $R
 for d in pmc_fetch pmc_write; do
   f=$(find $OUT/$d -name '*counter_collection.csv' | head -1)
@@ -20,4 +21,4 @@ for d in pmc_fetch pmc_write; do
 done
 find $OUT -name '*.csv' -size +8M -delete
 ls -laR $OUT | head -60
-tail -3 $OUT/pytest_gpu.log; cat $OUT/bench.json | cut -c1-600
+tail -3 $OUT/pytest_gpu.log; cat $OUT/smoke.log; cat $OUT/bench.json | cut -c1-600
