@@ -860,6 +860,19 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             return WN_OK;
         }
     }
+    if constexpr (EPI != EPI_STORE_F32_BOT) {
+        if (M % 128 == 0 && a.e.M_valid == M && a.zero) {
+            // 128-channel models (hparams.py defaults: R = S = 128): the same LDS-DMA main loop with a 128 x 128 tile (8 waves, 32 x 64 each)
+            a.mblocks = M / 128;
+            a.tiles_per_utt = cdiv(a.T, 128);
+            a.ntiles = a.tiles_per_utt * a.B;
+            const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+            a.stagger = grid >= 1024 ? 8000 : 0;
+            hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
+            WN_LAUNCH_CHECK(ctx);
+            return WN_OK;
+        }
+    }
     if constexpr (EPI == EPI_STORE_F32_BOT) {
         if (M == 96 && a.zero) {           // d c_up with <= 96 conditioning channels: 96 channels x 192 time rows, 6 waves (32 x 96 each)
             a.mblocks = 1;

@@ -311,17 +311,18 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
         if ((rc = launch_wgrad(c, w, side))) return rc;
     }
     // ---- weight gradients of the stack, each kind for ALL layers in one grouped launch (wn_wgrad.h)
-    bool grouped;
+    bool grouped, fused;
     { WgBatchArgs w; wgrad_w1_args(c, w, 0, 1, c->fB, c->fT); grouped = wn_wgrad_v2_ok(w);
-      wgrad_skip_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w);
-      wgrad_out_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w); }
+      wgrad_skipout_args(c, w, 0, 1, c->fB, c->fT); fused = wn_wgrad_v2_ok(w) && c->S % 8 == 0;     // N = S + R (256 for the 128-channel default hparams)
+      if (!fused) { wgrad_skip_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w);
+                    wgrad_out_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w); } }
     for (int l0 = 0; grouped && l0 < L; l0 += WN_MAX_GROUPS) {
         const int ng = min(WN_MAX_GROUPS, L - l0);
         {   // d [W_dil; W_cin], d biases:  A = [xd(t-2d) | xd(t-d) | xd(t) | c(t)],  B = d z
             WgBatchArgs w; wgrad_w1_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
             if ((rc = launch_wgrad_batch(c, w, st))) return rc;
         }
-        if (c->S % 256 == 0 && c->R % 256 == 0) {
+        if (fused) {
             // d W_skip (scaled by the legacy factor c_l) and d W_out with their biases in ONE launch: A = u_l, B = [d skip | rho dL/dh_{l+1}]
             WgBatchArgs w; wgrad_skipout_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
             if ((rc = launch_wgrad_batch(c, w, st))) return rc;

@@ -235,9 +235,10 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
         }
     }
     const int n0 = nblk * 256;
-    const bool hi = a.split_n > 0 && n0 >= a.split_n;
-    const bf16_t* b_base = hi ? a.Bm_hi + (int64_t)grp * a.b_gstride_hi + (n0 - a.split_n) : a.Bm + (int64_t)grp * a.b_gstride + n0;
-    const int b_ld = hi ? a.ldb_hi : a.ldb;
+    // B columns [0, split_n) come from Bm, [split_n, N) from Bm_hi (fused launches); the split may fall INSIDE a 256-column
+    // tile (narrow models: S = R = 128), so the operand is chosen per 8-column slot, i.e. per lane of the DMA
+    const bf16_t* const b_lo = a.Bm + (int64_t)grp * a.b_gstride;
+    const bf16_t* const b_hi = a.split_n > 0 ? a.Bm_hi + (int64_t)grp * a.b_gstride_hi : nullptr;
 
     f32x16_t acc[2][2];
 #pragma unroll
@@ -270,8 +271,10 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
             const int row = g * 2 + (lane >> 5);
             const int c = (lane & 31) ^ ((row & 3) << 2);
             const int t = tc + row;
-            const bool ok = (t < ts1) && (n0 + c * 8 < a.N);
-            const bf16_t* src = ok ? b_base + (rowbase + t) * b_ld + c * 8 : a.zero;
+            const int col = n0 + c * 8;
+            const bool ok = (t < ts1) && (col < a.N);
+            const bool hi = a.split_n > 0 && col >= a.split_n;
+            const bf16_t* src = !ok ? a.zero : hi ? b_hi + (rowbase + t) * a.ldb_hi + (col - a.split_n) : b_lo + (rowbase + t) * a.ldb + col;
             wg_lds_dma16(src, __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(bbuf + g * 1024)));
         }
     };
