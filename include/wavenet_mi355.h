@@ -82,7 +82,9 @@ typedef struct wn_config {
     int32_t gin_channels;           /* <= 0 disables                                                          */
     int32_t use_speaker_embedding;  /* 1: g = speaker ids looked up in the [n_speakers, gin_channels] table    */
     int32_t n_speakers;
-    int32_t reserved0;
+    /* Salimans & Kingma weight normalisation of every convolution (hparams.py:323; modules.py:44-177): the exported tensors
+     * become kernel (= v), g [last kernel axis], bias; kernels are used as g * v / ||v|| (norm over all axes but the last). */
+    int32_t weight_normalization;
 } wn_config;
 
 typedef struct wn_ctx wn_ctx;

@@ -59,6 +59,9 @@ CONFIGS = {
     'softmax': dict(input_type='mulaw-quantize', out_channels=32, quantize_channels=32, layers=6, stacks=3),
     'mol_gin_embed': dict(gin_channels=4, use_speaker_embedding=True),
     'mol_gin_raw_nobias': dict(gin_channels=4, use_speaker_embedding=False, use_bias=False),
+    # weight normalisation (modules.py:44-177): gains perturbed away from ||v|| so that the normalisation is visible
+    'mol_weightnorm': dict(wavenet_weight_normalization=True, NN_init=False),
+    'gauss_weightnorm_1d': dict(wavenet_weight_normalization=True, out_channels=2, upsample_type='1D', upsample_scales=[2, 2], NN_init=False, use_bias=False),
     # widths the HIP engine accepts (multiples of 64 / 16): tests/test_hip_reference_golden.py runs the DEVICE path on these
     'hip_mol_2d': dict(residual_channels=64, gate_channels=128, skip_out_channels=64, cin_channels=16, num_mels=16, out_channels=30,
                        upsample_scales=[4, 4], NN_init=False),
@@ -67,6 +70,8 @@ CONFIGS = {
     'hip_softmax_resize': dict(residual_channels=64, gate_channels=128, skip_out_channels=64, cin_channels=16, num_mels=16,
                                input_type='mulaw-quantize', out_channels=256, quantize_channels=256, upsample_type='Resize',
                                upsample_scales=[2, 8], upsample_activation='LeakyRelu', NN_init=False),
+    'hip_mol_weightnorm': dict(residual_channels=64, gate_channels=128, skip_out_channels=64, cin_channels=16, num_mels=16, out_channels=30,
+                               upsample_scales=[4, 4], NN_init=False, wavenet_weight_normalization=True),
     'hip_mol_gin_1d': dict(residual_channels=64, gate_channels=128, skip_out_channels=64, cin_channels=16, num_mels=16, out_channels=30,
                            upsample_type='1D', upsample_scales=[4, 4], gin_channels=16, use_speaker_embedding=True, n_speakers=4, NN_init=False),
 }
@@ -89,13 +94,13 @@ def _import_reference():
 
 def _oracle_name(ref_name):
     """shim variable name ('<layer.name>/kernel') -> oracle / engine tensor name."""
-    m = re.match(r'residual_block_(causal|cin|gin|skip|out)_conv_ResidualConv1DGLU_(\d+)/(kernel|bias)$', ref_name)
+    m = re.match(r'residual_block_(causal|cin|gin|skip|out)_conv_ResidualConv1DGLU_(\d+)/(kernel|bias|g)$', ref_name)
     if m:
         return 'ResidualConv1DGLU_%s/residual_block_%s_conv/%s' % (m.group(2), m.group(1), m.group(3))
-    m = re.match(r'(input_convolution|final_convolution_[12])/(kernel|bias)$', ref_name)
+    m = re.match(r'(input_convolution|final_convolution_[12])/(kernel|bias|g)$', ref_name)
     if m:
         return ref_name
-    m = re.match(r'(ConvTranspose2D|ConvTranspose1D|ResizeConvolution|SubPixelConvolution)_layer_(\d+)/(kernel|bias)$', ref_name)
+    m = re.match(r'(ConvTranspose2D|ConvTranspose1D|ResizeConvolution|SubPixelConvolution)_layer_(\d+)/(kernel|bias|g)$', ref_name)
     if m:
         return 'local_conditioning_upsampling_%d/%s' % (int(m.group(2)) + 1, m.group(3))
     if ref_name == 'gc_embedding':
@@ -130,6 +135,22 @@ def run_config(wn, name, over):
     for k, v in shim.variables().items():                           # reference biases start at zero: give them signal
         if k.endswith('/bias'):
             v.copy_((torch.rand(v.shape, generator=gen) * 2 - 1) * 0.1)
+    wn_on = bool(getattr(hp, 'wavenet_weight_normalization', False))
+    if wn_on:
+        for k, v in shim.variables().items():                       # gains start at ||v|| (kernel == v): move them
+            if k.endswith('/g'):
+                v.mul_(torch.rand(v.shape, generator=gen) * 0.8 + 0.6)
+        # in a TF graph `kernel = l2_normalize(v) * g` is re-evaluated on every run; the eager stand-in built it once
+        def _wn_layers(obj, seen):
+            if id(obj) in seen or not hasattr(obj, '__dict__'):
+                return
+            seen.add(id(obj))
+            if type(obj).__name__ == 'WeightNorm':
+                obj._compute_weights()
+            for vv in list(vars(obj).values()):
+                for o in (vv if isinstance(vv, (list, tuple)) else [vv]):
+                    _wn_layers(o, seen)
+        _wn_layers(model, set())
     y_hat = model.step(x, c=c, g=g, softmax=False)
     c_up = model.upsampled_local_features
     assert y_hat.shape == (B, hp.out_channels, T) and not torch.equal(y0, y_hat)
@@ -160,7 +181,7 @@ def run_config(wn, name, over):
     kw = dict(c=c, g=g, time_length=T, softmax=False, quantize=True, log_scale_min=hp.log_scale_min, log_scale_min_gauss=hp.log_scale_min_gauss)
     res = {}
     shim._STATE.uniform_draws.clear(); shim._STATE.normal_draws.clear()
-    if scalar:
+    if scalar and not wn_on:      # (with weight normalisation the reference's incremental path multiplies the RAW v: SURVEY C-7)
         out_tf = model_s.incremental(init, test_inputs=ti, **kw)
         res['inc_tf_raw'] = model_s.tower_y_hat_eval[0]              # [B, O, T]
         res['inc_tf_out'] = out_tf
@@ -187,9 +208,10 @@ def run_config(wn, name, over):
         arrays['params/' + _oracle_name(k)] = v.detach().numpy().copy()
     # SubPixelConvolution.build replaces its kernel attribute by W_0 tiled over the sub-pixel filters when NN_init is off
     # (modules.py:584-592): the EFFECTIVE kernel is what the layer multiplies with
-    ups = [l for l in getattr(model, 'upsample_conv', []) if hasattr(l, 'kernel') and l.kernel is not None]
-    for i, l in enumerate(ups):
-        arrays['params/local_conditioning_upsampling_%d/kernel' % (i + 1)] = l.kernel.detach().numpy().copy()
+    if not wn_on:
+        ups = [l for l in getattr(model, 'upsample_conv', []) if hasattr(l, 'kernel') and l.kernel is not None]
+        for i, l in enumerate(ups):
+            arrays['params/local_conditioning_upsampling_%d/kernel' % (i + 1)] = l.kernel.detach().numpy().copy()
     arrays['hparams_keys'] = np.array(sorted(over.keys()))
     arrays['hparams_json'] = np.array(__import__('json').dumps(over))
     np.savez_compressed(os.path.join(OUT, 'stack_%s.npz' % name), **arrays)

@@ -67,13 +67,30 @@ def _glorot_uniform(shape):
     return (torch.rand(shape, generator=_STATE.gen) * 2 - 1) * lim
 
 
+class _Shape(tuple):
+    """tf.TensorShape-like view of a variable's shape (WeightNorm.build reads kernel.shape.ndims, modules.py:149)."""
+    @property
+    def ndims(self):
+        return len(self)
+
+    def as_list(self):
+        return list(self)
+
+
+class _Var(torch.Tensor):
+    """A variable: a torch tensor whose .shape also answers .ndims."""
+    @property
+    def shape(self):
+        return _Shape(torch.Tensor.size(self))
+
+
 def _make_variable(name, shape, initializer):
     """Variables are shared by name (tf.AUTO_REUSE-like): the synthesis-mode model instance reuses the training one's."""
     if name in _STATE.variables:
         v = _STATE.variables[name]
         assert tuple(v.shape) == tuple(int(s) for s in shape), (name, v.shape, shape)
         return v
-    v = (initializer(shape) if initializer is not None else _glorot_uniform(shape)).float().contiguous()
+    v = (initializer(shape) if initializer is not None else _glorot_uniform(shape)).float().contiguous().as_subclass(_Var)
     _STATE.variables[name] = v
     return v
 
@@ -491,6 +508,8 @@ def install():
         softmax=lambda x, axis=-1: torch.softmax(x, dim=axis), softplus=F.softplus,
         bias_add=lambda x, b: x + b, embedding_lookup=lambda table, ids: table[_t(ids).long()],
         log_softmax=lambda x, axis=-1: torch.log_softmax(x, dim=axis),
+        l2_normalize=lambda x, axis=None, epsilon=1e-12: x * torch.rsqrt(torch.clamp((x * x).sum(dim=tuple(axis) if isinstance(axis, (list, tuple)) else axis, keepdim=True), min=epsilon)),
+        moments=lambda x, axes: (x.mean(dim=tuple(axes)), x.var(dim=tuple(axes), unbiased=False)),
         softmax_cross_entropy_with_logits_v2=lambda logits, labels: -(labels * torch.log_softmax(logits, dim=-1)).sum(-1))
     tf.train = types.SimpleNamespace(replica_device_setter=lambda *a, **k: None)
     tf.contrib = types.SimpleNamespace(distributions=types.SimpleNamespace(Normal=_Normal),
@@ -505,7 +524,10 @@ def install():
     npu.to_categorical = lambda y, num_classes=None: np.eye(int(num_classes if num_classes is not None else np.max(y) + 1), dtype=np.float32)[np.asarray(y).astype(int)]
     sys.modules['keras.utils.np_utils'] = npu
     sys.modules['keras.utils'].np_utils = npu; sys.modules['keras'].utils = sys.modules['keras.utils']
-    torch.Tensor.get_shape = lambda self: tuple(self.shape)       # mixture.py:7,14 call x.get_shape() on tensors
+    torch.Tensor.get_shape = lambda self: tuple(self.shape)
+    torch.Tensor.assign = lambda self, v: self.copy_(v)           # tf.Variable.assign (WeightNorm.build, modules.py:170)
+    if not hasattr(torch.Size, 'ndims'):
+        pass       # mixture.py:7,14 call x.get_shape() on tensors
     if not hasattr(np, 'int'):
         np.int = int          # removed in numpy >= 1.24; it always was the builtin
     return tf

@@ -64,6 +64,7 @@ class OracleConfig:
     gin_channels: int = -1                 # hparams.py:228: <= 0 disables global conditioning
     use_speaker_embedding: bool = True     # hparams.py:229
     n_speakers: int = 5                    # hparams.py:230
+    wavenet_weight_normalization: bool = False   # hparams.py:323
 
     @property
     def scalar_input(self):
@@ -147,7 +148,35 @@ def param_shapes(cfg: OracleConfig):
                 sh[p + 'kernel'] = (fk, 3, 1, s); sh[p + 'bias'] = (s,)
             else:
                 raise ValueError(cfg.upsample_type)
-    return sh
+    return weightnorm_param_shapes(cfg, sh)
+
+
+def weightnorm_param_shapes(cfg, sh):
+    """modules.py:152-166: every wrapped convolution gets g [kernel.shape[-1]] next to its kernel (= v)."""
+    if not cfg.wavenet_weight_normalization:
+        return sh
+    out = OrderedDict()
+    for k, v in sh.items():
+        out[k] = v
+        if k.endswith('/kernel'):
+            out[k[:-6] + 'g'] = (v[-1],)
+    return out
+
+
+def effective_params(params, cfg):
+    """kernel = l2_normalize(v, all axes but the last) * g   (WeightNorm._compute_weights, modules.py:98-103)."""
+    if not cfg.wavenet_weight_normalization or not any(k.endswith('/g') for k in params):
+        return params                                     # (already effective)
+    out = OrderedDict()
+    for k, v in params.items():
+        if k.endswith('/g'):
+            continue
+        if k.endswith('/kernel'):
+            g = params[k[:-6] + 'g']
+            axes = tuple(range(v.dim() - 1))
+            v = v * torch.rsqrt(torch.clamp((v * v).sum(dim=axes, keepdim=True), min=1e-12)) * g
+        out[k] = v
+    return out
 
 
 def _nn_init_kernel(cfg, i, s):
@@ -198,6 +227,8 @@ def init_params(cfg: OracleConfig, seed=5339, bias_scale=0.0):
     g = torch.Generator().manual_seed(seed)
     params = OrderedDict()
     for name, shape in param_shapes(cfg).items():
+        if name.endswith('/g'):
+            continue                                      # set from the kernels below
         if name.endswith('bias'):
             t = torch.zeros(shape)
             if bias_scale > 0:
@@ -216,6 +247,15 @@ def init_params(cfg: OracleConfig, seed=5339, bias_scale=0.0):
             lim = math.sqrt(6.0 / (fan_in + fan_out))
             t = (torch.rand(shape, generator=g) * 2 - 1) * lim
         params[name] = t.float().contiguous()
+    if cfg.wavenet_weight_normalization:                  # g = ||v|| (modules.py:104-108, 170)
+        ordered = OrderedDict()
+        for name in param_shapes(cfg):
+            if name.endswith('/g'):
+                v = params[name[:-1] + 'kernel']
+                ordered[name] = v.reshape(-1, v.shape[-1]).norm(dim=0)
+            else:
+                ordered[name] = params[name]
+        params = ordered
     return params
 
 
@@ -240,6 +280,7 @@ def _act(cfg, x):
 
 def upsample(params, cfg: OracleConfig, c):
     """c [B, C, Tc] -> [B, C, Tc*hop].  wavenet.py:680-702 / :781-803, modules.py:524-770."""
+    params = effective_params(params, cfg)
     B, C, Tc = c.shape
     t = cfg.upsample_type
     if t == 'NearestNeighbor':                     # modules.py:524-536, wavenet.py:165-167
@@ -300,6 +341,7 @@ def step(params, cfg: OracleConfig, x, c, dropout_masks=None, emulate_bf16=False
       the layer input is x*mask/(1-p) (tf.layers.dropout, modules.py:484); the residual
       path uses the un-dropped x (modules.py:483, 517-520).
     """
+    params = effective_params(params, cfg)
     q = bf16_round if emulate_bf16 else (lambda t: t)
     # HIP path: bf16 MFMA operands for every conv except the (fp32, K=Cin) input conv and the
     # (fp32) upsample kernels
@@ -511,6 +553,7 @@ def incremental(params, cfg: OracleConfig, c, T=None, noise=None, test_inputs=No
       :815-816); 'ring': O(1) ring buffers (what the HIP path does) -- identical results.
     Returns (outputs [B, Cout, T] as :911, raw [B, O, T] as :904-908).
     """
+    params = effective_params(params, cfg)      # (the reference would use the raw v here: SURVEY appendix C-7; fixed)
     B = c.shape[0]
     cu = upsample(params, cfg, c)            # [B,C,Tup]
     if T is None:

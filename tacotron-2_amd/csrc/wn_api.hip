@@ -66,6 +66,22 @@ static void build_layout(wn_ctx* c) {
             c->up_k.push_back(ko); c->up_b.push_back(bo);
         }
     }
+    // ---- exported (raw) layout.  With weight normalisation every convolution kernel gets a gain vector g over its LAST axis
+    // (WeightNorm.build: layer_depth = kernel.shape[-1], modules.py:152-166) right behind it; biases / embedding unchanged.
+    c->n_raw = 0;
+    for (const WnTensor& t : c->tensors) {
+        const bool is_kernel = c->wnorm && t.name.size() > 7 && t.name.compare(t.name.size() - 7, 7, "/kernel") == 0;
+        WnTensor r = t; r.offset = c->n_raw; c->n_raw = align_up(c->n_raw + r.numel, 8);
+        c->raw_tensors.push_back(r);
+        wn_ctx::WnMap m; m.raw_off = r.offset; m.eff_off = t.offset; m.numel = t.numel; m.g_off = -1; m.cout = t.shape[t.ndim - 1]; m.pad = 0;
+        if (is_kernel) {
+            WnTensor g; g.name = t.name.substr(0, t.name.size() - 6) + "g"; g.ndim = 1; g.shape[0] = m.cout; g.shape[1] = g.shape[2] = g.shape[3] = 1;
+            g.numel = m.cout; g.offset = c->n_raw; c->n_raw = align_up(c->n_raw + g.numel, 8);
+            m.g_off = g.offset;
+            c->raw_tensors.push_back(g);
+        }
+        c->wmap.push_back(m);
+    }
     if (!c->lbias) {      // absent layer biases READ from the zero tail behind the ctx-owned parameter copy
         c->zpad = (int)align_up(std::max(std::max(c->G, c->S), c->R), 8);
         for (auto& o : c->lay) { o.dil_b = o.cin_b = o.skip_b = o.out_b = c->n_params; if (c->gin > 0) o.gin_b = c->n_params; }
@@ -161,6 +177,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     c->Cin = (cfg->input_type == WN_INPUT_MULAW_QUANTIZE) ? cfg->quantize_channels : 1;
     c->hop = hop;
     c->lbias = cfg->use_bias != 0;
+    c->wnorm = cfg->weight_normalization != 0;
     c->gin = cfg->gin_channels > 0 ? cfg->gin_channels : 0;
     c->OP = (int)align_up(c->O, 32); c->CP = (int)align_up(c->C, 32);
     const int per = c->L / cfg->stacks;
@@ -203,6 +220,9 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->st2) hipStreamDestroy(c->st2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->wmap_dev) hipFree(c->wmap_dev);
+    if (c->raw_dev) hipFree(c->raw_dev);
+    if (c->deff) hipFree(c->deff);
     if (c->gvec) hipFree(c->gvec);
     if (c->gids) hipFree(c->gids);
     if (c->gbias) hipFree(c->gbias);
@@ -214,11 +234,11 @@ extern "C" void wn_destroy(wn_ctx* c) {
 
 extern "C" const char* wn_last_error(const wn_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 extern "C" int wn_receptive_field(const wn_ctx* c) { int s = 0; for (int d : c->dil) s += d; return 2 * s + 1; }
-extern "C" int64_t wn_param_count(const wn_ctx* c) { return c->n_params; }
-extern "C" int wn_num_tensors(const wn_ctx* c) { return (int)c->tensors.size(); }
+extern "C" int64_t wn_param_count(const wn_ctx* c) { return c->n_raw; }
+extern "C" int wn_num_tensors(const wn_ctx* c) { return (int)c->raw_tensors.size(); }
 extern "C" int wn_tensor_info(const wn_ctx* c, int i, char* name, int32_t* shape, int32_t* ndim, int64_t* offset) {
-    if (!c || i < 0 || i >= (int)c->tensors.size()) return WN_E_ARG;
-    const WnTensor& t = c->tensors[i];
+    if (!c || i < 0 || i >= (int)c->raw_tensors.size()) return WN_E_ARG;
+    const WnTensor& t = c->raw_tensors[i];
     if (name) { strncpy(name, t.name.c_str(), 127); name[127] = 0; }
     if (shape) for (int k = 0; k < 4; ++k) shape[k] = t.shape[k];
     if (ndim) *ndim = t.ndim;

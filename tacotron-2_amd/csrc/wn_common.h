@@ -85,7 +85,12 @@ struct wn_ctx {
     std::vector<float> skip_scale;        // c_l of the legacy skip recursion (wavenet.py:706-715)
     float res_scale;                      // sqrt(.5) if residual_legacy else 1
     std::vector<WnTensor> tensors;
-    int64_t n_params = 0;
+    int64_t n_params = 0;                 // floats of the EFFECTIVE parameter buffer the kernels read (ctx-owned params_dev)
+    // weight normalisation: the caller's flat buffers (params / grads / Adam slots / EMA) use the RAW layout `raw_tensors`
+    // (kernel = v, g, bias, ...); params_dev holds g * v / ||v||.  Without it raw == effective.
+    bool wnorm = false; int64_t n_raw = 0; std::vector<WnTensor> raw_tensors;
+    struct WnMap { int64_t raw_off, eff_off, numel, g_off; int32_t cout, pad; };
+    std::vector<WnMap> wmap; void* wmap_dev = nullptr; float* raw_dev = nullptr; float* deff = nullptr;
     WnLayerOffsets first;                 // dil_k = input kernel, dil_b = input bias
     std::vector<WnLayerOffsets> lay;
     int64_t fin1_k, fin1_b, fin2_k, fin2_b;
@@ -158,6 +163,8 @@ int wn_pipe_synthesize(wn_ctx* ctx, const float* c, int B, int Tc, const float* 
                        void* out_samples, float* out_raw, hipStream_t st);
 extern "C" int wn_noise_per_step(const wn_ctx* c);
 int wn_upsample_fwd(wn_ctx* ctx, const float* params_unused, const float* c, int B, int Tc, hipStream_t st);
+int wn_weightnorm_apply(wn_ctx* ctx, const float* raw_params, hipStream_t st);     // raw (v, g, bias) -> params_dev (effective)
+int wn_weightnorm_grad(wn_ctx* ctx, float* raw_grads, hipStream_t st);             // deff (effective grads) -> raw grads
 int wn_gbias_fwd(wn_ctx* ctx, int B, hipStream_t st);                 // global-conditioning bias table of this batch
 int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st);           // d W_g, d b_g, d embedding
 size_t wn_wgrad_partial_need(wn_ctx* ctx);

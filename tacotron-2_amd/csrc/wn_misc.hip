@@ -129,10 +129,16 @@ int wn_build_packs(wn_ctx* c) {
         WN_HIP(c, hipMalloc((void**)&c->gbias, (size_t)L * c->maxB * G * 4));
         WN_HIP(c, hipMalloc((void**)&c->colsum, (size_t)L * c->maxB * G * 4));
     }
-    const int nt = (int)c->tensors.size();
+    if (c->wnorm) {
+        WN_HIP(c, hipMalloc((void**)&c->raw_dev, (size_t)c->n_raw * 4));
+        WN_HIP(c, hipMalloc((void**)&c->deff, (size_t)c->n_params * 4));
+        WN_HIP(c, hipMalloc((void**)&c->wmap_dev, c->wmap.size() * sizeof(wn_ctx::WnMap)));
+        WN_HIP(c, hipMemcpy(c->wmap_dev, c->wmap.data(), c->wmap.size() * sizeof(wn_ctx::WnMap), hipMemcpyHostToDevice));
+    }
+    const int nt = (int)c->raw_tensors.size();          // per-VARIABLE clipping (wavenet.py:586-598): v and g are separate variables
     std::vector<int32_t> offs(nt + 1);
-    for (int i = 0; i < nt; ++i) offs[i] = (int32_t)c->tensors[i].offset;
-    offs[nt] = (int32_t)c->n_params;
+    for (int i = 0; i < nt; ++i) offs[i] = (int32_t)c->raw_tensors[i].offset;
+    offs[nt] = (int32_t)c->n_raw;
     WN_HIP(c, hipMalloc((void**)&c->tensor_offsets_dev, (nt + 1) * 4));
     WN_HIP(c, hipMemcpy(c->tensor_offsets_dev, offs.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
     WN_HIP(c, hipMalloc((void**)&c->norm2_dev, nt * 4));
@@ -147,7 +153,8 @@ static void add_pack_job(wn_ctx* c, std::vector<PackJob>& jobs, int& nblocks, co
 }
 
 int wn_launch_pack(wn_ctx* c, const float* params, hipStream_t st) {
-    WN_HIP(c, hipMemcpyAsync(c->params_dev, params, (size_t)c->n_params * 4, hipMemcpyDeviceToDevice, st));
+    if (c->wnorm) { int rcw = wn_weightnorm_apply(c, params, st); if (rcw) return rcw; }
+    else WN_HIP(c, hipMemcpyAsync(c->params_dev, params, (size_t)c->n_params * 4, hipMemcpyDeviceToDevice, st));
     if (!c->pack_jobs_dev) {          // job table: built once (pack buffers never move)
         std::vector<PackJob> jobs; int nblocks = 0;
         for (int l = 0; l < c->L; ++l) {
@@ -582,6 +589,59 @@ int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t 
     return WN_OK;
 }
 
+// =================================================================================== weight normalisation
+// modules.py:44-177 (WeightNorm): kernel = tf.nn.l2_normalize(v, axes all but the last) * g  (:98-103).  One thread per
+// (tensor, output channel) walks the K = numel / cout elements of its column (coalesced across the channels of a wave).
+__global__ void wn_weightnorm_apply_kernel(const float* __restrict__ raw, float* __restrict__ eff, const wn_ctx::WnMap* __restrict__ map, int nt) {
+    const wn_ctx::WnMap m = map[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m.g_off < 0) {                                   // not a normalised kernel: plain copy
+        for (int64_t i = c; i < m.numel; i += (int64_t)gridDim.x * blockDim.x) eff[m.eff_off + i] = raw[m.raw_off + i];
+        return;
+    }
+    for (int ch = c; ch < m.cout; ch += gridDim.x * blockDim.x) {
+        const int64_t K = m.numel / m.cout;
+        float ss = 0.0f;
+        for (int64_t k = 0; k < K; ++k) { const float v = raw[m.raw_off + k * m.cout + ch]; ss += v * v; }
+        const float sc = raw[m.g_off + ch] * rsqrtf(fmaxf(ss, 1e-12f));      // tf.nn.l2_normalize: x * rsqrt(max(sum(x^2), eps))
+        for (int64_t k = 0; k < K; ++k) eff[m.eff_off + k * m.cout + ch] = raw[m.raw_off + k * m.cout + ch] * sc;
+    }
+}
+// d g = sum_k dW v / ||v||;   d v = g / ||v|| * (dW - v * (sum_k dW v) / ||v||^2)
+__global__ void wn_weightnorm_grad_kernel(const float* __restrict__ raw, const float* __restrict__ deff, float* __restrict__ draw,
+                                          const wn_ctx::WnMap* __restrict__ map, int nt) {
+    const wn_ctx::WnMap m = map[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m.g_off < 0) {
+        for (int64_t i = c; i < m.numel; i += (int64_t)gridDim.x * blockDim.x) draw[m.raw_off + i] = deff[m.eff_off + i];
+        return;
+    }
+    for (int ch = c; ch < m.cout; ch += gridDim.x * blockDim.x) {
+        const int64_t K = m.numel / m.cout;
+        float ss = 0.0f, dot = 0.0f;
+        for (int64_t k = 0; k < K; ++k) { const float v = raw[m.raw_off + k * m.cout + ch]; ss += v * v; dot += deff[m.eff_off + k * m.cout + ch] * v; }
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f)), g = raw[m.g_off + ch];
+        draw[m.g_off + ch] = dot * inv;
+        const float a = g * inv, b = dot * inv * inv;
+        for (int64_t k = 0; k < K; ++k) draw[m.raw_off + k * m.cout + ch] = a * (deff[m.eff_off + k * m.cout + ch] - raw[m.raw_off + k * m.cout + ch] * b);
+    }
+}
+int wn_weightnorm_apply(wn_ctx* c, const float* raw_params, hipStream_t st) {
+    // keep the raw parameters for the backward (caller pointers are borrowed for the call only)
+    WN_HIP(c, hipMemcpyAsync(c->raw_dev, raw_params, (size_t)c->n_raw * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(wn_weightnorm_apply_kernel, dim3(4, (unsigned)c->wmap.size()), dim3(256), 0, st, c->raw_dev, c->params_dev,
+                       (const wn_ctx::WnMap*)c->wmap_dev, (int)c->wmap.size());
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+int wn_weightnorm_grad(wn_ctx* c, float* raw_grads, hipStream_t st) {
+    WN_HIP(c, hipMemsetAsync(raw_grads, 0, (size_t)c->n_raw * 4, st));        // alignment gaps
+    hipLaunchKernelGGL(wn_weightnorm_grad_kernel, dim3(4, (unsigned)c->wmap.size()), dim3(256), 0, st, c->raw_dev, c->deff, raw_grads,
+                       (const wn_ctx::WnMap*)c->wmap_dev, (int)c->wmap.size());
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
 // =================================================================================== global conditioning
 // wavenet.py:669-678 (embedding lookup + broadcast over time), modules.py:499-508 (z += W_g^T g + b_g).  g is constant over
 // time, so its contribution is a per-utterance bias of the gate pre-activation: gbias[l][b][:] = b1sum[l] + W_g[l]^T g_b + b_g[l].
@@ -967,8 +1027,8 @@ __global__ void wn_adam_kernel(float* __restrict__ p, const float* __restrict__ 
 
 int wn_optim_impl(wn_ctx* c, float* p, const float* g, float* m, float* v, float* ema, float lr, int64_t step, hipStream_t st) {
     const wn_config& h = c->cfg;
-    const int nt = (int)c->tensors.size();
-    const int64_t n = c->n_params;
+    const int nt = (int)c->raw_tensors.size();
+    const int64_t n = c->n_raw;
     if (h.clip_gradients) {
         WN_HIP(c, hipMemsetAsync(c->norm2_dev, 0, nt * 4, st));
         hipLaunchKernelGGL(wn_norm2_kernel, dim3(cdiv(cdiv(n, WN_NORM_SPAN), 4)), dim3(256), 0, st, g, c->tensor_offsets_dev, nt, n, c->norm2_dev);

@@ -275,7 +275,15 @@ static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st) {
     return WN_OK;
 }
 
+static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st);
 int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
+    if (!c->wnorm) return wn_bwd_eff(c, grads, st);
+    // weight normalisation: gradients w.r.t. the effective kernels go to a ctx-owned buffer, then d v / d g (modules.py:98-103)
+    int rc = wn_bwd_eff(c, c->deff, st);
+    if (rc) return rc;
+    return wn_weightnorm_grad(c, grads, st);
+}
+static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     if (!c->have_loss) WN_FAIL(c, WN_E_STATE, "wn_train_bwd needs a forward that computed the loss (loss_out != NULL)");
     const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C, O = c->O;
     const int64_t NT = c->NT;

@@ -42,7 +42,7 @@ class WnConfig(ctypes.Structure):
         ('adam_epsilon', ctypes.c_float), ('ema_decay', ctypes.c_float),
         ('max_batch', ctypes.c_int32), ('max_time', ctypes.c_int32),
         ('gin_channels', ctypes.c_int32), ('use_speaker_embedding', ctypes.c_int32), ('n_speakers', ctypes.c_int32),
-        ('reserved0', ctypes.c_int32),
+        ('weight_normalization', ctypes.c_int32),
     ]
 
 
@@ -151,6 +151,7 @@ def config_from_hparams(hp, max_batch, max_time):
     cfg.gin_channels = int(getattr(hp, 'gin_channels', -1))                       # hparams.py:228-230
     cfg.use_speaker_embedding = int(bool(getattr(hp, 'use_speaker_embedding', True))) if cfg.gin_channels > 0 else 0
     cfg.n_speakers = int(getattr(hp, 'n_speakers', 0) or 0)
+    cfg.weight_normalization = int(bool(getattr(hp, 'wavenet_weight_normalization', False)))      # hparams.py:323
     return cfg
 
 

@@ -65,7 +65,7 @@ def initialize_parameters(hparams, layout, seed=None):
     n_up = len(hparams.upsample_scales)
     for name, (shape, off) in layout.items():
         n = int(np.prod(shape))
-        if name.endswith('/bias'):
+        if name.endswith('/bias') or name.endswith('/g'):
             continue
         if name == 'gc_embedding':                           # tf.truncated_normal_initializer(0, 0.1) (reference modules.py:13-17)
             t = torch.fmod(torch.randn(shape, generator=gen), 2.0) * 0.1
@@ -81,4 +81,11 @@ def initialize_parameters(hparams, layout, seed=None):
         else:
             t = _glorot_uniform(shape, gen)
         flat[off:off + n] = t.reshape(-1)
+    # weight normalisation gains: g = ||v|| over all axes but the last, so that g * v / ||v|| == v at the start
+    # (WeightNorm.build assigns _init_norm(v) to g: reference modules.py:104-108, 161-171)
+    for name, (shape, off) in layout.items():
+        if name.endswith('/g'):
+            kshape, koff = layout[name[:-1] + 'kernel']
+            v = flat[koff:koff + int(np.prod(kshape))].reshape(-1, kshape[-1])
+            flat[off:off + shape[0]] = v.norm(dim=0)
     return flat

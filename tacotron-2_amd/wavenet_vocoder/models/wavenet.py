@@ -29,8 +29,6 @@ class WaveNet(object):
         assert hparams.layers % hparams.stacks == 0
         if hparams.gin_channels > 0 and hparams.use_speaker_embedding:
             assert hparams.n_speakers is not None                                    # wavenet.py:154
-        if hparams.wavenet_weight_normalization:
-            raise NotImplementedError('wavenet_weight_normalization=True is not built in this tree yet')
         self.scalar_input = is_scalar_input(hparams.input_type)
         self.receptive_field = receptive_field_size(hparams.layers, hparams.stacks, hparams.kernel_size)
         self.embed_speakers = 'gc_embedding' if (hparams.gin_channels > 0 and hparams.use_speaker_embedding) else None

@@ -60,6 +60,11 @@ CONFIGS = {
                                  log_scale_min_gauss=float(np.log(1e-7))),
     'paper_width_gin': dict(residual_channels=256, gate_channels=512, skip_out_channels=256, cin_channels=80, num_mels=80,
                             layers=4, stacks=2, gin_channels=16, use_speaker_embedding=True, n_speakers=3),
+    # Salimans & Kingma weight normalisation of every convolution (hparams.py:323): v, g are the trained variables
+    'mol_weightnorm': dict(wavenet_weight_normalization=True, wavenet_dropout=0.05),
+    'gauss_weightnorm_gin_nobias': dict(wavenet_weight_normalization=True, out_channels=2, use_bias=False, gin_channels=8,
+                                        use_speaker_embedding=True, n_speakers=3, upsample_type='SubPixel',
+                                        log_scale_min_gauss=float(np.log(1e-7))),
     'softmax_c1': dict(input_type='mulaw-quantize', out_channels=256, quantize_channels=256, layers=8, stacks=1,
                        upsample_activation='LeakyRelu'),
     'wide': dict(residual_channels=128, gate_channels=256, skip_out_channels=128, cin_channels=80, num_mels=80,
@@ -86,6 +91,9 @@ def _run_fwd(name, B=2, T=400, lengths=None, with_bwd=False):
     for k in params:
         if k.startswith('local_conditioning') and k.endswith('kernel'):
             params[k] = params[k] + 0.05 * torch.randn(params[k].shape, generator=g)
+    for k in params:
+        if k.endswith('/g'):          # gains start at ||v|| (kernel == v): move them so that the normalisation is exercised
+            params[k] = params[k] * (torch.rand(params[k].shape, generator=g) * 0.8 + 0.6)
     flat = upload_params(eng, params)
     eng.pack_weights(flat)
     x_dev, y_dev, x_or, y_or, c = _inputs(cfg, hp, B, T)
@@ -167,7 +175,8 @@ def test_train_backward(name):
     for k in g_or:
         n_or = float(g_or[k].norm())
         err = float((g_dev[k] - g_or[k]).norm())
-        worst.append((err / (n_or + 1e-12) if n_or > 1e-9 else err, k, n_or))
+        # (tensors whose true gradient vanishes -- e.g. v of a 1-element-per-channel weight-normalised kernel -- compare absolutely)
+        worst.append((err / (n_or + 1e-12) if n_or > 1e-6 else err, k, n_or))
     worst.sort(reverse=True)
     print('\n[%s] worst gradient errors:' % name)
     for e, k, n in worst[:12]:

@@ -19,7 +19,7 @@ GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 DEFAULTS = dict(layers=4, stacks=2, kernel_size=3, gin_channels=-1, use_speaker_embedding=True, n_speakers=3, input_type='raw',
                 quantize_channels=65536, use_bias=True, legacy=False, residual_legacy=False, wavenet_dropout=0.0, upsample_type='2D',
                 upsample_activation='Relu', leaky_alpha=0.4, freq_axis_kernel_size=3, NN_init=True, NN_scaler=0.3,
-                log_scale_min=float(np.log(1e-14)), log_scale_min_gauss=float(np.log(1e-7)), cdf_loss=False)
+                log_scale_min=float(np.log(1e-14)), log_scale_min_gauss=float(np.log(1e-7)), cdf_loss=False, wavenet_weight_normalization=False)
 
 
 def _load(path):

@@ -70,7 +70,7 @@ _STACK_DEFAULTS = dict(layers=4, stacks=2, residual_channels=16, gate_channels=3
                        cin_channels=8, gin_channels=-1, use_speaker_embedding=True, n_speakers=3, input_type='raw', quantize_channels=65536,
                        use_bias=True, legacy=False, residual_legacy=False, wavenet_dropout=0.0, upsample_type='2D', upsample_scales=[2, 3],
                        upsample_activation='Relu', leaky_alpha=0.4, freq_axis_kernel_size=3, NN_init=True, NN_scaler=0.3,
-                       log_scale_min=float(np.log(1e-14)), log_scale_min_gauss=float(np.log(1e-7)), cdf_loss=False)
+                       log_scale_min=float(np.log(1e-14)), log_scale_min_gauss=float(np.log(1e-7)), cdf_loss=False, wavenet_weight_normalization=False)
 _STACK_FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stack_*.npz')))
 
 
@@ -83,7 +83,7 @@ def _load_stack(path):
 
 
 def test_reference_executed_goldens_exist():
-    assert len(_STACK_FILES) >= 11, 'run oracle/gen_golden_stack.py in the container that has /root/reference'
+    assert len(_STACK_FILES) >= 18, 'run oracle/gen_golden_stack.py in the container that has /root/reference'
 
 
 @pytest.mark.parametrize('path', _STACK_FILES, ids=[os.path.basename(p)[6:-4] for p in _STACK_FILES])
