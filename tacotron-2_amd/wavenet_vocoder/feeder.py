@@ -199,9 +199,9 @@ def _limit_time(batch, hparams, rng):
     out = []
     for x, c, g, l in batch:
         max_steps = max_time_steps - max_time_steps % hop
-        if len(x) > max_steps:
+        if len(x) > max_time_steps:          # (the reference compares with max_time_steps and draws start in [0, frames - max_frames), feeder.py:376-380)
             max_frames = max_steps // hop
-            s = int(rng.randint(0, len(c) - max_frames + 1))
+            s = int(rng.randint(0, len(c) - max_frames))
             c = c[s:s + max_frames]
             x = x[s * hop:(s + max_frames) * hop]
         assert len(x) == len(c) * hop

@@ -190,3 +190,56 @@ def test_data_parallel_gradient_mean_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and 'rank ok' in o, o[-2000:]
+
+
+def test_host_formats_match_reference_execution(golden_dir, tmp_path):
+    """Batch assembly, learning-rate schedules, wav writer and hop size against golden vectors produced by executing the
+    reference's own feeder.py / wavenet.py / datasets/audio.py (oracle/gen_golden_host.py)."""
+    import hparams as H
+    from wavenet_vocoder import _ext
+    from wavenet_vocoder.feeder import Feeder, _limit_time
+    from datasets import audio
+    g = np.load(os.path.join(golden_dir, 'host_golden.npz'))
+    for tag, itype in (('raw', 'raw'), ('mulawq', 'mulaw-quantize')):
+        hp = H._build()
+        hp.parse('hop_size=16,num_mels=8,cin_channels=8,upsample_scales=[4,4],max_time_steps=4096,gin_channels=4,input_type=%s,quantize_channels=256' % itype)
+        fd = object.__new__(Feeder)
+        fd._hparams = hp; fd.local_condition = True; fd.global_condition = True; fd._rng = np.random.RandomState(5)
+        fd._spec_pad = -hp.max_abs_value if hp.symmetric_mels else 0.
+        ex = [(g['%s_ex%d_x' % (tag, i)], g['%s_ex%d_c' % (tag, i)], str(int(g['%s_ex%d_g' % (tag, i)])), len(g['%s_ex%d_x' % (tag, i)])) for i in range(4)]
+        inputs, targets, lengths, c, gb = fd._prepare_batch(ex)
+        order = np.argsort(lengths)
+        inputs, targets, lengths, c, gb = inputs[order], targets[order], lengths[order], c[order], gb[order]
+        assert np.array_equal(lengths, g[tag + '_lengths']) and lengths.dtype == np.int32
+        np.testing.assert_allclose(c, g[tag + '_c'], rtol=0, atol=1e-7)              # clip -> pad with range min -> [0,1] -> [B, mels, Tc]
+        assert np.array_equal(gb, g[tag + '_g']) and gb.dtype == np.int32 and gb.shape == (4, 1)
+        if itype == 'raw':
+            assert np.array_equal(inputs, g[tag + '_inputs']) and np.array_equal(targets, g[tag + '_targets'])
+        else:
+            # the reference feeds one-hot [B, Q, T] (all-zero columns in the padding); the device boundary takes the class ids
+            ref_ids = g[tag + '_inputs'].argmax(axis=1)
+            for b, n in enumerate(lengths):
+                assert np.array_equal(inputs[b, :n], ref_ids[b, :n]) and np.array_equal(targets[b, :n], g[tag + '_targets'][b, :n, 0])
+                assert not g[tag + '_inputs'][b, :, n:].any()
+    # hop-aligned random crop (feeder.py:368-387): same lengths, same range of start frames
+    hp = H._build(); hp.parse('hop_size=16,num_mels=8,cin_channels=8,upsample_scales=[4,4],max_time_steps=100')
+    rng = np.random.RandomState(0)
+    x = np.arange(20 * 16, dtype=np.float32); cc = np.repeat(np.arange(20, dtype=np.float32)[:, None], 8, axis=1)
+    starts = set()
+    for _ in range(400):
+        (xo, co, _, ln), = _limit_time([(x, cc, None, len(x))], hp, rng)
+        assert len(xo) == int(g['crop_x_len'][0]) and len(co) == int(g['crop_c_len'][0]) and xo[0] == co[0, 0] * 16
+        starts.add(int(co[0, 0]))
+    assert min(starts) == int(g['crop_start_min']) and max(starts) == int(g['crop_start_max'])
+    # learning-rate schedules (wavenet.py:615-629)
+    for s, a, b in zip(g['lr_steps'], g['lr_noam'], g['lr_exp']):
+        assert abs(_ext.learning_rate('noam', 1e-3, int(s), 0.5, 200000, 4000.0) - a) <= 1e-6 * a
+        assert abs(_ext.learning_rate('exponential', 1e-3, int(s), 0.5, 200000, 4000.0) - b) <= 1e-6 * b
+    # wav writer (datasets/audio.py:17-20): peak-normalised int16, inverse pre-emphasis NOT applied
+    p = os.path.join(str(tmp_path), 'w.wav')
+    audio.save_wavenet_wav(g['wav_in'].copy(), p, sr=22050, inv_preemphasize=True, k=0.97)
+    from scipy.io import wavfile
+    sr, data = wavfile.read(p)
+    assert sr == int(g['wav_sr']) and np.array_equal(data, g['wav_int16'])
+    hp2 = H._build(); hp2.hop_size = None; hp2.frame_shift_ms = 12.5
+    assert audio.get_hop_size(hp2) == int(g['hop_from_ms'])

@@ -53,12 +53,28 @@ int main() {
         for (int l = 0; l < L; ++l) for (int p = 0; p < parts; ++p) { hipStream_t st = (p & 1) ? s1 : s0; gate(l, p * nb, nb, st); outc(l, p * nb, nb, st); }
         CK(hipEventRecord(ef, s1)); CK(hipStreamWaitEvent(s0, ef, 0));
     };
+    hipEvent_t es; CK(hipEventCreateWithFlags(&es, hipEventDisableTiming));
+    // interleaved enqueue, part 1 held back until part 0's first gate GEMM has finished: gate(p0) | out(p1) from then on
+    auto run_stagger = [&]() {
+        CK(hipEventRecord(ef, s0)); CK(hipStreamWaitEvent(s1, ef, 0));
+        const int nb = B / 2;
+        for (int l = 0; l < L; ++l) {
+            gate(l, 0, nb, s0);
+            if (l == 0) { CK(hipEventRecord(es, s0)); CK(hipStreamWaitEvent(s1, es, 0)); }
+            outc(l, 0, nb, s0);
+            gate(l, nb, nb, s1); outc(l, nb, nb, s1);
+        }
+        CK(hipEventRecord(ef, s1)); CK(hipStreamWaitEvent(s0, ef, 0));
+    };
     for (int rep = 0; rep < 3; ++rep) {
         float ms;
         run_seq(); CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, s0)); for (int i = 0; i < 3; ++i) run_seq(); CK(hipEventRecord(e1, s0)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); printf("one stream, full batch      : %8.1f us per layer (gate+out)\n", ms * 1e3 / 3 / L);
-        for (int parts : {2, 4}) {
+        run_stagger(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, s0)); for (int i = 0; i < 3; ++i) run_stagger(); CK(hipEventRecord(e1, s0)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); printf("two streams, 2 parts, staggered by one gate GEMM: %8.1f us per layer\n", ms * 1e3 / 3 / L);
+        for (int parts : {2}) {
             run_split(parts); CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, s0)); for (int i = 0; i < 3; ++i) run_split(parts); CK(hipEventRecord(e1, s0)); CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1)); printf("two streams, %d batch parts  : %8.1f us per layer (gate+out)\n", parts, ms * 1e3 / 3 / L);
