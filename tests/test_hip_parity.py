@@ -288,3 +288,41 @@ def test_error_paths():
     with pytest.raises(_ext.WnError) as ei:          # Tc*hop != T  (wavenet.py:699)
         eng.train_fwd(x, torch.zeros(2, 16, 3, device='cuda'), y, ln, 0, loss)
     assert ei.value.code == -2
+
+
+def test_training_reduces_loss_and_tracks_oracle_trajectory():
+    """Several full steps (fwd + bwd + clip + TF-Adam + EMA + re-pack) on one batch: the device loss trajectory follows the
+    oracle's train_step (fp32, same dropout masks) and the loss goes down."""
+    kw = dict(SMALL); kw.update(wavenet_dropout=0.05, wavenet_learning_rate=1e-3)
+    hp = make_hp(**kw)
+    cfg = oracle_cfg(hp)
+    B, T = 2, 320
+    eng = _engine(hp, B, T)
+    params = O.init_params(cfg, seed=5339, bias_scale=0.0)
+    flat = upload_params(eng, params)
+    x_dev, y_dev, x_or, y_or, c = _inputs(cfg, hp, B, T)
+    ln = torch.full((B,), T, dtype=torch.int32, device='cuda')
+    m = torch.zeros_like(flat); v = torch.zeros_like(flat); ema = flat.clone(); grads = torch.empty_like(flat)
+    loss = torch.zeros(1, device='cuda')
+    state = O.init_opt_state(params)
+    dev_losses, or_losses = [], []
+    n_steps = 12
+    for step in range(n_steps):
+        seed = 100 + step
+        eng.pack_weights(flat)
+        eng.train_fwd(x_dev, c.cuda(), y_dev, ln, seed, loss)
+        eng.train_bwd(grads)
+        lr = float(O.learning_rate(step, init_lr=1e-3))
+        eng.optim_step(flat, grads, m, v, ema, lr, step)
+        dev_losses.append(float(loss.item()))
+        masks = oracle_masks(seed, cfg, B, T)
+        l, _, params, state = O.train_step(params, state, cfg, x_or, c, y_or, [T] * B, step, dropout_masks=masks)
+        or_losses.append(float(l))
+    print('\ndevice losses', ['%.4f' % l for l in dev_losses]); print('oracle losses', ['%.4f' % l for l in or_losses])
+    assert dev_losses[-1] < dev_losses[0] - 0.05 and or_losses[-1] < or_losses[0] - 0.05
+    for a, b in zip(dev_losses, or_losses):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b))                   # bf16 path vs fp32 oracle, compounding over the steps
+    # parameters after 12 updates stay close to the oracle's
+    p_or = torch.cat([params[k].reshape(-1) for k in eng.layout])
+    p_dev = torch.cat([flat.cpu()[off:off + int(np.prod(shape))] for _, (shape, off) in eng.layout.items()])
+    assert rel_err(p_dev, p_or) < 2e-2
