@@ -63,6 +63,10 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('libwavenet_mi355.so not found at %s -- the HIP extension is the only compute '
                            'path of this package; build it with `python tacotron-2_amd/csrc/build.py`' % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64: it must be the HIP runtime of the process (device memory and streams come from
+    # torch), so import torch BEFORE the library is dlopen'ed -- loaded the other way round, /opt/rocm's runtime is mapped first
+    # and the second runtime finds "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
     sigs = {
