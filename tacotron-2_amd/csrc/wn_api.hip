@@ -217,7 +217,7 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->tensor_offsets_dev) hipFree(c->tensor_offsets_dev);
     if (c->norm2_dev) hipFree(c->norm2_dev);
     if (c->params_dev) hipFree(c->params_dev);
-    if (c->st2) hipStreamDestroy(c->st2);
+    if (c->st2) { (void)hipStreamSynchronize(c->st2); hipStreamDestroy(c->st2); }      // nothing of ours may still be running on it
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->wmap_dev) hipFree(c->wmap_dev);
