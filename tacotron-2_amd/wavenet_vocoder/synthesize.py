@@ -52,7 +52,7 @@ def run_synthesis(args, checkpoint_path, output_dir, hparams):
 def wavenet_synthesize(args, hparams, checkpoint):
     output_dir = 'wavenet_' + args.output_dir
     checkpoint_path = get_checkpoint_state(checkpoint)
-    if checkpoint_path is None or not os.path.exists(checkpoint_path):
+    if checkpoint_path is None or not (os.path.exists(checkpoint_path) or os.path.exists(checkpoint_path + '.index')):
         raise RuntimeError('Failed to load checkpoint at {}'.format(checkpoint))
     log('loaded model at {}'.format(checkpoint_path))
     run_synthesis(args, checkpoint_path, output_dir, hparams)

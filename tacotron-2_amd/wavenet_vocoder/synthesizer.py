@@ -27,9 +27,14 @@ class Synthesizer(object):
         self.synth_debug = bool(hparams.wavenet_synth_debug)
         self.model = create_model(model_name, hparams)
         self._state = None
+        self._tf_prefix = None
         if checkpoint_path is not None:
             log('Loading checkpoint: {}'.format(checkpoint_path))
-            self._state = torch.load(checkpoint_path, map_location='cpu')
+            if os.path.exists(checkpoint_path + '.index'):
+                # a checkpoint written by the reference (TensorFlow tensor bundle): read by name once the layout is known
+                self._tf_prefix = checkpoint_path
+            else:
+                self._state = torch.load(checkpoint_path, map_location='cpu')
         self._capacity = (0, 0)
 
     def _ensure_capacity(self, batch, time_steps):
@@ -40,6 +45,14 @@ class Synthesizer(object):
             self.model.engine = None
         cap = (max(batch, self._capacity[0]), max(time_steps, self._capacity[1]))
         self.model.build(cap[0], cap[1])
+        if self._tf_prefix is not None:
+            from wavenet_vocoder.tf_checkpoint import load_reference_checkpoint
+            flat, step, missing = load_reference_checkpoint(self._tf_prefix, self.model.engine.layout)
+            if missing:
+                raise RuntimeError('TensorFlow checkpoint {} lacks {} of the model\'s tensors, e.g. {}'.format(self._tf_prefix, len(missing), missing[:3]))
+            p = torch.from_numpy(flat)
+            self._state = {'params': p, 'ema': p.clone(), 'adam_m': torch.zeros_like(p), 'adam_v': torch.zeros_like(p), 'global_step': step or 0}
+            self._tf_prefix = None
         if self._state is not None:
             self.model.load_state_dict(self._state)
             self.model.use_ema_weights() if getattr(self._hparams, 'mi355_synthesize_with_ema', False) else None

@@ -103,7 +103,14 @@ def get_checkpoint_state(save_dir):
     if not os.path.exists(index):
         return None
     with open(index) as f:
-        name = json.load(f).get('model_checkpoint_path')
+        text = f.read()
+    try:
+        name = json.loads(text).get('model_checkpoint_path')
+    except ValueError:
+        # the reference's (TensorFlow) index file: text proto `model_checkpoint_path: "wavenet_model.ckpt-1000"`
+        import re
+        m = re.search(r'^model_checkpoint_path:\s*"([^"]+)"', text, re.M)
+        name = m.group(1) if m else None
     return os.path.join(save_dir, name) if name else None
 
 

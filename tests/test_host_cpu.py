@@ -243,3 +243,63 @@ def test_host_formats_match_reference_execution(golden_dir, tmp_path):
     assert sr == int(g['wav_sr']) and np.array_equal(data, g['wav_int16'])
     hp2 = H._build(); hp2.hop_size = None; hp2.frame_shift_ms = 12.5
     assert audio.get_hop_size(hp2) == int(g['hop_from_ms'])
+
+
+def test_tf_checkpoint_bundle_reader_round_trip(tmp_path):
+    """TF-1 tensor-bundle reader: LevelDB-table index with prefix-compressed keys over several blocks, raw data
+    shard, reference variable names (EMA shadows, enclosing scopes) -> engine tensor names."""
+    from wavenet_vocoder import tf_checkpoint as C
+    rng = np.random.RandomState(0)
+    scope = 'WaveNet_model/inference/'
+    ema = '/ExponentialMovingAverage'
+    tensors, expect = {}, {}
+    for l in range(3):
+        for kind, shape in (('causal', (3, 8, 16)), ('cin', (1, 4, 16)), ('skip', (1, 8, 8)), ('out', (1, 8, 8))):
+            for leaf, shp in (('kernel', shape), ('bias', (shape[-1],))):
+                name = '%sResidualConv1DGLU_%d/residual_block_%s_conv_ResidualConv1DGLU_%d/%s%s' % (scope, l, kind, l, leaf, ema)
+                tensors[name] = rng.randn(*shp).astype(np.float32)
+                expect['ResidualConv1DGLU_%d/residual_block_%s_conv/%s' % (l, kind, leaf)] = tensors[name]
+    for nm, shp in (('input_convolution/input_convolution/kernel', (1, 1, 8)), ('input_convolution/input_convolution/bias', (8,)),
+                    ('skip_convolutions/final_convolution_1/kernel', (1, 8, 8)), ('skip_convolutions/final_convolution_2/bias', (6,)),
+                    ('local_conditioning_upsampling_1/ConvTranspose2D_layer_0/kernel', (3, 4, 1, 1)),
+                    ('local_conditioning_upsampling_2/ConvTranspose2D_layer_1/bias', (1,))):
+        tensors[scope + nm + ema] = rng.randn(*shp).astype(np.float32)
+    expect.update({'input_convolution/kernel': tensors[scope + 'input_convolution/input_convolution/kernel' + ema],
+                   'input_convolution/bias': tensors[scope + 'input_convolution/input_convolution/bias' + ema],
+                   'final_convolution_1/kernel': tensors[scope + 'skip_convolutions/final_convolution_1/kernel' + ema],
+                   'final_convolution_2/bias': tensors[scope + 'skip_convolutions/final_convolution_2/bias' + ema],
+                   'local_conditioning_upsampling_1/kernel': tensors[scope + 'local_conditioning_upsampling_1/ConvTranspose2D_layer_0/kernel' + ema],
+                   'local_conditioning_upsampling_2/bias': tensors[scope + 'local_conditioning_upsampling_2/ConvTranspose2D_layer_1/bias' + ema]})
+    tensors['global_step'] = np.array(123456, dtype=np.int64)
+    tensors['WaveNet_model/beta1_power'] = np.array(0.5, dtype=np.float32)          # optimiser junk: ignored by the name map
+    prefix = os.path.join(str(tmp_path), 'wavenet_model.ckpt-123456')
+    C.write_bundle(prefix, tensors, entries_per_block=5)
+    header, entries = C.read_index(prefix + '.index')
+    assert header['num_shards'] == 1 and set(entries) == set(tensors)
+    back = C.load_checkpoint(prefix)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and np.array_equal(back[k], v), k
+    # into an engine-style layout (name -> (shape, offset))
+    layout, off = {}, 0
+    for k, v in expect.items():
+        layout[k] = (tuple(v.shape), off); off += (v.size + 7) // 8 * 8
+    layout['final_convolution_2/kernel'] = ((1, 8, 6), off)                          # not in the checkpoint: reported as missing
+    flat, step, missing = C.load_reference_checkpoint(prefix, layout)
+    assert step == 123456 and missing == ['final_convolution_2/kernel']
+    for k, v in expect.items():
+        shape, o = layout[k]
+        assert np.array_equal(flat[o:o + v.size].reshape(shape), v), k
+    assert C.crc32c(b'123456789') == 0xe3069283                                        # CRC-32C check value
+    # a file that is not a table is rejected loudly
+    with open(os.path.join(str(tmp_path), 'junk.index'), 'wb') as f:
+        f.write(b'\x00' * 100)
+    with pytest.raises(ValueError):
+        C.read_index(os.path.join(str(tmp_path), 'junk.index'))
+
+
+def test_tf_checkpoint_state_file_is_understood(tmp_path):
+    from wavenet_vocoder.train import get_checkpoint_state
+    d = str(tmp_path)
+    with open(os.path.join(d, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "wavenet_model.ckpt-2000"\nall_model_checkpoint_paths: "wavenet_model.ckpt-1000"\nall_model_checkpoint_paths: "wavenet_model.ckpt-2000"\n')
+    assert get_checkpoint_state(d) == os.path.join(d, 'wavenet_model.ckpt-2000')
