@@ -853,7 +853,11 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             a.stagger = grid >= 1024 ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
             static const int pipe_override = [] { const char* e = getenv("WN_GEMM_PIPE"); return e ? atoi(e) : 1; }();   // A/B switch for measurements (PIPE 2/3 pad the chunk count: slower on the 8- and 16-chunk kernels)
-            if (pipe_override == 2) hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 2>), dim3(grid), dim3(512), 0, st, a);
+            // chunk count of this contraction: PIPE 2 (fragment reads one k-step ahead across chunk boundaries) pads it to a
+            // multiple of the ring depth, so it is only used where that costs nothing (gate 27, dx 48, skip sum L*8 chunks)
+            int nch = 0; for (int sgi = 0; sgi < a.nseg; ++sgi) nch += (a.seg[sgi].nk + 31) / 32; nch *= a.nrep;
+            const bool free_pad = (nch % 3 == 0) && nch >= 24;
+            if (pipe_override == 2 || (pipe_override == 4 && free_pad)) hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 2>), dim3(grid), dim3(512), 0, st, a);
             else if (pipe_override == 3) hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 3>), dim3(grid), dim3(512), 0, st, a);
             else hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
