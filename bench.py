@@ -305,7 +305,7 @@ def main():
             'hbm_roofline_whole_step': {'alg_bytes_per_sample': alg_bytes_per_sample(hp), 'achieved_GBps': alg_bytes_per_sample(hp) * value / world / 1e9,
                                         'peak_GBps': 8000.0, 'frac': alg_bytes_per_sample(hp) * value / world / 8e12},
         }
-        if not args.no_synth:
+        if not args.no_synth and world == 1:      # replicas-only path: measured on one GPU, not while the other ranks wait
             _log('synthesis measurement ...')
             try:
                 res['synthesis'] = measure_synthesis(hp, flat, device)

@@ -303,3 +303,22 @@ def test_tf_checkpoint_state_file_is_understood(tmp_path):
     with open(os.path.join(d, 'checkpoint'), 'w') as f:
         f.write('model_checkpoint_path: "wavenet_model.ckpt-2000"\nall_model_checkpoint_paths: "wavenet_model.ckpt-1000"\nall_model_checkpoint_paths: "wavenet_model.ckpt-2000"\n')
     assert get_checkpoint_state(d) == os.path.join(d, 'wavenet_model.ckpt-2000')
+
+
+def test_static_isa_audit_no_scratch_and_two_workgroups_per_cu():
+    """Regression guard on the compiled gfx950 code objects (no GPU needed): no kernel may spill to scratch, and the
+    production 256x128 tile kernels must stay within the VGPR / LDS budget that lets two 8-wave workgroups share a CU
+    (the overlap of one workgroup's epilogue with the other's main loop relies on it)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('isa_audit', os.path.join(ROOT, 'tools', 'isa_audit.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = mod.audit()
+    assert len(rows) > 40
+    bad = [r['name'] for r in rows if r['scratch'] or r['vspill'] or r['dyn_stack']]      # SGPR spills go to VGPR lanes, not memory
+    assert not bad, 'kernels with scratch / spills: %s' % bad
+    prod = [r for r in rows if r['name'].startswith('wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3,') or r['name'].startswith('wn_wgrad_lds_kernel')]
+    assert len(prod) >= 6
+    for r in prod:
+        assert r['vgpr'] <= 128, (r['name'], r['vgpr'])            # 512 / 128 = 4 waves per SIMD = two 8-wave workgroups per CU
+        assert 2 * r['lds'] <= 160 * 1024, (r['name'], r['lds'])   # two residents in the 160 KB LDS
