@@ -72,8 +72,10 @@ def alg_bytes_per_sample(hp, e=2):
     return 3 * e * (L * (2 * R + C + 2 * S) + cin + O) + 2 * e * L * (G + G // 2)
 
 
-# measured HBM-side traffic of ONE gate-GEMM launch at C2 (B=8, T=11000): 2 x 59.59e3 KiB fetched + 132.0e3 KiB written
-GATE_TRAFFIC_BYTES = (2 * 59.59e3 + 132.0e3) * 1024.0
+# measured HBM-side traffic of the gate-GEMM launches at C2, scaled to B=8 x T=11000 rows: the production half-batch launch (44 000 rows) fetches
+# 2 x 23.16e3 KiB (profiles/r1g_pmc_fetch_tile_order1.md; 2 x 30.13e3 KiB with the interleaved tile order) and writes 66.0e3 KiB
+# (profiles/r1f_pmc_write.md)
+GATE_TRAFFIC_BYTES = 2.0 * (2 * 23.16e3 + 66.0e3) * 1024.0
 
 
 def synthetic_batch(hp, B, T, seed, device):
@@ -292,7 +294,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1> (dilated conv + cond GEMM + gate, fwd)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
                          'traffic': GATE_TRAFFIC_BYTES * rows_launch / (8 * 11000.0) if args.workload == 'c2' and T == 11000 else None,
-                         'traffic_source': 'profiles/r1b_c2_train_pmc_{fetch,write}_size.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC, gfx950 correction)',
+                         'traffic_source': 'profiles/r1g_pmc_fetch_tile_order1.md + r1f_pmc_write.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC in separate passes, gfx950 correction), scaled by rows per launch',
                          'launches_timed': int(prof_n), 'avg_launch_ms': avg_s * 1e3 if prof_n else None,
                          'alg_flops_per_launch': flops_launch, 'alg_bytes_per_launch': float(rows_launch) * (2 * R + 2 * C + 2 * G + G),
                          'rows_per_launch': rows_launch,

@@ -53,6 +53,7 @@ struct GemmArgs {
     const bf16_t* zero;         // >= 16 B of zeros in device memory (source of out-of-range rows for the LDS-DMA kernel)
     unsigned long long* trace;  // harness-only (WN_EPI_ABLATE builds): per-workgroup s_memtime stamps of the main loop
     int32_t stagger;            // shader cycles the second-resident workgroups of the first round wait before starting (0: off)
+    int32_t xcd_span;           // LDS-DMA kernels: > 0 = XCD x owns the contiguous tiles [x * xcd_span, (x + 1) * xcd_span); 0 = tiles interleaved over XCDs
     EpiArgs e;
 };
 
@@ -403,10 +404,14 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
+    // Workgroup ids are dealt round-robin to the 8 XCDs.  The `mblocks` workgroups that share one activation tile get ids
+    // congruent mod 8 (one L2).  With xcd_span > 0 each XCD also walks a CONTIGUOUS run of time tiles, so the rows a
+    // dilated tap reaches back to (<= 2d rows = <= 32 tiles at d = 2048) were fetched by the same XCD a moment ago and are
+    // still in its 4 MB L2 (interleaved order: only taps of d % 1024 == 0 stay on their XCD; the others re-fetch).
     const int id = blockIdx.x;
     const int xcd = id & 7, q = id >> 3;
     const int mblk = q % a.mblocks;
-    const int tile = (q / a.mblocks) * 8 + xcd;
+    const int tile = a.xcd_span > 0 ? xcd * a.xcd_span + q / a.mblocks : (q / a.mblocks) * 8 + xcd;
     if (tile >= a.ntiles) return;
     if (a.stagger > 0 && id < 512) {
         // All tiles cost the same, so co-resident (and neighbouring) workgroups would reach their MFMA-idle, store-heavy
@@ -840,6 +845,12 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     }
 }
 
+// Tile order of the LDS-DMA kernels (A/B switch WN_TILE_ORDER: 1 = contiguous run of tiles per XCD, 0 = interleaved).
+static inline bool wn_tile_order_contiguous() {
+    static const int v = [] { const char* e = getenv("WN_TILE_ORDER"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
 // Host-side launcher: picks the main loop and workgroup shape from M.
 template <int EPI>
 static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st) {
@@ -850,6 +861,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.mblocks = M / 256;
             a.tiles_per_utt = cdiv(a.T, 128);
             a.ntiles = a.tiles_per_utt * a.B;
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             a.stagger = grid >= 1024 ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
             static const int pipe_override = [] { const char* e = getenv("WN_GEMM_PIPE"); return e ? atoi(e) : 1; }();   // A/B switch for measurements (PIPE 2/3 pad the chunk count: slower on the 8- and 16-chunk kernels)
@@ -870,6 +882,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.mblocks = M / 128;
             a.tiles_per_utt = cdiv(a.T, 128);
             a.ntiles = a.tiles_per_utt * a.B;
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             a.stagger = grid >= 1024 ? 8000 : 0;
             hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
@@ -882,6 +895,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.mblocks = 1;
             a.tiles_per_utt = cdiv(a.T, 192);
             a.ntiles = a.tiles_per_utt * a.B;
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * 8;
             hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 3, 3, 2, 32, 3, EPI>), dim3(grid), dim3(384), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
@@ -891,6 +905,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.mblocks = M / 128;
             a.tiles_per_utt = cdiv(a.T, 256);
             a.ntiles = a.tiles_per_utt * a.B;
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 2, 4, 32, 3, EPI>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
