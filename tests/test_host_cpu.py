@@ -322,3 +322,55 @@ def test_static_isa_audit_no_scratch_and_two_workgroups_per_cu():
     for r in prod:
         assert r['vgpr'] <= 128, (r['name'], r['vgpr'])            # 512 / 128 = 4 waves per SIMD = two 8-wave workgroups per CU
         assert 2 * r['lds'] <= 160 * 1024, (r['name'], r['lds'])   # two residents in the 160 KB LDS
+
+
+def test_c_abi_rejects_bad_configurations_before_touching_the_gpu():
+    """wn_create validates the configuration (the constraints the reference asserts, plus the tiling limits of this build) before any
+    HIP call, so status codes and messages can be checked on a box without a GPU.  No exception crosses the C boundary."""
+    import copy
+    import ctypes
+    import hparams as H
+    from wavenet_vocoder import _ext
+    lib = _ext.load_library()
+
+    def create(**over):
+        hp = H._build()
+        for k, v in over.items():
+            setattr(hp, k, v)
+        cfg = config(hp)
+        return call(cfg)
+
+    def config(hp):
+        return _ext.config_from_hparams(hp, 1, 275)
+
+    def call(cfg):
+        h = ctypes.c_void_p()
+        rc = lib.wn_create(ctypes.byref(cfg), ctypes.byref(h))
+        msg = (lib.wn_last_error(None) or b'').decode()
+        if rc == 0:                         # only on a GPU box
+            lib.wn_destroy(h)
+        return rc, msg
+
+    ARG, SHAPE, UNSUP = -1, -2, -4
+    rc, msg = create(layers=24, stacks=5)
+    assert rc == SHAPE and 'multiple of stacks' in msg                      # wavenet.py:97
+    rc, msg = create(out_channels=31)
+    assert rc == SHAPE and 'multiple of 3' in msg                           # mixture.py:30
+    rc, msg = create(input_type='mulaw-quantize', quantize_channels=256, out_channels=30)
+    assert rc == SHAPE and 'quantize' in msg                                # models/__init__.py:6-9
+    rc, msg = create(residual_channels=100)
+    assert rc == UNSUP and 'multiples of 64' in msg
+    rc, msg = create(kernel_size=5)
+    assert rc == UNSUP
+    rc, msg = create(wavenet_dropout=1.0)
+    assert rc == ARG and 'dropout' in msg
+    cfg = config(H._build())
+    cfg.abi_version = 1
+    rc, msg = call(cfg)
+    assert rc == ARG and 'abi_version' in msg
+    assert lib.wn_create(None, None) == ARG
+    # Python-side wrapper turns the status into an exception that carries it
+    hp = H._build(); hp.layers = 7; hp.stacks = 2
+    with pytest.raises(_ext.WnError) as ei:
+        _ext.Engine(hp, 1, 275)
+    assert ei.value.code == SHAPE and 'WN_E_SHAPE' in str(ei.value)
