@@ -233,9 +233,9 @@ extern "C" void wn_destroy(wn_ctx* c) {
 }
 
 extern "C" const char* wn_last_error(const wn_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
-extern "C" int wn_receptive_field(const wn_ctx* c) { int s = 0; for (int d : c->dil) s += d; return 2 * s + 1; }
-extern "C" int64_t wn_param_count(const wn_ctx* c) { return c->n_raw; }
-extern "C" int wn_num_tensors(const wn_ctx* c) { return (int)c->raw_tensors.size(); }
+extern "C" int wn_receptive_field(const wn_ctx* c) { if (!c) return WN_E_ARG; int s = 0; for (int d : c->dil) s += d; return 2 * s + 1; }
+extern "C" int64_t wn_param_count(const wn_ctx* c) { return c ? c->n_raw : (int64_t)WN_E_ARG; }
+extern "C" int wn_num_tensors(const wn_ctx* c) { return c ? (int)c->raw_tensors.size() : WN_E_ARG; }
 extern "C" int wn_tensor_info(const wn_ctx* c, int i, char* name, int32_t* shape, int32_t* ndim, int64_t* offset) {
     if (!c || i < 0 || i >= (int)c->raw_tensors.size()) return WN_E_ARG;
     const WnTensor& t = c->raw_tensors[i];
@@ -245,7 +245,7 @@ extern "C" int wn_tensor_info(const wn_ctx* c, int i, char* name, int32_t* shape
     if (offset) *offset = t.offset;
     return WN_OK;
 }
-extern "C" int64_t wn_workspace_bytes(const wn_ctx* c) { return (int64_t)(c->ws_bytes + c->wg_partial_bytes); }
+extern "C" int64_t wn_workspace_bytes(const wn_ctx* c) { return c ? (int64_t)(c->ws_bytes + c->wg_partial_bytes) : (int64_t)WN_E_ARG; }
 extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, 0, 1>"; }
 
 extern "C" int wn_pack_weights(wn_ctx* c, const float* params, void* stream) {
@@ -328,6 +328,7 @@ extern "C" int wn_synthesize(wn_ctx* c, const float* cc, int32_t B, int32_t Tc, 
 }
 
 extern "C" int wn_noise_per_step(const wn_ctx* c) {
+    if (!c) return WN_E_ARG;
     if (c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE) return c->cfg.quantize_channels;
     if (c->O == 2) return 1;
     return c->O / 3 + 1;

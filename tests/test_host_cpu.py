@@ -369,6 +369,12 @@ def test_c_abi_rejects_bad_configurations_before_touching_the_gpu():
     rc, msg = call(cfg)
     assert rc == ARG and 'abi_version' in msg
     assert lib.wn_create(None, None) == ARG
+    # a null context is an argument error on every entry point, never a crash
+    lib.wn_param_count.restype = ctypes.c_int64
+    assert lib.wn_receptive_field(None) == ARG and lib.wn_param_count(None) == ARG and lib.wn_num_tensors(None) == ARG
+    assert lib.wn_noise_per_step(None) == ARG and lib.wn_set_batch_parts(None, 1) == ARG and lib.wn_profile(None, 1) == ARG
+    assert lib.wn_train_bwd(None, None, None) == ARG and lib.wn_pack_weights(None, None, None) == ARG
+    lib.wn_destroy(None)
     # Python-side wrapper turns the status into an exception that carries it
     hp = H._build(); hp.layers = 7; hp.stacks = 2
     with pytest.raises(_ext.WnError) as ei:
