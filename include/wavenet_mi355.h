@@ -93,7 +93,7 @@ typedef struct wn_ctx wn_ctx;
 int  wn_create(const wn_config* cfg, wn_ctx** out);     /* validates cfg (wavenet.py:94,97; models/__init__.py:6-9) */
 void wn_destroy(wn_ctx* ctx);
 const char* wn_last_error(const wn_ctx* ctx);           /* ctx may be NULL: error of the last failed wn_create */
-int  wn_receptive_field(const wn_ctx* ctx);             /* wavenet.py:54-71 */
+int  wn_receptive_field(const wn_ctx* ctx);             /* wavenet.py:54-71; like every accessor below: WN_E_ARG for a NULL ctx */
 
 /* ---- parameter table (host-side; replaces tf.trainable_variables(), wavenet.py:467) ---------- */
 int64_t wn_param_count(const wn_ctx* ctx);              /* floats in the flat parameter buffer (incl. alignment pad) */
