@@ -127,12 +127,51 @@ def cpu_baseline(hp, seconds_budget=20.0):
                       % (B, T, n, dt, cores)}
 
 
-def cpu_baseline_subprocess(workload, hard_timeout=150):
+def cpu_synth_baseline(hp, steps=2200, seconds_budget=15.0):
+    """Oracle incremental loop (SURVEY 8d 'how the reference CPU path is timed', item 2) on a bounded sample: one stream of the same
+    architecture, `steps` samples (>= 2000) or until the budget runs out, RTF extrapolated from the per-step time.  Two formulations:
+    the reference's own ([B, 2d+1, R] queues rebuilt by slice + concat every step, modules.py:285-288) and O(1) ring buffers (what
+    the HIP path does), to separate the algorithmic from the hardware gain.  The per-step work is ~150 small matvecs, so a few threads."""
+    from oracle import wavenet_oracle as O
+    cores = min(os.cpu_count() or 1, 8)
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig.from_hparams(hp)
+    params = O.init_params(cfg, seed=5339)
+    g = torch.Generator().manual_seed(0)
+    Tc = max(2, -(-steps // cfg.hop))
+    c = torch.rand(1, cfg.cin_channels, Tc, generator=g)
+    out = {'unit': 'audio_samples/s', 'cores': cores, 'kind': 'port', 'sample_rate': hp.sample_rate}
+    with torch.no_grad():
+        for form in ('reference', 'ring'):
+            # time in slices so that a slow host stops at the budget instead of running all the steps
+            done, t0 = 0, time.time()
+            for T in (64, steps):
+                if T == steps and done:
+                    per = (time.time() - t0) / done
+                    T = int(max(256, min(steps, seconds_budget / max(per, 1e-9))))
+                    done, t0 = 0, time.time()
+                if cfg.out_channels == 2:
+                    noise = {'eps': torch.randn(T, 1, generator=g)}
+                elif cfg.scalar_input:
+                    noise = {'u1': torch.rand(T, 1, cfg.out_channels // 3, generator=g) * 0.98 + 0.01, 'u2': torch.rand(T, 1, generator=g) * 0.98 + 0.01}
+                else:
+                    noise = {'gumbel_u': torch.rand(T, 1, cfg.quantize_channels, generator=g) * 0.98 + 0.01}
+                O.incremental(params, cfg, c, T=T, noise=noise, formulation=form)
+                done = T
+            dt = time.time() - t0
+            out[form] = {'steps': done, 'wall_s': dt, 'samples_per_s': done / dt, 'rtf_extrapolated': hp.sample_rate * dt / done}
+    out['value'] = out['reference']['samples_per_s']
+    out['sample'] = ('oracle incremental loop, same architecture, 1 stream x %d (reference queues) / %d (ring buffers) samples, torch-CPU fp32 %d threads; '
+                     'RTF = extrapolated wall / audio time at %d Hz' % (out['reference']['steps'], out['ring']['steps'], cores, hp.sample_rate))
+    return out
+
+
+def cpu_baseline_subprocess(workload, hard_timeout=150, fn='cpu_baseline'):
     """Run the CPU leg in a child process so that a pathological host (thread oversubscription) can never
     take the GPU number down with it."""
     import subprocess
     code = ('import sys, json; sys.path.insert(0, %r); import bench; hp, _, _ = bench.build_hparams(%r); '
-            'print("CPUBASE" + json.dumps(bench.cpu_baseline(hp)))' % (ROOT, workload))
+            'print("CPUBASE" + json.dumps(bench.%s(hp)))' % (ROOT, workload, fn))
     try:
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=hard_timeout)
         for line in r.stdout.splitlines():
@@ -316,6 +355,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             _log('cpu baseline (oracle) ...')
             res['cpu_baseline'] = cpu_baseline_subprocess(args.workload)
+            if not args.no_synth:
+                _log('cpu baseline, synthesis (oracle incremental loop) ...')
+                res['cpu_baseline_synthesis'] = cpu_baseline_subprocess(args.workload, fn='cpu_synth_baseline')
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))

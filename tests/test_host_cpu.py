@@ -380,3 +380,17 @@ def test_c_abi_rejects_bad_configurations_before_touching_the_gpu():
     with pytest.raises(_ext.WnError) as ei:
         _ext.Engine(hp, 1, 275)
     assert ei.value.code == SHAPE and 'WN_E_SHAPE' in str(ei.value)
+
+
+def test_bench_cpu_synthesis_baseline_leg():
+    """bench.py's CPU synthesis baseline: the oracle incremental loop in the reference's queue formulation and with ring
+    buffers, on a bounded sample, reporting samples/s and the extrapolated real-time factor."""
+    sys.path.insert(0, ROOT)
+    import bench
+    hp, _, _ = bench.build_hparams('c2')
+    r = bench.cpu_synth_baseline(hp, steps=300, seconds_budget=3.0)
+    assert r['kind'] == 'port' and r['cores'] >= 1 and r['unit'] == 'audio_samples/s'
+    for form in ('reference', 'ring'):
+        assert r[form]['steps'] >= 256 and r[form]['samples_per_s'] > 0
+        assert abs(r[form]['rtf_extrapolated'] - hp.sample_rate / r[form]['samples_per_s']) < 1e-6 * r[form]['rtf_extrapolated']
+    assert r['value'] == r['reference']['samples_per_s']
