@@ -357,7 +357,10 @@ def main():
             res['cpu_baseline'] = cpu_baseline_subprocess(args.workload)
             if not args.no_synth:
                 _log('cpu baseline, synthesis (oracle incremental loop) ...')
-                res['cpu_baseline_synthesis'] = cpu_baseline_subprocess(args.workload, fn='cpu_synth_baseline')
+                try:
+                    res['cpu_baseline_synthesis'] = cpu_baseline_subprocess(args.workload, fn='cpu_synth_baseline')
+                except Exception as e:      # a reported extra: never lose the JSON line to it
+                    res['cpu_baseline_synthesis'] = {'value': None, 'sample': 'failed: ' + str(e)[:200]}
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))
