@@ -23,7 +23,7 @@ PINNING STATUS
     installable (no network), so ``oracle/tf1_shim.py`` serves the ~70 ``tf.*`` symbols those files use with
     eager torch ops of the documented TF semantics (kernel layouts, SAME/VALID padding, channels_first/last,
     batch_to_space_nd, TensorArray/while_loop ...), and ``oracle/gen_golden_stack.py`` records
-    ``WaveNet.step`` / ``.incremental`` / ``.add_loss`` outputs on 15 configurations into
+    ``WaveNet.step`` / ``.incremental`` / ``.add_loss`` outputs on 18 configurations (incl. weight normalisation and the engine-width `hip_*` ones) into
     ``tests/golden/stack_*.npz``.  What this pins is the reference's COMPOSITION of ops (order, transposes,
     paddings, splits, scalings, queue updates) -- the part a restatement can get wrong; the primitives of the
     stand-in are themselves checked against naive index loops (tests/test_oracle_golden.py).  It is not a run
