@@ -46,7 +46,8 @@ class Feeder(object):
         self._test_offset = 0
         self._device = device
         self._rank, self._world = _ranks()
-        self._rng = np.random.RandomState(hparams.wavenet_random_seed + 7919 * self._rank)
+        self._rng = np.random.RandomState(hparams.wavenet_random_seed + 7919 * self._rank)      # crops: independent per rank
+        self._order_rng = np.random.RandomState(hparams.wavenet_random_seed)                     # batch order: identical on every rank
         if hparams.symmetric_mels:
             self._spec_pad = -hparams.max_abs_value
         else:
@@ -114,7 +115,8 @@ class Feeder(object):
             examples = [self._get_example(self._train_meta, True) for _ in range(n * _batches_per_group)]
             examples.sort(key=lambda e: len(e[0]))                 # bucket by length
             batches = [examples[i:i + n] for i in range(0, len(examples), n)]
-            self._rng.shuffle(batches)
+            # same order on every rank: at each step the ranks hold the disjoint slices of ONE length bucket (equal padding => equal step time)
+            self._order_rng.shuffle(batches)
         else:
             examples = [self._get_example(self._test_meta, False) for _ in range(len(self._test_meta))]
             batches = [examples[i:i + n] for i in range(0, len(examples), n)]

@@ -394,3 +394,30 @@ def test_bench_cpu_synthesis_baseline_leg():
         assert r[form]['steps'] >= 256 and r[form]['samples_per_s'] > 0
         assert abs(r[form]['rtf_extrapolated'] - hp.sample_rate / r[form]['samples_per_s']) < 1e-6 * r[form]['rtf_extrapolated']
     assert r['value'] == r['reference']['samples_per_s']
+
+
+def test_feeder_ranks_take_disjoint_slices_of_the_same_batches(tmp_path, monkeypatch):
+    """Data-parallel feeding: at every step the ranks hold disjoint slices of ONE global batch -- same group composition,
+    same length-bucket order on every rank (so padding, hence step time, is equal) -- like tf.split over towers (wavenet.py:233-239)."""
+    import hparams as H
+    from wavenet_vocoder import feeder as F
+    hp = H._build()
+    hp.parse('hop_size=16,num_mels=16,cin_channels=16,upsample_scales=[4,4],max_time_steps=500,wavenet_batch_size=4,wavenet_test_batches=1')
+    meta = _write_dataset(str(tmp_path))
+    groups = {}
+    for r in range(2):
+        monkeypatch.setattr(F, '_ranks', lambda r=r: (r, 2))
+        fd = F.Feeder(None, meta, str(tmp_path), hp, device=torch.device('cpu'))
+        groups[r] = fd._next_group(train=True) + fd._next_group(train=True)        # two groups: the order rng advances identically
+    monkeypatch.setattr(F, '_ranks', lambda: (0, 1))
+    whole = F.Feeder(None, meta, str(tmp_path), hp, device=torch.device('cpu'))
+    ref = whole._next_group(train=True) + whole._next_group(train=True)
+    assert len(groups[0]) == len(groups[1]) == len(ref) == 128
+    for b0, b1, b in zip(groups[0], groups[1], ref):
+        assert len(b0) == len(b1) == 2 and len(b) == 4
+        for got, want in zip(b0 + b1, b):                                              # rank 0 = first half, rank 1 = second half
+            assert got[3] == want[3] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # an indivisible global batch is refused like the reference does (feeder.py:267-268)
+    monkeypatch.setattr(F, '_ranks', lambda: (0, 3))
+    with pytest.raises(AssertionError):
+        F.Feeder(None, meta, str(tmp_path), hp, device=torch.device('cpu'))._next_group(train=True)
