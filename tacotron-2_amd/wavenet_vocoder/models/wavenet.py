@@ -21,6 +21,12 @@ from wavenet_vocoder.util import is_mulaw, is_mulaw_quantize, is_scalar_input
 from .modules import initialize_parameters, receptive_field_size
 
 
+def dropout_seed(random_seed, global_step, rank=0):
+    """64-bit key of a training step's dropout masks.  Every rank draws its own masks, like the reference's towers each own a
+    tf.layers.dropout op (modules.py:484); rank 0 of any world size equals the single-GPU stream."""
+    return (int(random_seed) * 1000003 + int(global_step) + int(rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
+
 class WaveNet(object):
     def __init__(self, hparams, init=False):
         self._hparams = hparams
@@ -95,7 +101,8 @@ class WaveNet(object):
             if self.engine is None:
                 self.build(B, T)
             self._ensure_packed()
-            self._seed = int(hp.wavenet_random_seed) * 1000003 + self.global_step
+            rank = self._dist.get_rank() if (self._dist is not None and self._world > 1) else 0
+            self._seed = dropout_seed(hp.wavenet_random_seed, self.global_step, rank)
             self.tower_y, self.tower_input_lengths, self.tower_c = [y], [input_lengths], [c]
             self._y_hat_train = None
             self._set_global(g, B)

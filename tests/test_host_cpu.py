@@ -421,3 +421,10 @@ def test_feeder_ranks_take_disjoint_slices_of_the_same_batches(tmp_path, monkeyp
     monkeypatch.setattr(F, '_ranks', lambda: (0, 3))
     with pytest.raises(AssertionError):
         F.Feeder(None, meta, str(tmp_path), hp, device=torch.device('cpu'))._next_group(train=True)
+
+
+def test_dropout_seed_is_per_rank_and_single_gpu_compatible():
+    from wavenet_vocoder.models.wavenet import dropout_seed
+    assert dropout_seed(5339, 17) == 5339 * 1000003 + 17 == dropout_seed(5339, 17, rank=0)
+    seeds = {dropout_seed(5339, s, r) for s in range(100) for r in range(8)}
+    assert len(seeds) == 800 and all(0 <= v < 2 ** 64 for v in seeds)
