@@ -333,6 +333,46 @@ def _conv1x1(x, K, b):
     return y if b is None else y + b[None, :, None]
 
 
+def glu_layer(P, params, cfg: OracleConfig, l, h, cu, mask, q, gvec=None):
+    """One ResidualConv1DGLU.step (modules.py:471-521) of layer l on its input h [B,R,T]: returns (next layer input, skip
+    contribution, gate output u).  P = kernels as the contraction sees them (bf16-rounded when emulating), params = fp32 biases,
+    mask = {0,1} dropout mask [B,R,T] or None, q = rounding applied where the HIP path stores bf16 (identity for the fp32 oracle)."""
+    k = cfg.kernel_size
+    d = cfg.dilations()[l]
+    keep = 1.0 - cfg.wavenet_dropout
+    p = 'ResidualConv1DGLU_%d/' % l
+    residual = h
+    xin = h
+    if mask is not None:
+        xin = q(h * mask / keep)                                             # tf.layers.dropout on the conv INPUT only (modules.py:484)
+    W = P[p + 'residual_block_causal_conv/kernel']                           # [k,R,G]
+    z = F.conv1d(F.pad(xin, ((k - 1) * d, 0)), W.permute(2, 1, 0).contiguous(),
+                 params.get(p + 'residual_block_causal_conv/bias'), dilation=d)   # modules.py:306-320
+    if cu is not None:                                                       # modules.py:497-501
+        z = z + _conv1x1(cu, P[p + 'residual_block_cin_conv/kernel'],
+                         params.get(p + 'residual_block_cin_conv/bias'))
+    if gvec is not None:                                                     # modules.py:503-508: g broadcast over time
+        zg = gvec @ params[p + 'residual_block_gin_conv/kernel'][0]
+        bg = params.get(p + 'residual_block_gin_conv/bias')
+        z = z + (zg if bg is None else zg + bg)[:, :, None]
+    a, b = z.chunk(2, dim=1)                                                 # modules.py:494
+    u = q(torch.tanh(a) * torch.sigmoid(b))                                  # modules.py:510
+    s = _conv1x1(u, P[p + 'residual_block_skip_conv/kernel'], params.get(p + 'residual_block_skip_conv/bias'))
+    o = _conv1x1(u, P[p + 'residual_block_out_conv/kernel'], params.get(p + 'residual_block_out_conv/bias'))
+    h = (o + residual) * SQRT_HALF if cfg.residual_legacy else (o + residual)   # modules.py:517-520
+    return q(h), s, u
+
+
+def contraction_params(params, cfg, emulate_bf16):
+    """(P, params_effective): the kernels as the HIP contractions see them -- bf16 MFMA operands for every conv except the
+    (fp32, K = Cin) input conv, the fp32 upsample kernels and the fp32 global-conditioning matvec."""
+    params = effective_params(params, cfg)
+    q = bf16_round if emulate_bf16 else (lambda t: t)
+    P = {k: (q(v) if k.endswith('kernel') and not k.startswith(('local_conditioning', 'input_convolution')) and 'gin_conv' not in k else v)
+         for k, v in params.items()}
+    return P, params
+
+
 def step(params, cfg: OracleConfig, x, c, dropout_masks=None, emulate_bf16=False, return_aux=False, g=None):
     """Teacher-forced parallel forward.  wavenet.py:650-721.
 
@@ -341,14 +381,9 @@ def step(params, cfg: OracleConfig, x, c, dropout_masks=None, emulate_bf16=False
       the layer input is x*mask/(1-p) (tf.layers.dropout, modules.py:484); the residual
       path uses the un-dropped x (modules.py:483, 517-520).
     """
-    params = effective_params(params, cfg)
     q = bf16_round if emulate_bf16 else (lambda t: t)
-    # HIP path: bf16 MFMA operands for every conv except the (fp32, K=Cin) input conv and the
-    # (fp32) upsample kernels
-    P = {k: (q(v) if k.endswith('kernel') and not k.startswith(('local_conditioning', 'input_convolution')) and 'gin_conv' not in k else v)
-         for k, v in params.items()}
+    P, params = contraction_params(params, cfg, emulate_bf16)
     gvec = global_features(params, cfg, g)                                   # [B, gin] or None (wavenet.py:669-678)
-    k = cfg.kernel_size
     aux = {}
     cu = None
     if c is not None:
@@ -358,33 +393,12 @@ def step(params, cfg: OracleConfig, x, c, dropout_masks=None, emulate_bf16=False
         cu = q(cu)
     h = q(_conv1x1(x, P['input_convolution/kernel'], params['input_convolution/bias']))  # wavenet.py:705
     skips = None
-    keep = 1.0 - cfg.wavenet_dropout
     aux['layer_in'] = []
     aux['u'] = []
     for l, d in enumerate(cfg.dilations()):
-        p = 'ResidualConv1DGLU_%d/' % l
-        residual = h
-        xin = h
-        if dropout_masks is not None:
-            xin = q(h * dropout_masks[l] / keep)
         aux['layer_in'].append(h)
-        W = P[p + 'residual_block_causal_conv/kernel']                       # [k,R,G]
-        z = F.conv1d(F.pad(xin, ((k - 1) * d, 0)), W.permute(2, 1, 0).contiguous(),
-                     params.get(p + 'residual_block_causal_conv/bias'), dilation=d)   # modules.py:306-320
-        if cu is not None:                                                   # modules.py:497-501
-            z = z + _conv1x1(cu, P[p + 'residual_block_cin_conv/kernel'],
-                             params.get(p + 'residual_block_cin_conv/bias'))
-        if gvec is not None:                                                 # modules.py:503-508: g broadcast over time
-            zg = gvec @ params[p + 'residual_block_gin_conv/kernel'][0]
-            bg = params.get(p + 'residual_block_gin_conv/bias')
-            z = z + (zg if bg is None else zg + bg)[:, :, None]
-        a, b = z.chunk(2, dim=1)                                             # modules.py:494
-        u = q(torch.tanh(a) * torch.sigmoid(b))                              # modules.py:510
+        h, s, u = glu_layer(P, params, cfg, l, h, cu, None if dropout_masks is None else dropout_masks[l], q, gvec)
         aux['u'].append(u)
-        s = _conv1x1(u, P[p + 'residual_block_skip_conv/kernel'], params.get(p + 'residual_block_skip_conv/bias'))
-        o = _conv1x1(u, P[p + 'residual_block_out_conv/kernel'], params.get(p + 'residual_block_out_conv/bias'))
-        h = (o + residual) * SQRT_HALF if cfg.residual_legacy else (o + residual)   # modules.py:517-520
-        h = q(h)
         if skips is None:                                                    # wavenet.py:706-715
             skips = s
         else:

@@ -64,6 +64,26 @@ def dropout_mask(seed, layer, rows, R, p):
     return (bits >= thresh).astype(np.float32).reshape(rows, R)
 
 
+def dropout_mask_rows(seed, layer, row0, nrows, R, p):
+    """rows [row0, row0 + nrows) of the device mask (element e = row*R + r, absolute rows); in-place uint32 arithmetic
+    (wraps like the device's), ~0.1 s per 11000 x 256 layer."""
+    assert (row0 * R) % 2 == 0 and (nrows * R) % 2 == 0
+    lo, hi = layer_key(seed, layer)
+    w = np.arange((row0 * R) >> 1, ((row0 + nrows) * R) >> 1, dtype=np.uint32)
+
+    def mix(x):
+        x ^= (x >> np.uint32(16)); x *= np.uint32(0x85ebca6b)
+        x ^= (x >> np.uint32(13)); x *= np.uint32(0xc2b2ae35)
+        x ^= (x >> np.uint32(16))
+        return x
+    w ^= np.uint32(lo); w = mix(w); w += np.uint32(hi); w = mix(w)
+    thresh = int(np.rint(np.float32(p) * np.float32(65536.0)))
+    out = np.empty((nrows * R // 2, 2), dtype=np.float32)
+    out[:, 0] = (w & np.uint32(0xffff)) >= thresh
+    out[:, 1] = (w >> np.uint32(16)) >= thresh
+    return out.reshape(nrows, R)
+
+
 def oracle_masks(seed, cfg, B, T):
     """per-layer masks in the oracle's [B, R, T] layout."""
     out = []

@@ -81,3 +81,64 @@ def test_pipe_incremental_equals_batch_forward_on_device(B, kw):
     e = rel_err(raw, yhat)
     print('\npipe incremental vs batch (both HIP) B=%d rel err %.3e' % (B, e))
     assert e < 2e-2
+
+
+# ---- C4 scale (BASELINE configs[3]): the 24-layer / 2-stack paper model, against the ORACLE (not against another HIP path) ------
+PAPER_FULL = dict(PAPER_WIDTH, layers=24, stacks=2, out_channels=30, upsample_type='2D', upsample_scales=[5, 5, 11], hop_size=275,
+                  legacy=False, residual_legacy=False, NN_scaler=0.1, log_scale_min=float(np.log(1e-14)))
+TOL_RAW_EMUL = 1.2e-2     # raw network outputs vs the bf16-emulating oracle  (<= 3x measured, profiles/r2_pytest_gpu_verbose.log)
+TOL_RAW_FP32 = 2.5e-2     # ... vs the fp32 oracle (reference arithmetic)
+
+
+def _oracle_teacher_forced(params, cfg, wav, c, emulate):
+    """SURVEY.md A.8 (wavenet.py:724-911 vs :650-721): teacher-forced incremental generation == the batch forward on the input
+    shifted by one sample with the silence start frame (wavenet.py:433-445) in front.  Stream by stream (memory)."""
+    B, T = wav.shape
+    out = torch.empty(B, cfg.out_channels, T)
+    with torch.no_grad():
+        for b in range(B):
+            xs = torch.cat([torch.zeros(1, 1), wav[b:b + 1, :-1]], 1).view(1, 1, T)
+            out[b] = O.step(params, cfg, xs, c[b:b + 1], emulate_bf16=emulate)[0]
+    return out
+
+
+def test_pipe_c4_scale_teacher_forced_vs_oracle():
+    """B = 8 streams x 22 000 steps (> receptive field 16 381 and > the 8192-slot ring of the d = 2048 layers, so every ring
+    buffer wraps and every tap reads a slot written by this run), raw outputs of ALL streams vs the oracle."""
+    B, Tc = 8, 80
+    hp, cfg, eng, params, wav, c, T = _setup(B, Tc, **PAPER_FULL)
+    assert T == 22000 and eng.receptive_field == 16381
+    nz_dev, nz_or = _noise(cfg, T, B)
+    out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, cfg.out_channels, T, device='cuda')
+    eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, wav.contiguous().cuda(), steps_per_graph=0)
+    torch.cuda.synchronize()
+    raw = raw.cpu()
+    r_em = _oracle_teacher_forced(params, cfg, wav, c, True)
+    per = [rel_err(raw[b], r_em[b]) for b in range(B)]
+    tail = [rel_err(raw[b, :, 17000:], r_em[b, :, 17000:]) for b in range(B)]      # steps whose whole receptive field went through wrapped rings
+    print('\npipe C4-scale teacher-forced vs emulating oracle: per stream ' + ' '.join('%.2e' % e for e in per))
+    print('   last 5000 steps only: ' + ' '.join('%.2e' % e for e in tail))
+    assert max(per) < TOL_RAW_EMUL and max(tail) < TOL_RAW_EMUL
+    r_fp = _oracle_teacher_forced(params, cfg, wav[:2], c[:2], False)
+    e_fp = [rel_err(raw[b], r_fp[b]) for b in range(2)]
+    print('   vs fp32 oracle (streams 0, 1): ' + ' '.join('%.2e' % e for e in e_fp))
+    assert max(e_fp) < TOL_RAW_FP32
+    # the sampler ran on those raw outputs (mixture.py:76-107)
+    exp = O.sample_from_discretized_mix_logistic(raw, nz_or['u1'].permute(1, 0, 2), nz_or['u2'].t(), cfg.log_scale_min)
+    assert torch.allclose(out.cpu(), exp, atol=2e-5)
+
+
+def test_pipe_c4_scale_free_running_feedback():
+    """Free-running generation at depth: the oracle, teacher-forced with the DEVICE's own samples, must reproduce the device's raw
+    outputs (every sample fed back through the input convolution, wavenet.py:869-878)."""
+    B, Tc = 1, 80
+    hp, cfg, eng, params, wav, c, T = _setup(B, Tc, **PAPER_FULL)
+    nz_dev, nz_or = _noise(cfg, T, B, seed=9)
+    out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, cfg.out_channels, T, device='cuda')
+    eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, None, steps_per_graph=0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
+    r_em = _oracle_teacher_forced(params, cfg, out.cpu(), c, True)
+    e = rel_err(raw.cpu(), r_em)
+    print('\npipe C4-scale free-running vs emulating oracle (fed the device samples): %.2e' % e)
+    assert e < TOL_RAW_EMUL
