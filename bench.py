@@ -246,7 +246,7 @@ def main():
 
     from wavenet_vocoder import _ext
     from wavenet_vocoder.models.modules import initialize_parameters
-    from wavenet_vocoder.parallel import allreduce_mean_
+    from wavenet_vocoder.parallel import allreduce_mean_buckets_
     hp, B, T = build_hparams(args.workload)
     B = args.batch or B
     T = args.time or T
@@ -266,7 +266,7 @@ def main():
         eng.pack_weights(flat)
         eng.train_fwd(x, c, y, lengths, 1000 + i, loss)
         eng.train_bwd(grads)
-        allreduce_mean_(grads)
+        allreduce_mean_buckets_(eng, grads)          # per gradient bucket on a side stream, under the rest of the backward
         lr = _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, i, hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
         eng.optim_step(flat, grads, m, v, ema, lr, i)
 

@@ -14,8 +14,12 @@
  *     No C++ exception crosses this boundary.
  *   - all data pointers are DEVICE pointers (HBM) owned by the caller and borrowed for the call only,
  *     unless the parameter is documented "host".  Tensors are contiguous in the stated layout.
- *   - all work is enqueued asynchronously on the caller's stream (`void* stream` is a hipStream_t);
- *     no hidden device synchronisation.  One wn_ctx per (process, device); not thread-safe.
+ *   - all work is enqueued asynchronously, ordered after everything already on the caller's stream (`void* stream` is a
+ *     hipStream_t) and before whatever the caller enqueues next (ctx-owned side streams are forked and joined with events);
+ *     no entry point of the drop-in surface synchronises the device (wn_synth_check and the WN_TEST_HOOKS say so where they do).
+ *     One wn_ctx per (process, device); not thread-safe.
+ *   - memory: wn_create sizes the workspace once for (max_batch, max_time).  Training contexts allocate their synthesis state on the
+ *     first wn_synthesize (eval steps); inference-only contexts (cfg.inference_only) pre-size it and never allocate afterwards.
  *   - parameters, gradients and optimiser slots are single flat fp32 buffers; the tensors inside them
  *     keep the reference's TensorFlow layouts ([k,in,out] conv kernels ...) at the offsets reported by
  *     wn_tensor_info(), under names mirroring the reference's variable scopes.
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 2
+#define WN_ABI_VERSION 3
 
 enum wn_status {
     WN_OK = 0,
@@ -85,6 +89,11 @@ typedef struct wn_config {
     /* Salimans & Kingma weight normalisation of every convolution (hparams.py:323; modules.py:44-177): the exported tensors
      * become kernel (= v), g [last kernel axis], bias; kernels are used as g * v / ||v|| (norm over all axes but the last). */
     int32_t weight_normalization;
+    /* 1: synthesis-only context.  Skips the saved-activation / backward workspace of training (~45 KB per (batch x time) row at the
+     * paper shape; what remains -- conditioning, ring queues, mailboxes, the noise buffer -- is ~1.5 KB per row) and PRE-SIZES every
+     * synthesis buffer for (max_batch, max_time), so wn_synthesize never allocates.  wn_train_* / wn_optim_step return WN_E_STATE.
+     * A training context (0) can still synthesise (eval steps); it allocates its synthesis state on the first wn_synthesize. */
+    int32_t inference_only;
 } wn_config;
 
 typedef struct wn_ctx wn_ctx;
@@ -129,6 +138,17 @@ int wn_train_fwd(wn_ctx* ctx, const void* x, const float* c, const void* y, cons
  * Replaces optimizer.compute_gradients (wavenet.py:557). */
 int wn_train_bwd(wn_ctx* ctx, float* grads, void* stream);
 
+/* Gradient buckets for data-parallel training (replaces the tower-gradient loop of wavenet.py:553-581, which averages variable by
+ * variable after ALL gradients exist).  wn_train_bwd completes the flat gradient buffer in wn_bwd_num_buckets() contiguous
+ * pieces, top layers first: the weight gradients of a bucket are computed on a ctx-owned low-priority stream while the serial
+ * d z / d h chain is still working on the layers below.  wn_bwd_wait_bucket makes `stream` (e.g. the communication stream of the
+ * caller's all-reduce) wait until bucket i of the LAST enqueued wn_train_bwd is final; the caller's own stream is ordered after
+ * the whole buffer when wn_train_bwd returns, as before.  Ranges are floats into the flat buffer; the buckets are disjoint and
+ * cover every tensor.  Models with weight normalisation or global conditioning report one bucket. */
+int wn_bwd_num_buckets(const wn_ctx* ctx);
+int wn_bwd_bucket_range(const wn_ctx* ctx, int32_t i, int64_t* offset, int64_t* count);
+int wn_bwd_wait_bucket(wn_ctx* ctx, int32_t i, void* stream);
+
 /* Stand-alone masked loss on [B,O,T] network outputs.  shift = 1: training alignment (prediction t vs sample
  * t+1, wavenet.py:488-495); shift = 0: evaluation of the incremental loop's raw outputs (wavenet.py:497-506).
  * Invalidates the saved backward state of the last wn_train_fwd. */
@@ -152,7 +172,10 @@ float wn_learning_rate(int32_t schedule, float init_lr, int64_t step, float deca
  * c           float [B, cin, Tc]  (already transposed as wavenet.py:427)
  * noise       float [T, B, noise_per_step]: MoL: M uniforms u1 then 1 uniform u2 (mixture.py:91,104);
  *             Gaussian: 1 standard-normal draw (gaussian.py:50); softmax: Q uniforms (Gumbel-max form of
- *             tf.multinomial, wavenet.py:865).  NULL => device Philox stream keyed by `seed`.
+ *             tf.multinomial, wavenet.py:865).  NULL => drawn on the device: Philox4x32-10 keyed by `seed`, counter = the element
+ *             index of this [T, B, noise_per_step] layout (uniforms in (1e-5, 1 - 1e-5) as mixture.py:91,104; Gaussian draws by
+ *             Box-Muller) into a ctx-owned buffer -- replaces tf.random_uniform / Normal.sample / tf.multinomial's own generator;
+ *             wn_fill_noise exposes the same stream so that a run can be reproduced with an explicit buffer.
  * test_inputs optional teacher forcing (wavenet.py:877-878): float [B,T] (scalar) / int32 [B,T] ids.
  * out_samples float [B,T] (scalar types) or int32 [B,T] (class ids)   (wavenet.py:874, 897-911)
  * out_raw     optional float [B, out_channels, T] raw network outputs  (wavenet.py:847, 904-908)     */
@@ -160,6 +183,15 @@ int wn_synthesize(wn_ctx* ctx, const float* c, int32_t B, int32_t Tc, const floa
                   uint64_t seed, const void* test_inputs, void* out_samples, float* out_raw,
                   int32_t steps_per_graph, void* stream);
 int wn_noise_per_step(const wn_ctx* ctx);
+/* The device noise stream of wn_synthesize(noise = NULL, seed): fills float [T, B, noise_per_step]. */
+int wn_fill_noise(wn_ctx* ctx, float* noise, int32_t B, int32_t T, uint64_t seed, void* stream);
+/* wn_synthesize enqueues and returns (no device synchronisation).  The persistent pipeline bounds every hand-off spin; if one times
+ * out (a workgroup was not resident) the kernels leave early and raise a device flag.  wn_synth_check waits for the LAST
+ * wn_synthesize of this context to finish and returns WN_E_HIP (+ wn_last_error) if that happened, WN_OK otherwise; the next
+ * wn_synthesize on the context reports a pending failure too.  wn_synth_last_path: 0 none yet, 1 launch-per-layer hipGraph path,
+ * 2 persistent pipeline. */
+int wn_synth_check(wn_ctx* ctx);
+int wn_synth_last_path(const wn_ctx* ctx);
 
 /* Stand-alone samplers on [B,O,T] parameters (train-time log path, wavenet.py:302-325). */
 int wn_sample(wn_ctx* ctx, const float* y_hat, int32_t B, int32_t T, const float* noise /*[T,B,nps]*/,
@@ -173,22 +205,29 @@ int wn_inv_mulaw_quantize(const int32_t* q, float* x, int64_t n, void* stream);
 /* argmax over channels of [B,Q,T] logits -> int32 [B,T] (first max wins, like tf.argmax) */
 int wn_argmax_channels(const float* logits, int32_t* out, int32_t B, int32_t Q, int32_t T, void* stream);
 
-/* ---- test hook: copy an internal activation buffer of the last step to `out` as fp32 ("X","U","TS","DZ",
- * "R1","H2","DY","DSKIP","DPRE1","GX0","GX1","cbt" are bf16 [rows][channels]; "YHAT","DC","CUP" fp32). */
-int wn_debug_copy(wn_ctx* ctx, const char* name, int32_t layer, float* out, int64_t n, void* stream);
-
-/* ---- introspection for bench / profiling ----------------------------------------------------- */
+/* ---- introspection ------------------------------------------------------------------------------ */
 int64_t wn_workspace_bytes(const wn_ctx* ctx);
-/* live HIP-event timing of the dominant training kernel (the gate GEMM, one launch per layer and step),
- * recorded on the launch stream between wn_profile(ctx,1) and wn_profile_result (which synchronises). */
+/* name of the kernel that dominates training time (bench.py's roofline line names it) */
+const char* wn_dominant_kernel_name(void);
+
+/* ================================================================================================
+ * WN_TEST_HOOKS -- NOT part of the drop-in surface.  Entry points used only by tests/, bench.py and tools/ to look inside a
+ * context; a reference-side binding has no use for them.  Compile callers with -DWN_NO_TEST_HOOKS to hide the declarations.
+ * ================================================================================================ */
+#ifndef WN_NO_TEST_HOOKS
+/* copy an internal activation buffer of the last step to `out` as fp32 ("X","U","TS","DZ","R1","H2","DY","DSKIP","DPRE1","GX0",
+ * "GX1","cbt" are bf16 [rows][channels]; "YHAT","DC","CUP" fp32). */
+int wn_debug_copy(wn_ctx* ctx, const char* name, int32_t layer, float* out, int64_t n, void* stream);
+/* live HIP-event timing of the dominant training kernel (the gate GEMM, one launch per layer and step), recorded on the launch
+ * stream between wn_profile(ctx,1) and wn_profile_result -- which SYNCHRONISES on the recorded events (bench only). */
 int wn_profile(wn_ctx* ctx, int32_t enable);
 int wn_profile_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
 /* time rows (utterances x samples) one timed launch processed: the layer chain runs per half-batch on two streams */
 int64_t wn_profile_rows_per_launch(const wn_ctx* ctx);
-/* 0: default (2 when the batch has >= 2 utterances), 1: whole batch on the caller's stream, 2: two half-batches on two streams */
+/* A/B switch of the stream structure.  0: default (2 when the batch has >= 2 utterances), 1: whole batch on the caller's stream,
+ * 2: two half-batches on two streams */
 int wn_set_batch_parts(wn_ctx* ctx, int32_t parts);
-/* name of the kernel that dominates training time + its algorithmic bytes/flops per audio sample */
-const char* wn_dominant_kernel_name(void);
+#endif /* WN_NO_TEST_HOOKS */
 
 #ifdef __cplusplus
 }

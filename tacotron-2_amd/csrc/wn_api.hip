@@ -90,7 +90,37 @@ static void build_layout(wn_ctx* c) {
 
 static char* bump(char*& p, size_t bytes) { char* r = p; p += align_up((int64_t)bytes, 256); return r; }
 
+// Inference-only contexts (cfg.inference_only) keep what Fast-WaveNet synthesis touches: the upsampled conditioning (cbt + the
+// fp32 levels of the upsample net), scalars and the zero page.  Everything else below is saved-activation / backward workspace.
+static int alloc_workspace_inference(wn_ctx* c) {
+    const int64_t NT = c->NT;
+    size_t total = 0;
+    auto sz = [&](size_t b) { total += align_up((int64_t)b, 256); };
+    // level i of the upsample net holds Tc * prod(scales[0..i]) samples per stream: only the last one is full rate
+    std::vector<int64_t> lvl(c->cfg.n_upsample + 1, NT);
+    if (c->cfg.upsample_type != WN_UP_NEAREST) {
+        int64_t den = c->hop;
+        for (int i = 0; i < c->cfg.n_upsample; ++i) { den /= c->cfg.upsample_scales[i]; lvl[i] = NT / (den > 0 ? den : 1) + c->maxB; }
+    }
+    sz(NT * c->C * 2);
+    for (int i = 0; i <= c->cfg.n_upsample; ++i) sz(lvl[i] * c->C * 4);
+    sz(256); sz(256);
+    c->ws_bytes = total;
+    hipError_t e = hipMalloc((void**)&c->ws, total);
+    if (e != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMalloc(%zu bytes inference workspace) failed: %s", total, hipGetErrorString(e));
+    char* p = c->ws;
+    c->cbt = (bf16_t*)bump(p, NT * c->C * 2);
+    for (int i = 0; i <= c->cfg.n_upsample; ++i) c->CUP[i] = (float*)bump(p, lvl[i] * c->C * 4);
+    c->scal = (float*)bump(p, 256);
+    c->zero_page = (bf16_t*)bump(p, 256);
+    c->X = c->XD = c->TS = c->U = c->R1 = c->H2 = c->DY = c->DPRE1 = c->DSKIP = c->DZ = c->GXall = c->GX0 = c->GX1 = nullptr;
+    c->YHAT = c->DC = c->DCUP[0] = c->DCUP[1] = c->CIN = nullptr; c->XIN = nullptr;
+    if (hipMemset(c->zero_page, 0, 256) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
+    return WN_OK;
+}
+
 static int alloc_workspace(wn_ctx* c) {
+    if (c->inference) return alloc_workspace_inference(c);
     const int64_t NT = c->NT;
     const int ldDY = (int)align_up(c->O, 16);
     size_t total = 0;
@@ -178,6 +208,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     c->hop = hop;
     c->lbias = cfg->use_bias != 0;
     c->wnorm = cfg->weight_normalization != 0;
+    c->inference = cfg->inference_only != 0;
     c->gin = cfg->gin_channels > 0 ? cfg->gin_channels : 0;
     c->OP = (int)align_up(c->O, 32); c->CP = (int)align_up(c->C, 32);
     const int per = c->L / cfg->stacks;
@@ -189,15 +220,23 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
         c->skip_scale[l] = (float)pow((double)WN_SQRT_HALF, e);
     }
     build_layout(c);
+    wn_plan_buckets(c);
     c->cup_final_idx = (cfg->upsample_type == WN_UP_NEAREST) ? 0 : cfg->n_upsample - 1;
     c->maxB = cfg->max_batch; c->maxT = cfg->max_time; c->NT = (int64_t)c->maxB * c->maxT;
     int rc = alloc_workspace(c);
     if (rc == WN_OK) rc = wn_build_packs(c);
-    if (rc == WN_OK) {
+    if (rc == WN_OK && !c->inference) {
         c->wg_partial_bytes = wn_wgrad_partial_need(c);
         if (hipMalloc((void**)&c->wg_partial, c->wg_partial_bytes) != hipSuccess) {
             c->err = "hipMalloc(wgrad partial buffer) failed"; rc = WN_E_HIP;
         }
+    }
+    if (rc == WN_OK && c->inference) {
+        // pre-size every synthesis buffer for (max_batch, max_time): wn_synthesize never allocates on this context
+        if (c->maxB > 32) { c->err = "inference_only: max_batch must be <= 32 streams"; rc = WN_E_SHAPE; }
+        if (rc == WN_OK) rc = wn_noise_reserve(c, c->maxB, c->maxT);
+        // the persistent pipeline when the model fits it (up to 16 streams per run), else the launch-per-layer graph path
+        if (rc == WN_OK) rc = wn_pipe_eligible(c, std::min(c->maxB, 16)) ? wn_pipe_reserve(c, std::min(c->maxB, 16), c->maxT) : wn_synth_reserve(c);
     }
     if (rc != WN_OK) { g_create_err = c->err; wn_destroy(c); return rc; }
     *out = c;
@@ -218,6 +257,10 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->norm2_dev) hipFree(c->norm2_dev);
     if (c->params_dev) hipFree(c->params_dev);
     if (c->st2) { (void)hipStreamSynchronize(c->st2); hipStreamDestroy(c->st2); }      // nothing of ours may still be running on it
+    if (c->st3) { (void)hipStreamSynchronize(c->st3); hipStreamDestroy(c->st3); }
+    for (int p = 0; p < 2; ++p) for (int k = 0; k < WN_MAX_BUCKETS; ++k) if (c->ev_chain[p][k]) hipEventDestroy(c->ev_chain[p][k]);
+    for (int k = 0; k < WN_MAX_BUCKETS + 2; ++k) if (c->ev_bucket[k]) hipEventDestroy(c->ev_bucket[k]);
+    if (c->ev_w0) hipEventDestroy(c->ev_w0);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->wmap_dev) hipFree(c->wmap_dev);
@@ -227,6 +270,7 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->gids) hipFree(c->gids);
     if (c->gbias) hipFree(c->gbias);
     if (c->colsum) hipFree(c->colsum);
+    if (c->noise_buf) hipFree(c->noise_buf);
     if (c->ws) hipFree(c->ws);
     if (c->wg_partial) hipFree(c->wg_partial);
     delete c;
@@ -246,7 +290,7 @@ extern "C" int wn_tensor_info(const wn_ctx* c, int i, char* name, int32_t* shape
     return WN_OK;
 }
 extern "C" int64_t wn_workspace_bytes(const wn_ctx* c) { return c ? (int64_t)(c->ws_bytes + c->wg_partial_bytes) : (int64_t)WN_E_ARG; }
-extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, 0, 1>"; }
+extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, 0, 1, 3>"; }
 
 extern "C" int wn_pack_weights(wn_ctx* c, const float* params, void* stream) {
     if (!c || !params) return WN_E_ARG;
@@ -287,13 +331,14 @@ static int check_fwd_args(wn_ctx* c, const void* x, const float* cc, const void*
 extern "C" int wn_train_fwd(wn_ctx* c, const void* x, const float* cc, const void* y, const int32_t* lengths,
                             int32_t B, int32_t T, int32_t Tc, uint64_t seed, float* loss_out, float* y_hat_out, void* stream) {
     if (!c) return WN_E_ARG;
+    if (c->inference) WN_FAIL(c, WN_E_STATE, "wn_train_fwd on an inference-only context (cfg.inference_only = 1)");
     int rc = check_fwd_args(c, x, cc, y, lengths, B, T, Tc);
     if (rc) return rc;
     // x and c are needed again by wn_train_bwd: keep ctx-owned copies (caller pointers are borrowed for this call only)
     WN_HIP(c, hipMemcpyAsync(c->XIN, x, (size_t)B * T * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     WN_HIP(c, hipMemcpyAsync(c->CIN, cc, (size_t)B * c->C * Tc * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     c->fx = c->XIN; c->fc = c->CIN; c->fy = y; c->flen = lengths; c->fB = B; c->fT = T; c->fTc = Tc; c->fseed = seed;
-    c->have_fwd = false;
+    c->have_fwd = false; c->have_bwd = false;
     rc = wn_fwd_impl(c, (hipStream_t)stream, loss_out, y_hat_out);
     if (rc == WN_OK) c->have_fwd = true;
     return rc;
@@ -307,6 +352,7 @@ extern "C" int wn_train_bwd(wn_ctx* c, float* grads, void* stream) {
 
 extern "C" int wn_optim_step(wn_ctx* c, float* p, const float* g, float* m, float* v, float* ema, float lr, int64_t step, void* stream) {
     if (!c || !p || !g || !m || !v || !ema) return WN_E_ARG;
+    if (c->inference) WN_FAIL(c, WN_E_STATE, "wn_optim_step on an inference-only context (cfg.inference_only = 1)");
     return wn_optim_impl(c, p, g, m, v, ema, lr, step, (hipStream_t)stream);
 }
 
@@ -323,8 +369,32 @@ extern "C" int wn_synthesize(wn_ctx* c, const float* cc, int32_t B, int32_t Tc, 
     if (!c->packed) WN_FAIL(c, WN_E_STATE, "wn_pack_weights must be called before wn_synthesize");
     if (B <= 0 || B > 32) WN_FAIL(c, WN_E_SHAPE, "synthesis batch %d outside (0, 32]", B);
     if (Tc <= 0) WN_FAIL(c, WN_E_SHAPE, "Tc must be positive");
-    if (!noise) WN_FAIL(c, WN_E_UNSUPPORTED, "device-generated noise not built yet: pass a noise buffer");
+    int rc = wn_pipe_check(c, false);                  // a hand-off timeout of the previous pipeline run surfaces here at the latest
+    if (rc) return rc;
+    if (!noise) {                                      // device Philox stream keyed by `seed` (header)
+        const int T = Tc * c->hop;
+        if ((rc = wn_noise_reserve(c, B, T))) return rc;
+        if ((rc = wn_fill_noise_impl(c, c->noise_buf, B, T, seed, (hipStream_t)stream))) return rc;
+        noise = c->noise_buf;
+    }
     return wn_synth_impl(c, cc, B, Tc, noise, seed, test_inputs, out_samples, out_raw, steps_per_graph, (hipStream_t)stream);
+}
+
+extern "C" int wn_fill_noise(wn_ctx* c, float* noise, int32_t B, int32_t T, uint64_t seed, void* stream) {
+    if (!c || !noise || B <= 0 || T <= 0) return WN_E_ARG;
+    return wn_fill_noise_impl(c, noise, B, T, seed, (hipStream_t)stream);
+}
+extern "C" int wn_synth_check(wn_ctx* c) { if (!c) return WN_E_ARG; return wn_pipe_check(c, true); }
+extern "C" int wn_synth_last_path(const wn_ctx* c) { return c ? c->synth_path : WN_E_ARG; }
+
+int wn_noise_reserve(wn_ctx* c, int B, int T) {
+    const size_t need = (size_t)B * T * wn_noise_per_step(c) * 4;
+    if (need <= c->noise_bytes) return WN_OK;
+    if (c->inference && c->noise_buf) WN_FAIL(c, WN_E_SHAPE, "synthesis B*T = %d*%d exceeds the pre-sized noise buffer of this inference-only context", B, T);
+    if (c->noise_buf) { (void)hipDeviceSynchronize(); hipFree(c->noise_buf); c->noise_buf = nullptr; c->noise_bytes = 0; }
+    WN_HIP(c, hipMalloc((void**)&c->noise_buf, need));
+    c->noise_bytes = need;
+    return WN_OK;
 }
 
 extern "C" int wn_noise_per_step(const wn_ctx* c) {
@@ -346,6 +416,7 @@ __global__ void wn_bf16_to_f32(const bf16_t* __restrict__ in, float* __restrict_
 }
 extern "C" int wn_debug_copy(wn_ctx* c, const char* name, int32_t layer, float* out, int64_t n, void* stream) {
     if (!c || !name || !out || n <= 0) return WN_E_ARG;
+    if (c->inference && strcmp(name, "cbt") != 0 && strcmp(name, "CUP") != 0) WN_FAIL(c, WN_E_STATE, "wn_debug_copy('%s'): no training workspace on an inference-only context", name);
     const int64_t NT = c->NT;
     const bf16_t* b = nullptr; const float* f = nullptr;
     std::string s = name;

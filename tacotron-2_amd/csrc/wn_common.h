@@ -69,6 +69,8 @@ struct PackedW {          // one fragment-ordered bf16 matrix
     int32_t M_valid = 0;
     int32_t gate_interleave = 0;      // row permutation (see wn_pack.hip)
     int32_t GH = 0;
+    int32_t kil = 0;                  // > 0: the three dilated taps are interleaved along K in blocks of `kil` channels
+                                      //      [tap0 blk0 | tap1 blk0 | tap2 blk0 | tap0 blk1 | ...] (tile engine: taps of one k-block back to back => L2 reuse)
     std::vector<PackSeg> segs;
     PackSeg* dev_segs = nullptr;
 };
@@ -133,6 +135,15 @@ struct wn_ctx {
     // batch parts: the serial layer chain of the two half-batches runs on two streams so that the MFMA/power-bound GEMMs of
     // one half overlap the HBM-bound kernels of the other (fwd: gate | out conv, bwd: dx | dgate); joined before the loss / wgrads
     hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int parts = 1; int parts_req = 0; int prof_rows = 0;
+    // gradient buckets (wn_train.hip: wn_plan_buckets): weight gradients run bucket by bucket on a third, low-priority stream under
+    // the serial backward chain; ev_bucket[k] = bucket k of the flat gradient is final (index WN_MAX_BUCKETS: the whole buffer)
+#define WN_MAX_BUCKETS 8
+    hipStream_t st3 = nullptr; hipEvent_t ev_chain[2][WN_MAX_BUCKETS] = {}; hipEvent_t ev_bucket[WN_MAX_BUCKETS + 2] = {}; hipEvent_t ev_w0 = nullptr;
+    int nbuckets = 0, nbuckets_early = 0; int bucket_lo[WN_MAX_BUCKETS + 2] = {}, bucket_hi[WN_MAX_BUCKETS + 2] = {};
+    int64_t bucket_off[WN_MAX_BUCKETS + 2] = {}, bucket_cnt[WN_MAX_BUCKETS + 2] = {}; bool have_bwd = false;
+    bool inference = false;               // cfg.inference_only: no training workspace, synthesis state pre-sized at wn_create
+    float* noise_buf = nullptr; size_t noise_bytes = 0;      // device-drawn sampling noise [T][B][nps] (wn_synthesize with noise == NULL)
+    int synth_path = 0;                   // 0 none, 1 graph, 2 pipeline (wn_synth_last_path)
     // synthesis state (lazy)
     struct Synth* synth = nullptr;
     void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)
@@ -159,6 +170,11 @@ int wn_synth_impl(wn_ctx* ctx, const float* c, int B, int Tc, const float* noise
 void wn_synth_free(wn_ctx* ctx);
 void wn_pipe_free(wn_ctx* ctx);
 bool wn_pipe_eligible(const wn_ctx* ctx, int B);
+int wn_pipe_reserve(wn_ctx* ctx, int B, int T);            // size every pipeline buffer for (B, T) (no-op when already large enough)
+int wn_synth_reserve(wn_ctx* ctx);                        // state of the launch-per-layer graph path
+int wn_pipe_check(wn_ctx* ctx, bool wait);                // pending abort flag of the last pipeline run -> WN_E_HIP
+int wn_noise_reserve(wn_ctx* ctx, int B, int T);
+int wn_fill_noise_impl(wn_ctx* ctx, float* noise, int B, int T, uint64_t seed, hipStream_t st);
 int wn_pipe_synthesize(wn_ctx* ctx, const float* c, int B, int Tc, const float* noise, const void* test_inputs,
                        void* out_samples, float* out_raw, hipStream_t st);
 extern "C" int wn_noise_per_step(const wn_ctx* c);
@@ -168,4 +184,5 @@ int wn_weightnorm_grad(wn_ctx* ctx, float* raw_grads, hipStream_t st);          
 int wn_gbias_fwd(wn_ctx* ctx, int B, hipStream_t st);                 // global-conditioning bias table of this batch
 int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st);           // d W_g, d b_g, d embedding
 size_t wn_wgrad_partial_need(wn_ctx* ctx);
+void wn_plan_buckets(wn_ctx* ctx);
 int wn_sample_impl(wn_ctx* ctx, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st);

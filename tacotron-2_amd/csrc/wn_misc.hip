@@ -33,14 +33,16 @@ __global__ void wn_pack_kernel(const float* __restrict__ params, const PackJob* 
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.0f;
     if (mm < jb.M_valid) {
-        for (int s = 0; s < jb.nseg; ++s) {
-            const PackSeg sg = jb.segs[s];
+        // segments are sorted by k0 and they start at multiples of 8 (channel counts are multiples of 16): the 8 elements of this
+        // thread lie in ONE segment, found by binary search (a K-interleaved pack has 3 * R/32 + 1 of them)
+        int lo2 = 0, hi2 = jb.nseg - 1;
+        while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (jb.segs[mid].k0 <= k0) lo2 = mid; else hi2 = mid - 1; }
+        const PackSeg sg = jb.segs[lo2];
+        if (k0 >= sg.k0 && k0 < sg.k0 + sg.nk) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + j;
-                if (k >= sg.k0 && k < sg.k0 + sg.nk)
-                    v[j] = sg.scale * params[sg.base + (int64_t)(k - sg.k0) * sg.stride_k + (int64_t)mm * sg.stride_m];
-            }
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < sg.k0 + sg.nk)          // (the last segment may end inside the group: out_channels = 30 -> K padded to 32)
+                    v[j] = sg.scale * params[sg.base + (int64_t)(k0 + j - sg.k0) * sg.stride_k + (int64_t)mm * sg.stride_m];
         }
     }
     *reinterpret_cast<uint4*>(jb.out + idx8 * 8) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
@@ -80,8 +82,12 @@ int wn_build_packs(wn_ctx* c) {
         const WnLayerOffsets& o = c->lay[l];
         WnLayerPacks& p = c->packs[l];
         // W1: rows = gate channels (interleaved), K = [tap0 R | tap1 R | tap2 R | cin C]; W[g][j*R+r] = dil[j][r][g]
+        // Matrices that take the LDS-DMA tile engine (M % 128 == 0) interleave the taps along K in 32-channel blocks: the engine then
+        // stages (tap0, tap1, tap2) of one k-block back to back, so the rows two taps have in common are re-read while still in L2.
         init_pack(c, p.w1, G, 3 * R + C, 1);
-        for (int j = 0; j < 3; ++j) p.w1.segs.push_back({o.dil_k + (int64_t)j * R * G, j * R, R, G, 1, 1.0f});
+        p.w1.kil = (G % 128 == 0 && R % 32 == 0) ? 32 : 0;
+        if (p.w1.kil) { for (int kb = 0; kb < R / 32; ++kb) for (int j = 0; j < 3; ++j) p.w1.segs.push_back({o.dil_k + ((int64_t)j * R + kb * 32) * G, (kb * 3 + j) * 32, 32, G, 1, 1.0f}); }
+        else for (int j = 0; j < 3; ++j) p.w1.segs.push_back({o.dil_k + (int64_t)j * R * G, j * R, R, G, 1, 1.0f});
         p.w1.segs.push_back({o.cin_k, 3 * R, C, G, 1, 1.0f});
         if ((rc = finish_pack(c, p.w1))) return rc;
         // Wo: rows = residual channels, K = GH;  W[r][g'] = out_k[g'][r]
@@ -99,7 +105,9 @@ int wn_build_packs(wn_ctx* c) {
         if ((rc = finish_pack(c, p.w2T))) return rc;
         // W1T (dx): rows = r, K = [tap0 G | tap1 G | tap2 G];  W[r][j*G+g] = dil[j][r][g]
         init_pack(c, p.w1T, R, 3 * G, 0);
-        for (int j = 0; j < 3; ++j) p.w1T.segs.push_back({o.dil_k + (int64_t)j * R * G, j * G, G, 1, G, 1.0f});
+        p.w1T.kil = (R % 128 == 0 && G % 32 == 0) ? 32 : 0;
+        if (p.w1T.kil) { for (int kb = 0; kb < G / 32; ++kb) for (int j = 0; j < 3; ++j) p.w1T.segs.push_back({o.dil_k + (int64_t)j * R * G + kb * 32, (kb * 3 + j) * 32, 32, 1, G, 1.0f}); }
+        else for (int j = 0; j < 3; ++j) p.w1T.segs.push_back({o.dil_k + (int64_t)j * R * G, j * G, G, 1, G, 1.0f});
         if ((rc = finish_pack(c, p.w1T))) return rc;
     }
     // skip sum as ONE contraction over all layers' gate outputs: rows = s, K = L*GH (wavenet.py:706-715 unrolled)
@@ -958,6 +966,7 @@ int wn_loss_fwd_bwd(wn_ctx* c, float* loss_out, hipStream_t st) {
 extern "C" int wn_loss(wn_ctx* c, const float* y_hat, const void* y, const int32_t* lengths, int32_t B, int32_t T, int32_t shift, float* loss_out, void* stream) {
     if (!c || !y_hat || !y || !lengths || !loss_out) return WN_E_ARG;
     if (shift != 0 && shift != 1) WN_FAIL(c, WN_E_ARG, "shift must be 0 or 1");
+    if (c->inference) WN_FAIL(c, WN_E_STATE, "wn_loss on an inference-only context (the loss gradient buffer is training workspace)");
     c->have_loss = false;      // DY is overwritten
     return wn_loss_run(c, y_hat, y, lengths, B, T, shift, loss_out, (hipStream_t)stream);
 }
@@ -1128,6 +1137,52 @@ int wn_sample_impl(wn_ctx* c, const float* y_hat, int B, int T, const float* noi
     const int mode = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE ? 2 : (c->O == 2 ? 1 : 0);
     const float lsmin = mode == 1 ? c->cfg.log_scale_min_gauss : c->cfg.log_scale_min;
     hipLaunchKernelGGL(wn_sample_kernel, dim3(cdiv((int64_t)B * T, 256)), dim3(256), 0, st, y_hat, noise, out, B, T, c->O, mode, wn_noise_per_step(c), lsmin);
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
+// =================================================================================== device noise stream
+// Sampling noise of wn_synthesize(noise = NULL): replaces tf.random_uniform (mixture.py:91,104), Normal.sample (gaussian.py:50) and
+// tf.multinomial's generator (wavenet.py:865).  Philox4x32-10 (Salmon et al., SC'11), key = the 64-bit seed, counter = (group index,
+// 0, 0): group g yields the four 32-bit words of elements 4g .. 4g+3 of the flat [T][B][nps] buffer, so a draw depends only on
+// (seed, element index) -- any launch geometry reproduces it (tests/hip_util.py mirrors it in numpy, bit for bit).
+__host__ __device__ inline void wn_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+// 24 random bits -> (0, 1) open at both ends -> the reference's clipping range (1e-5, 1 - 1e-5)
+__host__ __device__ inline float wn_u01(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__global__ void wn_noise_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1, int gaussian) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g * 4 >= n) return;
+    uint32_t w[4];
+    wn_philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), k0, k1, w);
+    float v[4];
+    if (gaussian) {                                   // Box-Muller on the word pairs (w0, w1) and (w2, w3)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float r = sqrtf(-2.0f * logf(wn_u01(w[2 * h]))), ph = 6.28318530717958647692f * wn_u01(w[2 * h + 1]);
+            v[2 * h] = r * cosf(ph); v[2 * h + 1] = r * sinf(ph);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = wn_u01(w[j]) * (1.0f - 2e-5f) + 1e-5f;
+    }
+    if (g * 4 + 3 < n) *reinterpret_cast<float4*>(out + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    else for (int j = 0; j < 4 && g * 4 + j < n; ++j) out[g * 4 + j] = v[j];
+}
+int wn_fill_noise_impl(wn_ctx* c, float* noise, int B, int T, uint64_t seed, hipStream_t st) {
+    const int64_t n = (int64_t)B * T * wn_noise_per_step(c);
+    if ((reinterpret_cast<uintptr_t>(noise) & 15) != 0) WN_FAIL(c, WN_E_ARG, "noise buffer must be 16-byte aligned");
+    const int gaussian = (c->cfg.input_type != WN_INPUT_MULAW_QUANTIZE && c->O == 2) ? 1 : 0;
+    hipLaunchKernelGGL(wn_noise_kernel, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, st, noise, n, (uint32_t)seed, (uint32_t)(seed >> 32), gaussian);
     WN_LAUNCH_CHECK(c);
     return WN_OK;
 }

@@ -41,7 +41,7 @@ __device__ __forceinline__ float acc_at(const float* red, int wave_stride, int n
 __global__ __launch_bounds__(256) void wn_synth_gate(const bf16_t* __restrict__ Apk, int ksteps, const bf16_t* __restrict__ ring, int mask,
                                                      int d, int R, const bf16_t* __restrict__ cbt, int C, int T, int B,
                                                      const float* __restrict__ bias, int bias_bstride, int GH, bf16_t* __restrict__ ucur,
-                                                     const int32_t* __restrict__ t_dev) {
+                                                     const int32_t* __restrict__ t_dev, int kil) {
     __shared__ float red[4 * 2 * 64 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = *t_dev;
@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void wn_synth_gate(const bf16_t* __restrict__ 
         uint4 bv = make_uint4(0, 0, 0, 0);
         if (n < B) {
             if (k0 < 3 * R) {
-                const int j = k0 / R, r = k0 - j * R;
+                // K order of the pack: [tap0 | tap1 | tap2] or, interleaved in blocks of `kil` channels, [tap0 b0 | tap1 b0 | tap2 b0 | tap0 b1 | ...]
+                int j, r;
+                if (kil > 0) { const int blk = k0 / kil; j = blk % 3; r = (blk / 3) * kil + (k0 - blk * kil); }
+                else { j = k0 / R; r = k0 - j * R; }
                 const int tau = t - (2 - j) * d;
                 if (tau >= 0) bv = *reinterpret_cast<const uint4*>(ring + ((size_t)(tau & mask) * 32 + n) * R + r);
             } else {
@@ -262,7 +265,7 @@ static int enqueue_step(wn_ctx* c, Synth* s, const float* noise, const void* tes
     const int L = c->L, R = c->R, GH = c->GH, S = c->S, C = c->C, B = s->B, T = s->T;
     for (int l = 0; l < L; ++l) {
         hipLaunchKernelGGL(wn_synth_gate, dim3(GH / 32), dim3(256), 0, st, c->packs[l].w1.dev, c->packs[l].w1.K >> 4, s->ring[l], s->mask[l],
-                           c->dil[l], R, c->cbt, C, T, B, c->gin > 0 ? c->gbias + (size_t)l * B * c->G : c->b1sum + (size_t)l * c->G, c->gin > 0 ? c->G : 0, GH, s->ucur, s->t_dev);
+                           c->dil[l], R, c->cbt, C, T, B, c->gin > 0 ? c->gbias + (size_t)l * B * c->G : c->b1sum + (size_t)l * c->G, c->gin > 0 ? c->G : 0, GH, s->ucur, s->t_dev, c->packs[l].w1.kil);
         const bool top = (l == L - 1);
         hipLaunchKernelGGL(wn_synth_out, dim3(R / 32 + S / 32), dim3(256), 0, st, c->packs[l].wo.dev, c->packs[l].ws.dev, GH >> 4, R, S, s->ucur, GH,
                            c->params_dev + c->lay[l].out_b, c->res_scale, s->ring[l], s->mask[l], top ? nullptr : s->ring[l + 1], top ? 0 : s->mask[l + 1],
@@ -275,6 +278,29 @@ static int enqueue_step(wn_ctx* c, Synth* s, const float* noise, const void* tes
     hipLaunchKernelGGL(wn_synth_sample, dim3(1), dim3(256), 0, st, s->yraw, c->O, c->OP, mode, wn_noise_per_step(c), lsmin, noise, test_inputs, out_samples, out_raw,
                        c->params_dev + c->first.dil_k, c->params_dev + c->first.dil_b, R, s->ring[0], s->mask[0], B, T, s->t_dev);
     WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
+// state of the launch-per-layer path: ring queues for up to 32 streams, per-step scratch, the capture stream (sizes do not depend
+// on the utterance length).  wn_create calls this on inference-only contexts; training contexts get here on first use.
+int wn_synth_reserve(wn_ctx* c) {
+    if (c->synth) return WN_OK;
+    const int L = c->L, R = c->R;
+    Synth* s = new Synth(); c->synth = s;
+        s->ring.assign(L, nullptr); s->mask.assign(L, 0);
+        for (int l = 0; l < L; ++l) {
+            int slots = 4; while (slots < 4 * c->dil[l]) slots <<= 1;
+            s->mask[l] = slots - 1;
+            WN_HIP(c, hipMalloc((void**)&s->ring[l], (size_t)slots * 32 * R * 2));
+        }
+        WN_HIP(c, hipMalloc((void**)&s->ucur, 32 * c->GH * 2));
+        WN_HIP(c, hipMalloc((void**)&s->skip_acc, 32 * c->S * 4));
+        WN_HIP(c, hipMalloc((void**)&s->h2, 32 * c->S * 2));
+        WN_HIP(c, hipMalloc((void**)&s->yraw, 32 * c->OP * 4));
+        WN_HIP(c, hipMalloc((void**)&s->t_dev, 4));
+        WN_HIP(c, hipStreamCreateWithFlags(&s->priv, hipStreamNonBlocking));
+        WN_HIP(c, hipEventCreateWithFlags(&s->ev0, hipEventDisableTiming));
+        WN_HIP(c, hipEventCreateWithFlags(&s->ev1, hipEventDisableTiming));
     return WN_OK;
 }
 
@@ -291,25 +317,11 @@ int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise
         if (want_pipe && wn_pipe_eligible(c, B)) return wn_pipe_synthesize(c, cin, B, Tc, noise, test_inputs, out_samples, out_raw, caller_st);
         if (steps_per_graph <= 0) steps_per_graph = 32;
     }
+    int rc0 = wn_synth_reserve(c);
+    if (rc0) return rc0;
     const int L = c->L, R = c->R;
     Synth* s = c->synth;
-    if (!s) {
-        s = new Synth(); c->synth = s;
-        s->ring.assign(L, nullptr); s->mask.assign(L, 0);
-        for (int l = 0; l < L; ++l) {
-            int slots = 4; while (slots < 4 * c->dil[l]) slots <<= 1;
-            s->mask[l] = slots - 1;
-            WN_HIP(c, hipMalloc((void**)&s->ring[l], (size_t)slots * 32 * R * 2));
-        }
-        WN_HIP(c, hipMalloc((void**)&s->ucur, 32 * c->GH * 2));
-        WN_HIP(c, hipMalloc((void**)&s->skip_acc, 32 * c->S * 4));
-        WN_HIP(c, hipMalloc((void**)&s->h2, 32 * c->S * 2));
-        WN_HIP(c, hipMalloc((void**)&s->yraw, 32 * c->OP * 4));
-        WN_HIP(c, hipMalloc((void**)&s->t_dev, 4));
-        WN_HIP(c, hipStreamCreateWithFlags(&s->priv, hipStreamNonBlocking));
-        WN_HIP(c, hipEventCreateWithFlags(&s->ev0, hipEventDisableTiming));
-        WN_HIP(c, hipEventCreateWithFlags(&s->ev1, hipEventDisableTiming));
-    }
+    c->synth_path = 1;
     // everything below runs on the ctx-owned stream, ordered after the caller's stream and before its next op
     hipStream_t st = s->priv;
     WN_HIP(c, hipEventRecord(s->ev0, caller_st));

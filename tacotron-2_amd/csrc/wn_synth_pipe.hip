@@ -573,6 +573,8 @@ struct Pipe {
     u32x4* XM = nullptr; u32x4* SM = nullptr; u32x4* XML = nullptr; u32x4* SML = nullptr; size_t xm_bytes = 0, sm_bytes = 0;
     bf16_t* ring = nullptr; size_t ring_bytes = 0; int ring_B = 0;
     int32_t* abort_dev = nullptr;
+    int32_t* abort_host = nullptr;      // pinned: the abort flag of the last run lands here asynchronously (read by wn_pipe_check)
+    bool pending = false;               // a run has been enqueued whose flag has not been inspected yet
     int layer_lds = 0, head_lds = 0;
     PipeArgs proto;
     hipStream_t priv = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -583,6 +585,8 @@ void wn_pipe_free(wn_ctx* c) {
     if (!p) return;
     if (p->slices) hipFree(p->slices); if (p->jobs_dev) hipFree(p->jobs_dev); if (p->job_block0_dev) hipFree(p->job_block0_dev);
     if (p->XM) hipFree(p->XM); if (p->SM) hipFree(p->SM); if (p->XML) hipFree(p->XML); if (p->SML) hipFree(p->SML); if (p->ring) hipFree(p->ring); if (p->abort_dev) hipFree(p->abort_dev);
+    if (p->priv) (void)hipStreamSynchronize(p->priv);
+    if (p->abort_host) hipHostFree(p->abort_host);
     if (p->ev0) hipEventDestroy(p->ev0); if (p->ev1) hipEventDestroy(p->ev1); if (p->priv) hipStreamDestroy(p->priv);
     delete p; c->pipe = nullptr;
 }
@@ -670,6 +674,8 @@ static int pipe_build(wn_ctx* c, Pipe* p) {
     WN_HIP(c, hipMalloc((void**)&p->job_block0_dev, b0.size() * sizeof(int)));
     WN_HIP(c, hipMemcpy(p->job_block0_dev, b0.data(), b0.size() * sizeof(int), hipMemcpyHostToDevice));
     WN_HIP(c, hipMalloc((void**)&p->abort_dev, 256 + 4096));       // [0]: abort flag; +256: XCC table (grid <= 1024 entries)
+    WN_HIP(c, hipHostMalloc((void**)&p->abort_host, 64, hipHostMallocDefault));
+    *p->abort_host = 0;
     WN_HIP(c, hipStreamCreateWithFlags(&p->priv, hipStreamNonBlocking));
     WN_HIP(c, hipEventCreateWithFlags(&p->ev0, hipEventDisableTiming));
     WN_HIP(c, hipEventCreateWithFlags(&p->ev1, hipEventDisableTiming));
@@ -699,13 +705,47 @@ __global__ void wn_pipe_fixup_kernel(const float* __restrict__ params, char* __r
     }
 }
 
+// Size mailboxes and ring queues for B streams (they do not depend on T; the conditioning lives in the ctx workspace).  Called from
+// wn_create on inference-only contexts, so that wn_synthesize never allocates there; training contexts get here on first use.
+int wn_pipe_reserve(wn_ctx* c, int B, int T) {
+    (void)T;
+    Pipe* p = (Pipe*)c->pipe;
+    int rc;
+    if (!p) { p = new Pipe(); c->pipe = p; if ((rc = pipe_build(c, p))) return rc; }
+    const int L = c->L, R = c->R, P = p->P;
+    const size_t xm = (size_t)(L + 1) * B * P * PIPE_XG * 16, sm = (size_t)(L + 1) * B * P * PIPE_SG * 16;
+    int64_t roff = 0;
+    for (int l = 0; l < L; ++l) { int slots = 4; while (slots < 2 * c->dil[l] + 1) slots <<= 1; roff += (int64_t)P * B * slots * R; }
+    const bool grow = xm > p->xm_bytes || sm > p->sm_bytes || (size_t)roff * 2 > p->ring_bytes;
+    if (!grow) return WN_OK;
+    if (c->inference && p->xm_bytes) WN_FAIL(c, WN_E_SHAPE, "synthesis batch %d exceeds the pre-sized pipeline of this inference-only context", B);
+    if (p->priv) WN_HIP(c, hipStreamSynchronize(p->priv));          // (growing: nothing of ours may still read the old buffers)
+    if (xm > p->xm_bytes) { if (p->XM) hipFree(p->XM); if (p->XML) hipFree(p->XML); WN_HIP(c, hipMalloc((void**)&p->XM, xm)); WN_HIP(c, hipMalloc((void**)&p->XML, xm)); p->xm_bytes = xm; }
+    if (sm > p->sm_bytes) { if (p->SM) hipFree(p->SM); if (p->SML) hipFree(p->SML); WN_HIP(c, hipMalloc((void**)&p->SM, sm)); WN_HIP(c, hipMalloc((void**)&p->SML, sm)); p->sm_bytes = sm; }
+    if ((size_t)roff * 2 > p->ring_bytes) { if (p->ring) hipFree(p->ring); WN_HIP(c, hipMalloc((void**)&p->ring, (size_t)roff * 2)); p->ring_bytes = (size_t)roff * 2; }
+    return WN_OK;
+}
+
+// Abort flag of the last pipeline run.  wait = false: report it only if that run has already finished (no synchronisation);
+// wait = true: wait for it (wn_synth_check).
+int wn_pipe_check(wn_ctx* c, bool wait) {
+    Pipe* p = (Pipe*)c->pipe;
+    if (!p || !p->pending) return WN_OK;
+    if (wait) WN_HIP(c, hipEventSynchronize(p->ev1));
+    else if (hipEventQuery(p->ev1) != hipSuccess) return WN_OK;     // still running: nothing to report yet
+    p->pending = false;
+    const int32_t flag = *p->abort_host;
+    if (flag != 0) WN_FAIL(c, WN_E_HIP, "synthesis pipeline timed out waiting for a hand-off (code %d): are all %d workgroups resident?", flag, p->grid);
+    return WN_OK;
+}
+
 int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* noise, const void* test_inputs,
                        void* out_samples, float* out_raw, hipStream_t caller_st) {
     const int T = Tc * c->hop, L = c->L, R = c->R;
     if ((int64_t)B * T > c->NT) WN_FAIL(c, WN_E_SHAPE, "synthesis B*T = %d*%d exceeds the workspace (max_batch*max_time = %lld)", B, T, (long long)c->NT);
-    Pipe* p = (Pipe*)c->pipe;
     int rc;
-    if (!p) { p = new Pipe(); c->pipe = p; if ((rc = pipe_build(c, p))) return rc; }
+    if ((rc = wn_pipe_reserve(c, B, T))) return rc;
+    Pipe* p = (Pipe*)c->pipe;
     hipStream_t st = p->priv;
     WN_HIP(c, hipEventRecord(p->ev0, caller_st));
     WN_HIP(c, hipStreamWaitEvent(st, p->ev0, 0));
@@ -725,15 +765,12 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     }
     // ---- mailboxes, rings
     const size_t xm = (size_t)(L + 1) * B * P * PIPE_XG * 16, sm = (size_t)(L + 1) * B * P * PIPE_SG * 16;
-    if (xm > p->xm_bytes) { if (p->XM) hipFree(p->XM); if (p->XML) hipFree(p->XML); WN_HIP(c, hipMalloc((void**)&p->XM, xm)); WN_HIP(c, hipMalloc((void**)&p->XML, xm)); p->xm_bytes = xm; }
-    if (sm > p->sm_bytes) { if (p->SM) hipFree(p->SM); if (p->SML) hipFree(p->SML); WN_HIP(c, hipMalloc((void**)&p->SM, sm)); WN_HIP(c, hipMalloc((void**)&p->SML, sm)); p->sm_bytes = sm; }
     int64_t roff = 0;
     for (int l = 0; l < L; ++l) {
         int slots = 4; while (slots < 2 * c->dil[l] + 1) slots <<= 1;
         a.ring_mask[l] = slots - 1; a.dil[l] = c->dil[l]; a.ring_off[l] = roff;
         roff += (int64_t)P * B * slots * R;
     }
-    if ((size_t)roff * 2 > p->ring_bytes) { if (p->ring) hipFree(p->ring); WN_HIP(c, hipMalloc((void**)&p->ring, (size_t)roff * 2)); p->ring_bytes = (size_t)roff * 2; }
     WN_HIP(c, hipMemsetAsync(p->XM, 0, xm, st));
     WN_HIP(c, hipMemsetAsync(p->SM, 0, sm, st));
     WN_HIP(c, hipMemsetAsync(p->XML, 0, xm, st));
@@ -755,10 +792,11 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(wn_synth_pipe_kernel, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     WN_LAUNCH_CHECK(c);
-    int32_t flag = 0;
-    WN_HIP(c, hipMemcpyAsync(&flag, p->abort_dev, 4, hipMemcpyDeviceToHost, st));
-    WN_HIP(c, hipStreamSynchronize(st));
-    if (trace_dev) {      // per-stage latencies in units of the 100 MHz real-time counter (10 ns)
+    // the abort flag travels to pinned host memory behind the kernel; nobody waits for it here (wn_pipe_check / the next call read it)
+    WN_HIP(c, hipMemcpyAsync(p->abort_host, p->abort_dev, 4, hipMemcpyDeviceToHost, st));
+    p->pending = true; c->synth_path = 2;
+    if (trace_dev) {      // per-stage latencies in units of the 100 MHz real-time counter (10 ns)   [diagnostic mode: synchronises]
+        WN_HIP(c, hipStreamSynchronize(st));
         std::vector<unsigned long long> h((size_t)trace_n * 2 * (L + 2));
         hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost); hipFree(trace_dev);
         const int W = 2 * (L + 2);
@@ -776,7 +814,6 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         fprintf(stderr, "\n[pipe trace] head us: skip-wait %.2f conv %.2f sample %.2f publish %.2f | head->L0 hop %.2f | step %.2f\n", hskip / trace_n / 100.0, hconv / trace_n / 100.0,
                 hsamp / trace_n / 100.0, hpub / trace_n / 100.0, hop[0] / (trace_n - 1) / 100.0, step / (trace_n - 1) / 100.0);
     }
-    if (flag != 0) WN_FAIL(c, WN_E_HIP, "synthesis pipeline timed out waiting for a hand-off (code %d): are all %d workgroups resident?", flag, p->grid);
     WN_HIP(c, hipEventRecord(p->ev1, st));
     WN_HIP(c, hipStreamWaitEvent(caller_st, p->ev1, 0));
     return WN_OK;

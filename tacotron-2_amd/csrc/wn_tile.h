@@ -54,6 +54,8 @@ struct GemmArgs {
     unsigned long long* trace;  // harness-only (WN_EPI_ABLATE builds): per-workgroup s_memtime stamps of the main loop
     int32_t stagger;            // shader cycles the second-resident workgroups of the first round wait before starting (0: off)
     int32_t xcd_span;           // LDS-DMA kernels: > 0 = XCD x owns the contiguous tiles [x * xcd_span, (x + 1) * xcd_span); 0 = tiles interleaved over XCDs
+    int32_t taps;               // 3: seg[0..2] are the dilated taps of ONE tensor (same base / ld / nk), staged interleaved in BK-channel blocks
+                                //    (tap0, tap1, tap2 of block 0, then of block 1, ...: the K order of a `kil` pack); 0: segments one after the other
     EpiArgs e;
 };
 
@@ -394,10 +396,11 @@ struct LdsGemmCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 0>
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 0, int TAPS = 0>
 __global__ __launch_bounds__(WM * WN * 64, (lds_gemm_min_waves(MT, NT, WM, WN, BK, NBUF)))
 void wn_gemm_lds_kernel(const GemmArgs a) {
     using Cfg = LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>;
+    static_assert(TAPS == 0 || (TAPS == 3 && NBUF == 3 && PIPE <= 1), "interleaved taps: the tap of a chunk is its ring slot (ring depth 3 == 3 taps)");
     __shared__ __attribute__((aligned(1024))) char lds[Cfg::LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -457,6 +460,9 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     // a dynamically indexed a.seg[i] would be an s_load + s_waitcnt lgkmcnt(0) (which also drains the ds_reads) per chunk.
     int s_rep = 0, s_sg = 0, s_left = a.seg[0].nk, s_kstep = 0;
     const bf16_t* s_ptr = a.seg[0].base + a.seg[0].col0;                // + rep offset + channels already staged (wave-uniform)
+    // TAPS: chunk c < t_total is tap c % 3 of the k-block c / 3 of seg[0..2] (one tensor, three row shifts).  Reuse distance of a
+    // row shared by two taps = one chunk of the co-resident tiles (a few 100 KiB) instead of a whole segment pass (> L2).
+    int t_left = TAPS ? TAPS * (a.seg[0].nk / BK) : 0;
     // per-lane constants of the B image: piece g = wave + p*NW holds rows g*(1024/RB)...; LDS byte lane*16 -> (row, slot)
     // DMA issuers: all waves, or (PIPE 5) only waves [0, NW/2) -- one per SIMD and workgroup -- with twice the pieces each, so
     // that after every barrier the other wave of the SIMD goes straight to the MFMA pipe while its partner queues on the TA.
@@ -481,12 +487,51 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         b_c8[p] = ((lane % Cfg::SPR) ^ ((row / Cfg::RPL) % Cfg::SPR)) * 8;
         b_t[p] = t0 + row;
     }
-    enter_segment();
+    int b_offt[TAPS ? TAPS : 1][BPW];          // TAPS: per-tap element offsets of this lane's rows (-1: zero page)
+    if constexpr (TAPS > 0) {
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            const int ld = a.seg[k].ld, shift = a.seg[k].shift;
+#pragma unroll
+            for (int p = 0; p < BPW; ++p) {
+                const int ts = b_t[p] + shift;
+                b_offt[k][p] = (b_t[p] < T && ts >= 0 && ts < T) ? (int)((rowbase + ts) * ld + b_c8[p]) : -1;
+            }
+        }
+        s_sg = TAPS;                               // the sequential iterator takes over at seg[TAPS] (if any) once the taps are staged
+        if (TAPS < a.nseg) { s_left = a.seg[TAPS].nk; s_ptr = a.seg[TAPS].base + a.seg[TAPS].col0; enter_segment(); }
+        else {
+            s_rep = a.nrep; s_left = BK;
+#pragma unroll
+            for (int p = 0; p < BPW; ++p) b_off[p] = -1;
+        }
+    } else enter_segment();
 
     auto stage = [&](auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
         char* const abuf = lds + BUF * Cfg::BUF_BYTES;
         char* const bbuf = abuf + Cfg::A_BYTES;
+        if constexpr (TAPS > 0) {
+            if (t_left > 0) {
+                // chunk c lives in ring slot c % NBUF and NBUF == TAPS: this buffer always holds tap BUF
+                if (dma_wave) {
+#pragma unroll
+                    for (int p = 0; p < APW; ++p) {
+                        const int f = wave + p * NWD;
+                        const bf16_t* base = a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512;
+                        lds_dma16(base + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + f * 1024)));
+                    }
+                    const bf16_t* const tp = a.seg[0].base + a.seg[0].col0 + (s_kstep / (TAPS * Cfg::KS)) * BK;     // k-block of this chunk
+#pragma unroll
+                    for (int p = 0; p < BPW; ++p) {
+                        const bf16_t* src = b_offt[BUF][p] >= 0 ? tp + b_offt[BUF][p] : a.zero;
+                        lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                    }
+                }
+                s_kstep += Cfg::KS; --t_left;
+                return;
+            }
+        }
         const int kc = (s_rep < a.nrep) ? min(BK, s_left) : 0;      // past the last chunk: an all-zero chunk (PIPE 2 pads the count)
         // A: fragment f = mt*KS + ks  <-  Apk[(mtile_wg + mt)][s_kstep + ks]; wave-uniform base + lane*16
         if (!(dbg & 1) && dma_wave) {
@@ -864,6 +909,13 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             a.stagger = grid >= 1024 ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
+            if constexpr (EPI == EPI_GATE || EPI == EPI_DX) {
+                if (a.taps == 3) {       // K-interleaved taps (packs built with kil = 32)
+                    hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1, 3>), dim3(grid), dim3(512), 0, st, a);
+                    WN_LAUNCH_CHECK(ctx);
+                    return WN_OK;
+                }
+            }
             static const int pipe_override = [] { const char* e = getenv("WN_GEMM_PIPE"); return e ? atoi(e) : 1; }();   // A/B switch for measurements (PIPE 2/3 pad the chunk count: slower on the 8- and 16-chunk kernels)
             // chunk count of this contraction: PIPE 2 (fragment reads one k-step ahead across chunk boundaries) pads it to a
             // multiple of the ring depth, so it is only used where that costs nothing (gate 27, dx 48, skip sum L*8 chunks)
@@ -885,6 +937,13 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             a.stagger = grid >= 1024 ? 8000 : 0;
+            if constexpr (EPI == EPI_GATE || EPI == EPI_DX) {
+                if (a.taps == 3) {
+                    hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 2, 4, 2, 32, 3, EPI, 1, 3>), dim3(grid), dim3(512), 0, st, a);
+                    WN_LAUNCH_CHECK(ctx);
+                    return WN_OK;
+                }
+            }
             hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
             return WN_OK;
@@ -912,6 +971,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             return WN_OK;
         }
     }
+    if (a.taps != 0) WN_FAIL(ctx, WN_E_STATE, "K-interleaved pack (taps = %d) reached a kernel with sequential K order (M = %d)", a.taps, M);
     // v1: all shapes stage 128 time rows per workgroup (36 KiB LDS, 2 workgroups per CU)
     const int nrows = 128;
     const int mrows = (M % 128 == 0) ? 128 : (M % 64 == 0) ? 64 : 32;

@@ -104,7 +104,7 @@ static void wgrad_skipout_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B,
 // bytes of split-K partials the grouped launches can need for any batch <= max_batch at max_time
 size_t wn_wgrad_partial_need(wn_ctx* c) {
     size_t need = 0;
-    const int ng = min(WN_MAX_GROUPS, c->L);
+    for (int ng = 1; ng <= min(WN_MAX_GROUPS, c->L); ++ng)          // any bucket size (wn_plan_buckets) up to all layers at once
     for (int B = 1; B <= c->maxB; ++B) {
         WgBatchArgs w;
         wgrad_w1_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
@@ -147,6 +147,7 @@ static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
         a.seg[1] = seg(XDl, R, 0, R, -d, 0);
         a.seg[2] = seg(XDl, R, 0, R, 0, 0);
         a.seg[3] = seg(c->cbt, C, 0, C, 0, 0);
+        a.taps = c->packs[l].w1.kil ? 3 : 0;
         if (c->gin > 0) { a.e.bias = c->gbias + (size_t)l * c->fB * G; a.e.bias_bstride = G; }      // + W_g^T g + b_g per utterance
         else a.e.bias = c->b1sum + (size_t)l * G;
         a.e.out0 = c->TS + (size_t)l * NT * G; a.e.ld_out0 = G;
@@ -226,7 +227,7 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
 // backward serial chain of the utterances [b0, b0 + nb): head dgrads, then d z / d h of every layer, top to bottom.
 // GXall[l] = rho * dL/dh_l is kept for every layer (rho = sqrt(.5) if residual_legacy), so that all weight gradients can be
 // contracted afterwards over the whole batch.
-static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st) {
+static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
     const int L = c->L, R = c->R, G = c->G, S = c->S, O = c->O;
     const int64_t NT = c->NT;
     const int ldDY = (O + 15) / 16 * 16;
@@ -264,6 +265,7 @@ static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st) {
             a.seg[0] = seg(DZl, G, 0, G, 2 * d, 0);
             a.seg[1] = seg(DZl, G, 0, G, d, 0);
             a.seg[2] = seg(DZl, G, 0, G, 0, 0);
+            a.taps = c->packs[l].w1T.kil ? 3 : 0;
             set_dropout(c, l, a.key_lo, a.key_hi, a.thresh16, a.keep_scale, a.drop_ld);
             if (!drop) a.thresh16 = 0;
             a.e.in0 = top ? nullptr : gx_up; a.e.ld_in0 = R;
@@ -271,6 +273,9 @@ static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st) {
             a.e.out0 = gx_dn; a.e.ld_out0 = R;
             if ((rc = wn_launch_gemm<EPI_DX>(c, a, c->packs[l].w1T.M, st))) return rc;
         }
+        // d z / d h of the layers [l, L) exist for this batch part: the weight gradients of a bucket whose lowest layer is l may start
+        for (int k = 0; k < c->nbuckets_early; ++k)
+            if (c->bucket_lo[k] == l) WN_HIP(c, hipEventRecord(c->ev_chain[part][k], st));
     }
     return WN_OK;
 }
@@ -281,70 +286,161 @@ int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
     // weight normalisation: gradients w.r.t. the effective kernels go to a ctx-owned buffer, then d v / d g (modules.py:98-103)
     int rc = wn_bwd_eff(c, c->deff, st);
     if (rc) return rc;
-    return wn_weightnorm_grad(c, grads, st);
+    if ((rc = wn_weightnorm_grad(c, grads, st))) return rc;
+    WN_HIP(c, hipEventRecord(c->ev_bucket[WN_MAX_BUCKETS], st));          // (single bucket: final after the v / g mapping)
+    return WN_OK;
 }
+// Gradient buckets (data-parallel overlap, replaces the tower loop of wavenet.py:553-581): the flat gradient buffer is completed in
+// `nbuckets` contiguous pieces, top layers first.  The weight gradients of bucket k (MFMA-bound grouped launches) run on a third,
+// low-priority stream as soon as the serial d z / d h chain has passed the bucket's lowest layer, i.e. UNDER the rest of the chain
+// (whose launches leave CUs idle in their tail rounds), and an event per bucket lets the caller start that bucket's all-reduce
+// while the next one is still being computed (wn_bwd_wait_bucket).
+static int buckets_setup(wn_ctx* c) {
+    if (c->st3) return WN_OK;
+    int lo_pri = 0, hi_pri = 0;
+    WN_HIP(c, hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));            // (least, greatest)
+    WN_HIP(c, hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, lo_pri));
+    for (int p = 0; p < 2; ++p)
+        for (int k = 0; k < WN_MAX_BUCKETS; ++k) WN_HIP(c, hipEventCreateWithFlags(&c->ev_chain[p][k], hipEventDisableTiming));
+    for (int k = 0; k < WN_MAX_BUCKETS + 2; ++k) WN_HIP(c, hipEventCreateWithFlags(&c->ev_bucket[k], hipEventDisableTiming));
+    WN_HIP(c, hipEventCreateWithFlags(&c->ev_w0, hipEventDisableTiming));
+    return WN_OK;
+}
+// bucket table (fixed at wn_create): early buckets = layer groups from the top, then [input conv + lowest layers], then the tail
+// (embedding table, upsample net).  Offsets are in the caller's (raw) layout.
+void wn_plan_buckets(wn_ctx* c) {
+    const int L = c->L;
+    c->nbuckets_early = 0; c->nbuckets = 0;
+    const int64_t tail0 = (c->emb_off >= 0) ? c->emb_off : (c->up_k.empty() ? c->n_params : c->up_k[0]);
+    static const int want = [] { const char* e = getenv("WN_BWD_BUCKETS"); return e ? atoi(e) : 4; }();
+    const bool early = !c->wnorm && c->gin == 0 && want > 1 && L >= 2 * want;
+    if (!early) {      // weight normalisation maps the effective gradients to (v, g) in a final pass; global conditioning adds per-layer
+        c->bucket_off[0] = 0; c->bucket_cnt[0] = c->n_raw; c->nbuckets = 1;          // tensors late: ONE bucket, final when the call ends
+        return;
+    }
+    const int per = (L + want - 1) / want;
+    int hi = L;
+    for (int k = 0; k < want - 1; ++k) {
+        const int lo = hi - per;
+        c->bucket_lo[k] = lo; c->bucket_hi[k] = hi;
+        c->bucket_off[k] = c->lay[lo].dil_k;
+        c->bucket_cnt[k] = (k == 0 ? tail0 : c->lay[hi].dil_k) - c->lay[lo].dil_k;      // bucket 0 also carries the head (final_convolution_*)
+        hi = lo; ++c->nbuckets_early;
+    }
+    c->nbuckets = c->nbuckets_early;
+    c->bucket_lo[c->nbuckets] = 0; c->bucket_hi[c->nbuckets] = hi;
+    c->bucket_off[c->nbuckets] = 0; c->bucket_cnt[c->nbuckets] = c->lay[hi].dil_k; ++c->nbuckets;       // input conv + layers [0, hi)
+    if (tail0 < c->n_params) { c->bucket_off[c->nbuckets] = tail0; c->bucket_cnt[c->nbuckets] = c->n_params - tail0; ++c->nbuckets; }
+}
+extern "C" int wn_bwd_num_buckets(const wn_ctx* c) { return c ? c->nbuckets : WN_E_ARG; }
+extern "C" int wn_bwd_bucket_range(const wn_ctx* c, int32_t i, int64_t* offset, int64_t* count) {
+    if (!c || i < 0 || i >= c->nbuckets || !offset || !count) return WN_E_ARG;
+    *offset = c->bucket_off[i]; *count = c->bucket_cnt[i];
+    return WN_OK;
+}
+extern "C" int wn_bwd_wait_bucket(wn_ctx* c, int32_t i, void* stream) {
+    if (!c || i < 0 || i >= c->nbuckets) return WN_E_ARG;
+    if (!c->have_bwd) WN_FAIL(c, WN_E_STATE, "wn_bwd_wait_bucket: no wn_train_bwd has been enqueued");
+    WN_HIP(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_bucket[i < c->nbuckets_early ? i : WN_MAX_BUCKETS], 0));
+    return WN_OK;
+}
+
+// stack weight gradients of the layers [l0, l0 + ng) on stream st: d [W_dil; W_cin] (+ biases), d W_skip, d W_out (+ biases)
+static int stack_wgrads(wn_ctx* c, float* grads, int l0, int ng, bool fused, hipStream_t st) {
+    const int L = c->L;
+    int rc;
+    {   // d [W_dil; W_cin], d biases:  A = [xd(t-2d) | xd(t-d) | xd(t) | c(t)],  B = d z
+        WgBatchArgs w; wgrad_w1_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
+        if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+    }
+    if (fused) {
+        // d W_skip (scaled by the legacy factor c_l) and d W_out with their biases in ONE launch: A = u_l, B = [d skip | rho dL/dh_{l+1}]
+        WgBatchArgs w; wgrad_skipout_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
+        if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+    } else {
+        {   // d W_skip (scaled by the legacy factor c_l), d skip bias:  A = u_l,  B = d skip (shared by all layers)
+            WgBatchArgs w; wgrad_skip_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
+            if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+        }
+        const int ngo = min(ng, L - 1 - l0);      // the top layer's residual branch is dead: zero gradient
+        if (ngo > 0) {   // d W_out, d out bias:  A = u_l,  B = rho * dL/dh_{l+1}
+            WgBatchArgs w; wgrad_out_args(c, w, l0, ngo, c->fB, c->fT); w.grads = grads;
+            if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+        }
+    }
+    return WN_OK;
+}
+
 static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     if (!c->have_loss) WN_FAIL(c, WN_E_STATE, "wn_train_bwd needs a forward that computed the loss (loss_out != NULL)");
     const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C, O = c->O;
     const int64_t NT = c->NT;
     const int ldDY = (O + 15) / 16 * 16;
     int rc;
+    if ((rc = buckets_setup(c))) return rc;
     WN_HIP(c, hipMemsetAsync(grads, 0, (size_t)c->n_params * 4, st));
     const int64_t rows = (int64_t)c->fB * c->fT;
     WN_HIP(c, hipMemsetAsync(c->GXall + (size_t)L * NT * R, 0, (size_t)rows * R * 2, st));   // top layer: residual branch is dead
+    bool grouped, fused;
+    { WgBatchArgs w; wgrad_w1_args(c, w, 0, 1, c->fB, c->fT); grouped = wn_wgrad_v2_ok(w);
+      wgrad_skipout_args(c, w, 0, 1, c->fB, c->fT); fused = wn_wgrad_v2_ok(w) && c->S % 8 == 0;     // N = S + R (256 for the 128-channel default hparams)
+      if (!fused) { wgrad_skip_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w);
+                    wgrad_out_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w); } }
+    const int nearly = grouped ? c->nbuckets_early : 0;       // (per-layer v1 kernels: everything after the chain, as one piece)
+    // ---- weight-gradient stream: head weight gradients first (their operands exist since the forward / loss), then one bucket of
+    // stack weight gradients whenever both chain streams have passed its lowest layer
+    WN_HIP(c, hipEventRecord(c->ev_w0, st));
+    hipStream_t wst = c->st3;
+    WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
     // ---- the serial chain, per batch part (two streams)
-    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool) { return bwd_part(c, b0, nb, s); }))) return rc;
-    // ---- everything that is NOT a weight gradient of the stack (head weight gradients, global-conditioning / input-conv /
-    // upsample-net gradients: small or latency-bound kernels, ~1 ms in sum) goes to the second stream and runs under the
-    // MFMA-bound grouped weight gradients of the stack; all of them write disjoint regions of `grads`.
-    hipStream_t side = st;
-    if (c->parts == 2) {
-        WN_HIP(c, hipEventRecord(c->ev_fork, st));
-        WN_HIP(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
-        side = c->st2;
+    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first) { return bwd_part(c, b0, nb, s, first ? 0 : 1); }))) return rc;
+    // ---- head weight gradients over the whole batch (wavenet.py:136-149): need DY / DPRE1 of BOTH parts (head of the chain)
+    {   // (enqueued after the chain in host order, but gated only by the events of the first bucket)
+        if (nearly > 0) {
+            WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[0][0], 0));
+            if (c->parts == 2) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[1][0], 0));
+        } else {
+            WN_HIP(c, hipEventRecord(c->ev_w0, st));
+            WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
+        }
     }
-    // ---- head weight gradients over the whole batch (wavenet.py:136-149)
     {   // d final_convolution_2 = H2^T dY
         WgArgs w; memset(&w, 0, sizeof w);
         w.nseg = 1; w.seg[0] = seg(c->H2, S, 0, S, 0, 0); w.ones_row = 1;
         w.Bm = c->DY; w.ldb = ldDY; w.colb0 = 0; w.N = O;
         w.out = grads + c->fin2_k; w.ldw = O; w.bias_out = grads + c->fin2_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-        if ((rc = launch_wgrad(c, w, side))) return rc;
+        if ((rc = launch_wgrad(c, w, wst))) return rc;
     }
     {   // d final_convolution_1 = R1^T dpre1
         WgArgs w; memset(&w, 0, sizeof w);
         w.nseg = 1; w.seg[0] = seg(c->R1, S, 0, S, 0, 0); w.ones_row = 1;
         w.Bm = c->DPRE1; w.ldb = S; w.N = S;
         w.out = grads + c->fin1_k; w.ldw = S; w.bias_out = grads + c->fin1_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-        if ((rc = launch_wgrad(c, w, side))) return rc;
+        if ((rc = launch_wgrad(c, w, wst))) return rc;
     }
-    // ---- weight gradients of the stack, each kind for ALL layers in one grouped launch (wn_wgrad.h)
-    bool grouped, fused;
-    { WgBatchArgs w; wgrad_w1_args(c, w, 0, 1, c->fB, c->fT); grouped = wn_wgrad_v2_ok(w);
-      wgrad_skipout_args(c, w, 0, 1, c->fB, c->fT); fused = wn_wgrad_v2_ok(w) && c->S % 8 == 0;     // N = S + R (256 for the 128-channel default hparams)
-      if (!fused) { wgrad_skip_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w);
-                    wgrad_out_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w); } }
-    for (int l0 = 0; grouped && l0 < L; l0 += WN_MAX_GROUPS) {
-        const int ng = min(WN_MAX_GROUPS, L - l0);
-        {   // d [W_dil; W_cin], d biases:  A = [xd(t-2d) | xd(t-d) | xd(t) | c(t)],  B = d z
-            WgBatchArgs w; wgrad_w1_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
-            if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+    // ---- weight gradients of the stack, each kind for all layers of a bucket in one grouped launch (wn_wgrad.h)
+    for (int k = 0; k < nearly; ++k) {
+        if (k > 0) {
+            WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[0][k], 0));
+            if (c->parts == 2) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[1][k], 0));
         }
-        if (fused) {
-            // d W_skip (scaled by the legacy factor c_l) and d W_out with their biases in ONE launch: A = u_l, B = [d skip | rho dL/dh_{l+1}]
-            WgBatchArgs w; wgrad_skipout_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
-            if ((rc = launch_wgrad_batch(c, w, st))) return rc;
-        } else {
-            {   // d W_skip (scaled by the legacy factor c_l), d skip bias:  A = u_l,  B = d skip (shared by all layers)
-                WgBatchArgs w; wgrad_skip_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
-                if ((rc = launch_wgrad_batch(c, w, st))) return rc;
-            }
-            const int ngo = min(ng, L - 1 - l0);      // the top layer's residual branch is dead: zero gradient
-            if (ngo > 0) {   // d W_out, d out bias:  A = u_l,  B = rho * dL/dh_{l+1}
-                WgBatchArgs w; wgrad_out_args(c, w, l0, ngo, c->fB, c->fT); w.grads = grads;
-                if ((rc = launch_wgrad_batch(c, w, st))) return rc;
-            }
-        }
+        if ((rc = stack_wgrads(c, grads, c->bucket_lo[k], c->bucket_hi[k] - c->bucket_lo[k], fused, wst))) return rc;
+        WN_HIP(c, hipEventRecord(c->ev_bucket[k], wst));
+    }
+    // ---- after the chain: the lowest layers' weight gradients (weight-gradient stream), and on the second stream everything small
+    // or latency-bound (global-conditioning / input-conv / upsample-net gradients, the d c_up GEMM); disjoint regions of `grads`
+    WN_HIP(c, hipEventRecord(c->ev_w0, st));
+    WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
+    hipStream_t side = st;
+    if (c->parts == 2) {
+        WN_HIP(c, hipEventRecord(c->ev_fork, st));
+        WN_HIP(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+        side = c->st2;
+    }
+    if (grouped) {
+        const int hi = nearly > 0 ? c->bucket_lo[nearly - 1] : L;
+        for (int l0 = 0; l0 < hi; l0 += WN_MAX_GROUPS)
+            if ((rc = stack_wgrads(c, grads, l0, min(WN_MAX_GROUPS, hi - l0), fused, wst))) return rc;
     }
     for (int l = L - 1; !grouped && l >= 0; --l) {      // narrow channel counts (N % 256 != 0): per-layer v1 kernels
         const int d = c->dil[l];
@@ -360,7 +456,7 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
             w.Bm = c->DZ + (size_t)l * NT * G; w.ldb = G; w.N = G;
             w.out = grads + c->lay[l].dil_k; w.ldw = G; w.bias_out = c->lbias ? grads + c->lay[l].dil_b : nullptr; w.bias_out2 = c->lbias ? grads + c->lay[l].cin_b : nullptr;
             w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-            if ((rc = launch_wgrad(c, w, st))) return rc;
+            if ((rc = launch_wgrad(c, w, wst))) return rc;
         }
         {
             WgArgs w; memset(&w, 0, sizeof w);
@@ -368,7 +464,7 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
             w.Bm = c->DSKIP; w.ldb = S; w.N = S;
             w.out = grads + c->lay[l].skip_k; w.ldw = S; w.bias_out = c->lbias ? grads + c->lay[l].skip_b : nullptr;
             w.scale = c->skip_scale[l]; w.B = c->fB; w.T = c->fT;
-            if ((rc = launch_wgrad(c, w, st))) return rc;
+            if ((rc = launch_wgrad(c, w, wst))) return rc;
         }
         if (l != L - 1) {
             WgArgs w; memset(&w, 0, sizeof w);
@@ -376,7 +472,7 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
             w.Bm = gxu; w.ldb = R; w.N = R;
             w.out = grads + c->lay[l].out_k; w.ldw = R; w.bias_out = c->lbias ? grads + c->lay[l].out_b : nullptr;
             w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
-            if ((rc = launch_wgrad(c, w, st))) return rc;
+            if ((rc = launch_wgrad(c, w, wst))) return rc;
         }
     }
     if ((rc = wn_gin_bwd(c, grads, side))) return rc;     // d W_g, d b_g, d embedding table (modules.py:499-508)
@@ -395,5 +491,9 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
         WN_HIP(c, hipEventRecord(c->ev_join, side));
         WN_HIP(c, hipStreamWaitEvent(st, c->ev_join, 0));
     }
+    WN_HIP(c, hipEventRecord(c->ev_w0, wst));
+    WN_HIP(c, hipStreamWaitEvent(st, c->ev_w0, 0));
+    WN_HIP(c, hipEventRecord(c->ev_bucket[WN_MAX_BUCKETS], st));          // everything (incl. the late buckets) is final here
+    c->have_bwd = true;
     return WN_OK;
 }

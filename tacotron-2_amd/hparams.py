@@ -79,9 +79,10 @@ TACOTRON_ONLY = dict(
 
 # ---- keys added by this tree
 MI355 = dict(
-    mi355_steps_per_graph=16,      # synthesis steps captured per hipGraph replay
+    mi355_steps_per_graph=0,       # synthesis path: 0 = the persistent dataflow pipeline (real time at 22.05 kHz) whenever the model fits it, else the
+                                   # launch-per-layer path with 32 steps per hipGraph replay; N > 0 = that path with N steps per replay
     mi355_synthetic_data=False,    # train on LJSpeech-shaped synthetic tensors (no dataset on disk)
-    mi355_compute_dtype='bf16',    # MFMA operand type of the dense contractions (fp32 accumulate)
+    mi355_synthesize_with_ema=False,   # Synthesizer.load: pack the EMA shadow weights instead of the raw ones
 )
 
 

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'csrc', 'libwavenet_mi355.so'))
 
-WN_ABI_VERSION = 2
+WN_ABI_VERSION = 3
 WN_MAX_UPSAMPLE = 8
 INPUT_TYPES = {'raw': 0, 'mulaw': 1, 'mulaw-quantize': 2}
 UPSAMPLE_TYPES = {'NearestNeighbor': 0, '2D': 1, 'SubPixel': 2, '1D': 3, 'Resize': 4}
@@ -43,6 +43,7 @@ class WnConfig(ctypes.Structure):
         ('max_batch', ctypes.c_int32), ('max_time', ctypes.c_int32),
         ('gin_channels', ctypes.c_int32), ('use_speaker_embedding', ctypes.c_int32), ('n_speakers', ctypes.c_int32),
         ('weight_normalization', ctypes.c_int32),
+        ('inference_only', ctypes.c_int32),
     ]
 
 
@@ -80,11 +81,17 @@ def load_library():
         'wn_pack_weights': (ctypes.c_int, [vp, vp, vp]),
         'wn_train_fwd': (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, u64, vp, vp, vp]),
         'wn_train_bwd': (ctypes.c_int, [vp, vp, vp]),
+        'wn_bwd_num_buckets': (ctypes.c_int, [vp]),
+        'wn_bwd_bucket_range': (ctypes.c_int, [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
+        'wn_bwd_wait_bucket': (ctypes.c_int, [vp, i32, vp]),
         'wn_get_upsampled_features': (ctypes.c_int, [vp, vp, vp]),
         'wn_optim_step': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, vp]),
         'wn_learning_rate': (f32, [i32, f32, i64, f32, i64, f32]),
         'wn_synthesize': (ctypes.c_int, [vp, vp, i32, i32, vp, u64, vp, vp, vp, i32, vp]),
         'wn_noise_per_step': (ctypes.c_int, [vp]),
+        'wn_fill_noise': (ctypes.c_int, [vp, vp, i32, i32, u64, vp]),
+        'wn_synth_check': (ctypes.c_int, [vp]),
+        'wn_synth_last_path': (ctypes.c_int, [vp]),
         'wn_sample': (ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         'wn_mulaw': (ctypes.c_int, [vp, vp, i64, vp]),
         'wn_inv_mulaw': (ctypes.c_int, [vp, vp, i64, vp]),
@@ -114,7 +121,7 @@ def exported_symbols():
     return list(load_library()._wn_symbols)
 
 
-def config_from_hparams(hp, max_batch, max_time):
+def config_from_hparams(hp, max_batch, max_time, inference_only=False):
     """hparams (reference keys, hparams.py:187-233, 309-327) -> wn_config."""
     cfg = WnConfig()
     cfg.abi_version = WN_ABI_VERSION
@@ -156,6 +163,7 @@ def config_from_hparams(hp, max_batch, max_time):
     cfg.use_speaker_embedding = int(bool(getattr(hp, 'use_speaker_embedding', True))) if cfg.gin_channels > 0 else 0
     cfg.n_speakers = int(getattr(hp, 'n_speakers', 0) or 0)
     cfg.weight_normalization = int(bool(getattr(hp, 'wavenet_weight_normalization', False)))      # hparams.py:323
+    cfg.inference_only = int(bool(inference_only))
     return cfg
 
 
@@ -182,9 +190,10 @@ def _check(t, dtype, name):
 class Engine:
     """One wn_ctx: owns packed weights + workspace on the current device."""
 
-    def __init__(self, hp, max_batch, max_time):
+    def __init__(self, hp, max_batch, max_time, inference_only=False):
+        """inference_only: synthesis-only context (no training workspace, every synthesis buffer pre-sized: wn_config.inference_only)."""
         self.lib = load_library()
-        self.cfg = config_from_hparams(hp, max_batch, max_time)
+        self.cfg = config_from_hparams(hp, max_batch, max_time, inference_only)
         h = ctypes.c_void_p()
         rc = self.lib.wn_create(ctypes.byref(self.cfg), ctypes.byref(h))
         if rc != 0:
@@ -260,6 +269,19 @@ class Engine:
         _check(grads, torch.float32, 'grads')
         self._ok(self.lib.wn_train_bwd(self.h, _ptr(grads), _stream()))
 
+    def grad_buckets(self):
+        """[(offset, count)] of the pieces in which train_bwd completes the flat gradient buffer (top layers first)."""
+        out = []
+        off, cnt = ctypes.c_int64(), ctypes.c_int64()
+        for i in range(int(self.lib.wn_bwd_num_buckets(self.h))):
+            self._ok(self.lib.wn_bwd_bucket_range(self.h, i, ctypes.byref(off), ctypes.byref(cnt)))
+            out.append((int(off.value), int(cnt.value)))
+        return out
+
+    def wait_bucket(self, i, stream):
+        """Order `stream` (a torch.cuda.Stream) after bucket i of the last train_bwd."""
+        self._ok(self.lib.wn_bwd_wait_bucket(self.h, int(i), ctypes.c_void_p(stream.cuda_stream)))
+
     def optim_step(self, params, grads, m, v, ema, lr, step):
         self._ok(self.lib.wn_optim_step(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(ema),
                                         ctypes.c_float(lr), ctypes.c_int64(step), _stream()))
@@ -267,10 +289,29 @@ class Engine:
     def upsampled_features(self, out):
         self._ok(self.lib.wn_get_upsampled_features(self.h, _ptr(out), _stream()))
 
-    def synthesize(self, c, noise, out_samples, out_raw=None, test_inputs=None, steps_per_graph=16, seed=0):
+    def synthesize(self, c, noise, out_samples, out_raw=None, test_inputs=None, steps_per_graph=0, seed=0):
+        """Enqueue the generation of T = Tc*hop samples for B streams (asynchronous: call synth_check() after synchronising).
+        noise None: drawn on the device from `seed` (Philox4x32-10; fill_noise gives the same stream).  steps_per_graph <= 0: the
+        persistent pipeline when the model fits it, else the launch-per-layer hipGraph path; > 0: that path with this many steps
+        per captured graph."""
         B, Tc = int(c.shape[0]), int(c.shape[-1])
-        self._ok(self.lib.wn_synthesize(self.h, _ptr(c), B, Tc, _ptr(noise), ctypes.c_uint64(seed), _ptr(test_inputs),
+        self._ok(self.lib.wn_synthesize(self.h, _ptr(c), B, Tc, _ptr(noise), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(test_inputs),
                                         _ptr(out_samples), _ptr(out_raw), int(steps_per_graph), _stream()))
+
+    def fill_noise(self, noise, B, T, seed):
+        """The device noise stream of synthesize(noise=None, seed): float32 [T, B, noise_per_step]."""
+        import torch
+        _check(noise, torch.float32, 'noise')
+        self._ok(self.lib.wn_fill_noise(self.h, _ptr(noise), int(B), int(T), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _stream()))
+        return noise
+
+    def synth_check(self):
+        """Wait for the last synthesize of this engine and raise if the pipeline gave up on a hand-off."""
+        self._ok(self.lib.wn_synth_check(self.h))
+
+    @property
+    def synth_path(self):
+        return {0: None, 1: 'graph', 2: 'pipeline'}.get(int(self.lib.wn_synth_last_path(self.h)))
 
     def loss(self, y_hat, y, lengths, shift, loss_out):
         B, T = int(y_hat.shape[0]), int(y_hat.shape[-1])

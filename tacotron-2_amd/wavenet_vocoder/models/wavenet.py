@@ -15,7 +15,7 @@ import torch
 from datasets import audio
 from infolog import log
 from wavenet_vocoder import _ext, util
-from wavenet_vocoder.parallel import allreduce_mean_
+from wavenet_vocoder.parallel import allreduce_mean_buckets_
 from wavenet_vocoder.util import is_mulaw, is_mulaw_quantize, is_scalar_input
 
 from .modules import initialize_parameters, receptive_field_size
@@ -46,26 +46,31 @@ class WaveNet(object):
         self._dist = None
 
     # ------------------------------------------------------------------ construction
-    def build(self, max_batch, max_time, device=None, params=None):
-        """Allocate the engine (packed weights + workspace) and the flat fp32 parameter / optimiser buffers."""
+    def build(self, max_batch, max_time, device=None, params=None, inference_only=False):
+        """Allocate the engine (packed weights + workspace) and the flat fp32 parameter / optimiser buffers.  inference_only: a
+        synthesis-only engine (no training workspace: ~1.5 KB instead of ~45 KB of HBM per (stream x sample))."""
         hp = self._hparams
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = device
         hop = audio.get_hop_size(hp)
         max_time = (int(max_time) + hop - 1) // hop * hop
-        self.engine = _ext.Engine(hp, max_batch, max_time)
+        self.engine = _ext.Engine(hp, max_batch, max_time, inference_only=inference_only)
+        self.inference_only = bool(inference_only)
         self.max_batch, self.max_time = max_batch, max_time
         if params is None:
             params = initialize_parameters(hp, self.engine.layout)
         self.params = params.to(device).contiguous()
         assert self.params.numel() == self.engine.n_params
-        self.grads = torch.zeros_like(self.params)
-        self.adam_m = torch.zeros_like(self.params)
-        self.adam_v = torch.zeros_like(self.params)
+        if inference_only:                                  # synthesis only: no gradient / Adam slots (4 x 55 MB at the paper shape)
+            self.grads = self.adam_m = self.adam_v = torch.zeros(0, device=device)
+        else:
+            self.grads = torch.zeros_like(self.params)
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
         self.ema_params = self.params.clone()                # tf.train.ExponentialMovingAverage shadow (wavenet.py:473)
         self.variables = self.engine.views(self.params)      # name -> tensor view (TF layouts)
-        self.gradients = self.engine.views(self.grads)
+        self.gradients = None if inference_only else self.engine.views(self.grads)
         self._loss_dev = torch.zeros(1, device=device)
         self._dirty = True
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -178,7 +183,7 @@ class WaveNet(object):
             raise RuntimeError('add_optimizer needs a training-mode initialize() first')
         step = self.global_step if global_step is None else int(global_step)
         self.engine.train_bwd(self.grads)
-        allreduce_mean_(self.grads)
+        allreduce_mean_buckets_(self.engine, self.grads)      # per bucket, as soon as it is final: overlaps the rest of the backward
         self.learning_rate = self.learning_rate_at(step)
         self.engine.optim_step(self.params, self.grads, self.adam_m, self.adam_v, self.ema_params, self.learning_rate, step)
         self._dirty = True
@@ -246,15 +251,10 @@ class WaveNet(object):
             self.build(B, T)
         self._ensure_packed()
         dev = c.device
-        nps = self.engine.noise_per_step
-        if noise is None:
-            gen = getattr(self, '_noise_gen', None)
-            if gen is None:
-                gen = torch.Generator(device=dev); gen.manual_seed(int(hp.wavenet_random_seed)); self._noise_gen = gen
-            if hp.out_channels == 2 and self.scalar_input:
-                noise = torch.randn(T, B, nps, device=dev, generator=gen)
-            else:
-                noise = torch.rand(T, B, nps, device=dev, generator=gen) * (1. - 2e-5) + 1e-5        # U(1e-5, 1-1e-5): mixture.py:91,104
+        # noise None: drawn on the device (Philox keyed by (wavenet_random_seed, call counter)): U(1e-5, 1 - 1e-5) as mixture.py:91,104,
+        # standard normal for the Gaussian head (gaussian.py:50), Gumbel uniforms for tf.multinomial (wavenet.py:865)
+        self._synth_calls = getattr(self, '_synth_calls', 0) + 1
+        seed = (int(hp.wavenet_random_seed) << 20) + self._synth_calls
         out = torch.empty(B, T, device=dev, dtype=torch.float32 if self.scalar_input else torch.int32)
         raw = torch.empty(B, hp.out_channels, T, device=dev) if return_raw else None
         ti = None
@@ -262,11 +262,24 @@ class WaveNet(object):
             ti = test_inputs.reshape(B, -1)[:, :T]
             ti = (ti.float() if self.scalar_input else ti.to(torch.int32)).contiguous()
             assert ti.shape[1] == T, 'teacher-forcing inputs must cover the whole synthesis length'
-        self._set_global(g, B)                                                         # wavenet.py:766-777
-        self.engine.synthesize(c.contiguous().float(), noise.contiguous(), out, raw, ti,
-                               steps_per_graph=int(getattr(hp, 'mi355_steps_per_graph', 16)))
+        spg = int(getattr(hp, 'mi355_steps_per_graph', 0))
+        cc = c.contiguous().float()
         feats = torch.empty(B, hp.cin_channels, T, device=dev)
-        self.engine.upsampled_features(feats)
+        # The persistent pipeline (real time at 22.05 kHz) pipelines up to 8 streams per run through its layer ring at the wall time
+        # of one; larger batches go through it in groups of 8 (streams are independent: wavenet.py:237-239 splits them over towers).
+        # Global conditioning / very wide models take the launch-per-layer graph path for the whole batch.
+        group = B if (spg > 0 or g is not None or B <= 8) else 8
+        for b0 in range(0, B, group):
+            b1 = min(B, b0 + group)
+            nz = None if noise is None else noise[:, b0:b1].contiguous()
+            if g is not None:
+                self._set_global(g, B)                                                 # wavenet.py:766-777
+            self.engine.synthesize(cc[b0:b1].contiguous(), nz, out[b0:b1], None if raw is None else raw[b0:b1], None if ti is None else ti[b0:b1].contiguous(),
+                                   steps_per_graph=spg, seed=seed * 64 + b0 // group)
+            self.engine.upsampled_features(feats[b0:b1])
+        if getattr(self, '_logged_synth_path', None) != self.engine.synth_path:
+            self._logged_synth_path = self.engine.synth_path
+            log('WaveNet synthesis path: {} ({} streams per run)'.format(self.engine.synth_path, group))
         self.upsampled_local_features = feats
         return (out, raw) if return_raw else out
 
@@ -278,6 +291,8 @@ class WaveNet(object):
 
     def load_state_dict(self, sd):
         for name, dst in (('params', self.params), ('ema', self.ema_params), ('adam_m', self.adam_m), ('adam_v', self.adam_v)):
+            if getattr(self, 'inference_only', False) and name.startswith('adam'):
+                continue
             src = sd[name]
             if src.numel() != dst.numel():
                 raise ValueError('checkpoint tensor %s has %d elements, model expects %d' % (name, src.numel(), dst.numel()))

@@ -44,7 +44,9 @@ class Synthesizer(object):
             self.model.engine.close()
             self.model.engine = None
         cap = (max(batch, self._capacity[0]), max(time_steps, self._capacity[1]))
-        self.model.build(cap[0], cap[1])
+        # synthesis-only engine: no saved-activation / backward workspace (that is ~45 KB of HBM per (stream x sample) at the paper
+        # shape, i.e. ~180 GB for the default 20 x 9 s batch; what synthesis needs is ~1.5 KB) and every buffer pre-sized
+        self.model.build(cap[0], cap[1], inference_only=True)
         if self._tf_prefix is not None:
             from wavenet_vocoder.tf_checkpoint import load_reference_checkpoint
             flat, step, missing = load_reference_checkpoint(self._tf_prefix, self.model.engine.layout)
@@ -88,6 +90,7 @@ class Synthesizer(object):
         # c: [B, Tc, num_mels] like the reference's placeholder; the model transposes it (wavenet.py:427)
         self.model.initialize(None, torch.from_numpy(c_batch).to(dev), None if g is None else g.to(dev), None, test_inputs=test_inputs)
         torch.cuda.synchronize()
+        self.model.engine.synth_check()           # the generation is enqueued asynchronously: a pipeline hand-off timeout surfaces here
         generated = self.model.tower_y_hat[0].float().cpu().numpy()
         feats = self.model.tower_synth_upsampled_local_features[0].cpu().numpy()
         generated_wavs = [w[:length] for w, length in zip(generated, audio_lengths)]

@@ -201,3 +201,41 @@ def test_c5_width_full_depth():
     """BASELINE configs[4] shape: 30 layers / 3 stacks, R = S = 512, G = 1024, Gaussian, SubPixel [15, 20], legacy scalings."""
     r = _case(C5, 2, 12000, [12000, 12000], [0, 9, 10, 29], report='c5_b2')
     _assert_case(r)
+
+
+def test_gradient_buckets_are_final_when_their_event_fires():
+    """wn_bwd_num_buckets / _bucket_range / _wait_bucket (data-parallel overlap): the table is disjoint and covers the whole flat
+    buffer; a side stream that waits for bucket i only and snapshots its range sees exactly the bytes the finished backward leaves
+    there (the bucket is FINAL at its event, while the layers below are still being computed), at the bench geometry."""
+    from wavenet_vocoder import _ext
+    hp = make_hp(**PAPER)
+    cfg = oracle_cfg(hp)
+    B, T = 4, 11000
+    eng = _ext.Engine(hp, B, T)
+    params = O.init_params(cfg, seed=5339, bias_scale=0.05)
+    eng.pack_weights(upload_params(eng, params))
+    buckets = eng.grad_buckets()
+    assert len(buckets) >= 4
+    cover = np.zeros(eng.n_params, dtype=np.int32)
+    for off, n in buckets:
+        cover[off:off + n] += 1
+    assert cover.min() == 1 and cover.max() == 1                       # disjoint + covering
+    assert buckets[0][0] > buckets[1][0] > buckets[2][0]                # top layers first
+    wav, c = synth_batch(cfg, B, T, seed=5)
+    x = wav.view(B, 1, T).contiguous().cuda(); y = wav.view(B, T, 1).contiguous().cuda()
+    ln = torch.full((B,), T, dtype=torch.int32, device='cuda'); loss = torch.zeros(1, device='cuda')
+    grads = torch.empty(eng.n_params, device='cuda')
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        eng.train_fwd(x, c.cuda(), y, ln, 77 + rep, loss)
+        grads.fill_(float('nan'))
+        eng.train_bwd(grads)
+        snaps = []
+        for i, (off, n) in enumerate(buckets):
+            eng.wait_bucket(i, side)
+            with torch.cuda.stream(side):
+                snaps.append(grads[off:off + n].clone())
+        torch.cuda.synchronize()
+        for (off, n), s in zip(buckets, snaps):
+            assert torch.isfinite(s).all()
+            assert torch.equal(s, grads[off:off + n])

@@ -192,6 +192,49 @@ def test_data_parallel_gradient_mean_gloo(tmp_path):
         assert p.returncode == 0 and 'rank ok' in o, o[-2000:]
 
 
+_BUCKET_WORKER = r'''
+import sys, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/tacotron-2_amd')
+import torch.distributed as dist
+from wavenet_vocoder.parallel import allreduce_mean_buckets_, allreduce_mean_
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=int(sys.argv[1]), world_size=2)
+class FakeEngine:                       # the engine's bucket interface (wn_bwd_num_buckets / _range / _wait_bucket) without a GPU
+    def __init__(self, buckets): self.buckets = buckets; self.waited = []
+    def grad_buckets(self): return list(self.buckets)
+    def wait_bucket(self, i, stream): self.waited.append(i)
+n = 1000
+# the shape of the real table: top layers (+ head) first, ..., [0, lowest layers), tail; disjoint, covering, NOT in address order
+buckets = [(600, 300), (400, 200), (200, 200), (0, 200), (900, 100)]
+g = torch.Generator().manual_seed(int(sys.argv[1]) + 1)
+mine = torch.randn(n, generator=g)
+other = torch.randn(n, generator=torch.Generator().manual_seed(2 - int(sys.argv[1])))
+flat = mine.clone()
+eng = FakeEngine(buckets)
+allreduce_mean_buckets_(eng, flat)
+assert eng.waited == [0, 1, 2, 3, 4], eng.waited                       # every bucket gated on ITS event, in completion order
+assert torch.allclose(flat, (mine + other) / 2, atol=1e-7)
+ref = mine.clone(); allreduce_mean_(ref)
+assert torch.equal(flat, ref)                                          # identical to the single flat collective
+try:
+    allreduce_mean_buckets_(FakeEngine(buckets[:-1]), mine.clone()); raise SystemExit('a hole in the bucket table went unnoticed')
+except RuntimeError: pass
+dist.barrier(); dist.destroy_process_group()
+print('rank ok')
+'''
+
+
+def test_bucketed_gradient_allreduce_gloo(tmp_path):
+    """The product's bucket walk (WaveNet.add_optimizer -> parallel.allreduce_mean_buckets_) on two gloo ranks with a stand-in for
+    the engine's bucket table: same result as one flat all-reduce, one wait per bucket, holes in the table are detected."""
+    port = 31500 + (os.getpid() % 2000)
+    script = tmp_path / 'bucket_worker.py'
+    script.write_text(_BUCKET_WORKER % {'root': ROOT, 'port': port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and 'rank ok' in o, o[-2000:]
+
+
 def test_host_formats_match_reference_execution(golden_dir, tmp_path):
     """Batch assembly, learning-rate schedules, wav writer and hop size against golden vectors produced by executing the
     reference's own feeder.py / wavenet.py / datasets/audio.py (oracle/gen_golden_host.py)."""
