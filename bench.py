@@ -194,27 +194,79 @@ def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8)):
         T = Tc * hop
         for B in batches:
             _log('synthesis %s B=%d T=%d' % (mode, B, T))
-            eng = _ext.Engine(hp, B, T)
+            eng = _ext.Engine(hp, B, T, inference_only=True)       # synthesis-only context: pre-sized, ~1.5 KB of HBM per (stream x sample)
             eng.pack_weights(eng_params_flat)
-            nps = eng.noise_per_step
             c = torch.rand(B, hp.cin_channels, Tc, device=device)
-            noise = (torch.rand(T, B, nps, device=device) * 0.98 + 0.01) if hp.out_channels != 2 else torch.randn(T, B, nps, device=device)
             samples = torch.empty(B, T, device=device)
+            # sampling noise is drawn on the device (noise = None: Philox keyed by the seed); nothing is uploaded
             if mode == 'graph':
-                eng.synthesize(c, noise, samples, None, None, steps_per_graph=spg)      # warm-up + graph build
+                eng.synthesize(c, None, samples, None, None, steps_per_graph=spg, seed=1)      # warm-up + graph build
             else:
                 cw = c[:, :, :8].contiguous(); Tw = 8 * hop                            # short warm-up (weight slices, LDS images)
-                eng.synthesize(cw, noise[:Tw].contiguous(), torch.empty(B, Tw, device=device), None, None, steps_per_graph=0)
-            torch.cuda.synchronize()
+                eng.synthesize(cw, None, torch.empty(B, Tw, device=device), None, None, steps_per_graph=0, seed=1)
+            torch.cuda.synchronize(); eng.synth_check()
             t0 = time.time()
-            eng.synthesize(c, noise, samples, None, None, steps_per_graph=spg)
+            eng.synthesize(c, None, samples, None, None, steps_per_graph=spg, seed=2)
             torch.cuda.synchronize()
             dt = time.time() - t0
-            out['%s_B%d' % (mode, B)] = {'seconds_of_audio_per_stream': T / hp.sample_rate, 'wall_s': dt,
+            eng.synth_check()
+            wbytes = 2.0 * sum(int(np.prod(sh)) for sh, _ in eng.layout.values())     # bf16 weights every stream-step multiplies
+            out['%s_B%d' % (mode, B)] = {'seconds_of_audio_per_stream': T / hp.sample_rate, 'wall_s': dt, 'path': eng.synth_path,
                                         'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt,
-                                        'us_per_step': dt / T * 1e6, 'finite': bool(torch.isfinite(samples).all().item())}
+                                        'us_per_step': dt / T * 1e6, 'deadline_us': 1e6 / hp.sample_rate,
+                                        # synthesis roofline: latency-bound; the bandwidth that matters is the weight re-read rate,
+                                        # served from LDS (pipeline: weights stay resident in 8 x 24 + 1 CUs) or L2 (graph path)
+                                        'weight_reread_GBps': wbytes * B * T / dt / 1e9, 'stream_tflops': 2.0 * mac_per_sample(hp) * B * T / dt / 1e12,
+                                        'workspace_MB': eng.lib.wn_workspace_bytes(eng.h) / 1e6,
+                                        'finite': bool(torch.isfinite(samples).all().item())}
             eng.close()
     return out
+
+
+class SmiSampler:
+    """rocm-smi power / clock samples while a block runs (one subprocess call per ~second, in a thread).  Best effort: any failure
+    just leaves the lists empty."""
+
+    def __init__(self, device_index=0):
+        import threading
+        self.idx, self.power, self.sclk, self._stop = device_index, [], [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                r = subprocess.run(['rocm-smi', '-d', str(self.idx), '--showpower', '--showclocks'], capture_output=True, text=True, timeout=10)
+                m = re.search(r'(?:Average|Current Socket) Graphics Package Power \(W\):\s*([0-9.]+)', r.stdout)
+                if m:
+                    self.power.append(float(m.group(1)))
+                m = re.search(r'sclk clock level:.*?\((\d+)Mhz\)', r.stdout)
+                if m:
+                    self.sclk.append(float(m.group(1)))
+            except Exception:
+                pass
+            self._stop.wait(0.5)
+
+    def __enter__(self):
+        self._t.start(); return self
+
+    def __exit__(self, *a):
+        self._stop.set(); self._t.join(timeout=15)
+
+    def summary(self):
+        out = {'samples': len(self.power)}
+        if self.power:
+            out.update(power_w_mean=float(np.mean(self.power)), power_w_max=float(np.max(self.power)))
+        if self.sclk:
+            out.update(sclk_mhz_mean=float(np.mean(self.sclk)), sclk_mhz_min=float(np.min(self.sclk)))
+        return out
+
+
+# HBM-side traffic of one C2 training step, ALL kernels: sum over the kernels of (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3
+# PMC passes of this round (separate passes; FETCH_SIZE doubled as the gfx950 calibration in DESIGN 4 prescribes), per step.
+STEP_TRAFFIC_BYTES = {'c2': None}
+STEP_TRAFFIC_SOURCE = 'profiles/r2_pmc_fetch.md + profiles/r2_pmc_write.md'
 
 
 def main():
@@ -226,6 +278,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-synth', action='store_true')
     ap.add_argument('--no-exclusive', action='store_true', help='skip the untimed single-stream pass (keeps a rocprofv3 trace to the timed configuration)')
+    ap.add_argument('--sustained', type=int, default=100, help='steps per block of the untimed-by-contract sustained measurement (3 blocks after the timed region; 0 = off)')
     ap.add_argument('--batch', type=int, default=None, help='override per-GPU batch (debug)')
     ap.add_argument('--time', type=int, default=None, help='override T (debug)')
     args = ap.parse_args()
@@ -290,6 +343,29 @@ def main():
     _log('timed region done: %.1f ms/step' % (dt / args.steps * 1e3))
     prof_ms, prof_n = eng.profile_result()
     rows_launch = eng.profile_rows_per_launch()
+    eng.profile(False)
+    # ---- sustained view (>= 20 warm-up, >= 100 timed steps, median of 3): the contract's timed region above may be a
+    # fraction of a second (power and clocks have not settled); this block is NOT the headline `value`, it is reported next to it
+    sustained = None
+    if args.sustained > 0:
+        blocks = []
+        with SmiSampler(local_rank) as smi:
+            step_i = args.warmup + args.steps
+            for _ in range(3):
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                tb = time.time()
+                for _i in range(args.sustained):
+                    one_step(step_i); step_i += 1
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                blocks.append((time.time() - tb) / args.sustained * 1e3)
+        med = float(np.median(blocks))
+        sustained = {'what': '3 blocks x %d steps right after the timed region, same step function; median block' % args.sustained,
+                     'ms_per_step_blocks': blocks, 'ms_per_step': med, 'value': world * B * T / (med * 1e-3), 'unit': 'audio_samples/s', 'smi': smi.summary()}
+        _log('sustained: %s ms/step' % ', '.join('%.2f' % b for b in blocks))
     # untimed extra: the same kernel with the GPU to itself (whole batch on one stream), for the kernel-quality view
     excl_ms, excl_n, excl_rows = 0.0, 0, 0
     if not args.no_exclusive:
@@ -344,7 +420,11 @@ def main():
                                    'frac': (2.0 * G * (3 * R + C) * excl_rows / (excl_ms / max(excl_n, 1) * 1e-3) / 1e12 / peak) if excl_n else None},
             # whole-step view asked for by the north star: SURVEY 8d algorithmic HBM bytes per audio sample (bf16) x samples/s vs 8 TB/s
             'hbm_roofline_whole_step': {'alg_bytes_per_sample': alg_bytes_per_sample(hp), 'achieved_GBps': alg_bytes_per_sample(hp) * value / world / 1e9,
-                                        'peak_GBps': 8000.0, 'frac': alg_bytes_per_sample(hp) * value / world / 8e12},
+                                        'peak_GBps': 8000.0, 'frac': alg_bytes_per_sample(hp) * value / world / 8e12,
+                                        'alg_bytes_per_step': alg_bytes_per_sample(hp) * B * T,
+                                        'traffic_per_step': STEP_TRAFFIC_BYTES.get(args.workload) if (B, T) == (8, 11000) else None,
+                                        'traffic_source': STEP_TRAFFIC_SOURCE + ': sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE per step'},
+            'sustained': sustained,
         }
         if not args.no_synth and world == 1:      # replicas-only path: measured on one GPU, not while the other ranks wait
             _log('synthesis measurement ...')

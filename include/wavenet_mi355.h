@@ -94,6 +94,10 @@ typedef struct wn_config {
      * synthesis buffer for (max_batch, max_time), so wn_synthesize never allocates.  wn_train_* / wn_optim_step return WN_E_STATE.
      * A training context (0) can still synthesise (eval steps); it allocates its synthesis state on the first wn_synthesize. */
     int32_t inference_only;
+    /* Data-parallel training: number of pieces in which wn_train_bwd completes the layer stack's gradients (wn_bwd_*bucket*), so that
+     * the caller can all-reduce one piece while the next is computed.  <= 1 (single GPU): everything is final when the call ends and
+     * the weight gradients run after the backward chain (measured 1.5 % faster than overlapping them when there is nothing to hide). */
+    int32_t grad_buckets;
 } wn_config;
 
 typedef struct wn_ctx wn_ctx;
@@ -173,7 +177,7 @@ float wn_learning_rate(int32_t schedule, float init_lr, int64_t step, float deca
  * noise       float [T, B, noise_per_step]: MoL: M uniforms u1 then 1 uniform u2 (mixture.py:91,104);
  *             Gaussian: 1 standard-normal draw (gaussian.py:50); softmax: Q uniforms (Gumbel-max form of
  *             tf.multinomial, wavenet.py:865).  NULL => drawn on the device: Philox4x32-10 keyed by `seed`, counter = the element
- *             index of this [T, B, noise_per_step] layout (uniforms in (1e-5, 1 - 1e-5) as mixture.py:91,104; Gaussian draws by
+ *             index of this [T, B, noise_per_step] layout (24-bit uniforms clamped to [1e-5, 1 - 1e-5], mixture.py:91,104; Gaussian draws by
  *             Box-Muller) into a ctx-owned buffer -- replaces tf.random_uniform / Normal.sample / tf.multinomial's own generator;
  *             wn_fill_noise exposes the same stream so that a run can be reproduced with an explicit buffer.
  * test_inputs optional teacher forcing (wavenet.py:877-878): float [B,T] (scalar) / int32 [B,T] ids.

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 REF = '/root/reference'
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+OUT = os.environ.get('WN_GOLDEN_DIR') or os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')      # WN_GOLDEN_DIR: write elsewhere (regen check of __graft_entry__.regen_golden)
 
 
 class _Recorder:

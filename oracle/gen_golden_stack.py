@@ -27,7 +27,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = '/root/reference'
-OUT = os.path.join(ROOT, 'tests', 'golden')
+OUT = os.environ.get('WN_GOLDEN_DIR') or os.path.join(ROOT, 'tests', 'golden')      # WN_GOLDEN_DIR: write elsewhere (regen check of __graft_entry__.regen_golden)
 
 sys.path.insert(0, ROOT)
 from oracle import tf1_shim as shim  # noqa: E402

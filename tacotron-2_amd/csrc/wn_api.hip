@@ -129,7 +129,7 @@ static int alloc_workspace(wn_ctx* c) {
     sz(NT * c->C * 2);                     // cbt
     sz((size_t)(L) * NT * c->R * 2);       // X[0..L-1]
     if (c->cfg.dropout > 0.0f) sz((size_t)(L) * NT * c->R * 2);   // XD
-    sz((size_t)L * NT * c->G * 2);         // TS
+    sz((size_t)L * NT * c->GH * 2);        // TS: sigmoid half of the gate (tanh is recovered from u in the backward)
     sz((size_t)L * NT * c->GH * 2);        // U
     sz(NT * c->S * 2); sz(NT * c->S * 2);  // R1, H2
     sz(NT * ldDY * 2);                     // DY
@@ -150,7 +150,7 @@ static int alloc_workspace(wn_ctx* c) {
     c->cbt = (bf16_t*)bump(p, NT * c->C * 2);
     c->X = (bf16_t*)bump(p, (size_t)L * NT * c->R * 2);
     c->XD = (c->cfg.dropout > 0.0f) ? (bf16_t*)bump(p, (size_t)L * NT * c->R * 2) : c->X;
-    c->TS = (bf16_t*)bump(p, (size_t)L * NT * c->G * 2);
+    c->TS = (bf16_t*)bump(p, (size_t)L * NT * c->GH * 2);
     c->U = (bf16_t*)bump(p, (size_t)L * NT * c->GH * 2);
     c->R1 = (bf16_t*)bump(p, NT * c->S * 2); c->H2 = (bf16_t*)bump(p, NT * c->S * 2);
     c->DY = (bf16_t*)bump(p, NT * ldDY * 2);
@@ -422,7 +422,7 @@ extern "C" int wn_debug_copy(wn_ctx* c, const char* name, int32_t layer, float* 
     std::string s = name;
     if (s == "cbt") b = c->cbt;
     else if (s == "X") b = c->X + (size_t)layer * NT * c->R;
-    else if (s == "TS") b = c->TS + (size_t)layer * NT * c->G;
+    else if (s == "TS") b = c->TS + (size_t)layer * NT * c->GH;      // sigmoid [rows][G/2]
     else if (s == "U") b = c->U + (size_t)layer * NT * c->GH;
     else if (s == "R1") b = c->R1;
     else if (s == "H2") b = c->H2;

@@ -1157,7 +1157,7 @@ __host__ __device__ inline void wn_philox4x32_10(uint32_t c0, uint32_t c1, uint3
     }
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
-// 24 random bits -> (0, 1) open at both ends -> the reference's clipping range (1e-5, 1 - 1e-5)
+// 24 random bits -> (0, 1) open at both ends, then clamped to the reference's range [1e-5, 1 - 1e-5] (mixture.py:91,104)
 __host__ __device__ inline float wn_u01(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 __global__ void wn_noise_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1, int gaussian) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1173,7 +1173,7 @@ __global__ void wn_noise_kernel(float* __restrict__ out, int64_t n, uint32_t k0,
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = wn_u01(w[j]) * (1.0f - 2e-5f) + 1e-5f;
+        for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(wn_u01(w[j]), 1e-5f), 1.0f - 1e-5f);     // exact ops only (no rounding: any compiler, and the numpy mirror, give the same bits)
     }
     if (g * 4 + 3 < n) *reinterpret_cast<float4*>(out + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
     else for (int j = 0; j < 4 && g * 4 + j < n; ++j) out[g * 4 + j] = v[j];

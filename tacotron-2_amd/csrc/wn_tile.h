@@ -70,6 +70,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.442695041f)); }
+// The forward saves sigmoid(b) and u = tanh(a) * sigmoid(b) (both bf16); the backward needs tanh(a) only inside (1 - tanh^2), the other
+// factor being tanh * sigmoid = u exactly.  tanh = u / sigmoid: well conditioned wherever the gradient is not already ~0 (sigmoid is never
+// near 0 unless the unit is shut, where d a = g * sigmoid * (...) vanishes with it); clamped to [-1, 1]; 0 when sigmoid underflowed.
+// Saves one of the three [rows][G/2] tensors the gate would write (and the backward read): 512 B of 1.5 KB per row and layer at R = 256.
+__device__ __forceinline__ float gate_tanh_from(float u, float s) {
+    const float t = u * __builtin_amdgcn_rcpf(s);
+    return s > 0.0f ? fminf(fmaxf(t, -1.0f), 1.0f) : 0.0f;
+}
 
 __device__ __forceinline__ bool drop_keep(uint32_t key_lo, uint32_t key_hi, uint32_t thresh16, uint32_t e) {
     uint32_t w = wn_drop_word(key_lo, key_hi, e >> 1);
@@ -130,8 +138,8 @@ __device__ __forceinline__ void wn_tile_epilogue(const GemmArgs& a, f32x16_t (&a
                     float zb = acc[MT - 1][j][qd * 4 + r] + gb[e.GH + g + r];
                     ta[r] = fast_tanh(za); sgm[r] = fast_sigmoid(zb); u[r] = ta[r] * sgm[r];
                 }
-                *reinterpret_cast<uint2*>(TS + row * e.ld_out0 + g) = make_uint2(pack_bf2(ta[0], ta[1]), pack_bf2(ta[2], ta[3]));
-                *reinterpret_cast<uint2*>(TS + row * e.ld_out0 + e.GH + g) = make_uint2(pack_bf2(sgm[0], sgm[1]), pack_bf2(sgm[2], sgm[3]));
+                // saved for backward: sigmoid and the gate output u = tanh * sigmoid; tanh itself is recovered as u / sigmoid (EPI_DGATE)
+                *reinterpret_cast<uint2*>(TS + row * e.ld_out0 + g) = make_uint2(pack_bf2(sgm[0], sgm[1]), pack_bf2(sgm[2], sgm[3]));
                 *reinterpret_cast<uint2*>(U + row * e.ld_out1 + g) = make_uint2(pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3]));
             }
         } else {
@@ -181,16 +189,16 @@ __device__ __forceinline__ void wn_tile_epilogue(const GemmArgs& a, f32x16_t (&a
                             }
                         }
                     } else if constexpr (EPI == EPI_DGATE) {
-                        const bf16_t* TS = (const bf16_t*)e.in0;
-                        uint2 xa = *reinterpret_cast<const uint2*>(TS + row * e.ld_in0 + m);
-                        uint2 xb = *reinterpret_cast<const uint2*>(TS + row * e.ld_in0 + e.GH + m);
-                        float ta[4] = {bf2f((bf16_t)(xa.x & 0xffff)), bf2f((bf16_t)(xa.x >> 16)), bf2f((bf16_t)(xa.y & 0xffff)), bf2f((bf16_t)(xa.y >> 16))};
+                        uint2 xa = *reinterpret_cast<const uint2*>((const bf16_t*)e.in1 + row * e.ld_in0 + m);      // u = tanh * sigmoid
+                        uint2 xb = *reinterpret_cast<const uint2*>((const bf16_t*)e.in0 + row * e.ld_in0 + m);      // sigmoid
+                        float uu[4] = {bf2f((bf16_t)(xa.x & 0xffff)), bf2f((bf16_t)(xa.x >> 16)), bf2f((bf16_t)(xa.y & 0xffff)), bf2f((bf16_t)(xa.y >> 16))};
                         float sg[4] = {bf2f((bf16_t)(xb.x & 0xffff)), bf2f((bf16_t)(xb.x >> 16)), bf2f((bf16_t)(xb.y & 0xffff)), bf2f((bf16_t)(xb.y >> 16))};
                         float da[4], db[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            da[r] = v[r] * sg[r] * (1.0f - ta[r] * ta[r]);
-                            db[r] = v[r] * ta[r] * sg[r] * (1.0f - sg[r]);
+                            const float ta = gate_tanh_from(uu[r], sg[r]);
+                            da[r] = v[r] * sg[r] * (1.0f - ta * ta);
+                            db[r] = v[r] * uu[r] * (1.0f - sg[r]);
                         }
                         bf16_t* DZ = (bf16_t*)e.out0;
                         *reinterpret_cast<uint2*>(DZ + row * e.ld_out0 + m) = make_uint2(pack_bf2(da[0], da[1]), pack_bf2(da[2], da[3]));
@@ -400,7 +408,7 @@ template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 
 __global__ __launch_bounds__(WM * WN * 64, (lds_gemm_min_waves(MT, NT, WM, WN, BK, NBUF)))
 void wn_gemm_lds_kernel(const GemmArgs a) {
     using Cfg = LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>;
-    static_assert(TAPS == 0 || (TAPS == 3 && NBUF == 3 && PIPE <= 1), "interleaved taps: the tap of a chunk is its ring slot (ring depth 3 == 3 taps)");
+    static_assert(TAPS == 0 || (TAPS == 3 && NBUF == 3 && (PIPE <= 1 || PIPE >= 6)), "interleaved taps: the tap of a chunk is its ring slot (ring depth 3 == 3 taps)");
     __shared__ __attribute__((aligned(1024))) char lds[Cfg::LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -593,8 +601,27 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         }
     };
 
+    // PIPE 6 / 7: the two halves of the workgroup (waves [0, NW/2) and [NW/2, NW): one wave of each half per SIMD) run HALF A
+    // CHUNK APART.  After the barrier of chunk ch the early half requests its fragments of chunk ch and issues the DMAs of chunk
+    // ch+2 while the late half multiplies the fragments of chunk ch-1 it already holds; then the early half multiplies chunk ch
+    // while the late half reads chunk ch and issues its DMAs.  On every SIMD a matrix-bound wave thus sits beside a memory-bound
+    // one instead of two waves fighting for the matrix pipe and then idling together.  Same k order per wave: bitwise-identical sums.
+    constexpr bool SPLIT = (PIPE >= 6);
+    const bool late = SPLIT && wave >= Cfg::NW / 2;
+    bf16x8_t haf[SPLIT ? Cfg::KS : 1][MT], hbf[SPLIT ? Cfg::KS : 1][NT];
+    auto mfma_held = [&]() {
+        if constexpr (PIPE == 7) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < (SPLIT ? Cfg::KS : 1); ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(haf[ks][i], hbf[ks][j], acc[i][j], 0, 0, 0);
+        if constexpr (PIPE == 7) __builtin_amdgcn_s_setprio(0);
+    };
     // one ring step: chunk `ch` lives in buffer BUF; chunk ch+NBUF-1 is DMA'd into the buffer freed by chunk ch-1
-    auto ring_step = [&](auto bufc, int ch) {
+    auto ring_step = [&](auto bufc, int ch, auto latec) {
         constexpr int BUF = decltype(bufc)::value;
         // all DMAs except those of the (NBUF-2) youngest chunks have landed
         const int younger = min(NBUF - 2, nchunks - 1 - ch);
@@ -604,6 +631,35 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         if constexpr (PIPE == 0) {
             if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
             compute(bufc);
+        } else if constexpr (SPLIT) {
+            const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+            auto read_held = [&]() {
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        haf[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        hbf[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+                }
+            };
+            if constexpr (decltype(latec)::value) {
+                mfma_held();                                 // late half: chunk ch-1 (zeros before the first chunk), fragments read before the barrier
+                __builtin_amdgcn_sched_barrier(0);
+                read_held();
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+                // the next barrier releases this buffer to the DMA of chunk ch+3: the reads just issued must have returned by then
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                read_held();
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_held();                                 // early half: chunk ch
+            }
         } else {
             // PIPE 1: every fragment of the chunk is requested from LDS straight after the barrier, the DMA issue + iterator
             // bookkeeping of the next chunk runs while those reads are in flight, then the chunk's MFMAs go back to back.
@@ -641,7 +697,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     };
     static_assert(NBUF == 2 || NBUF == 3 || (NBUF == 4 && PIPE >= 2), "ring depth");
 
-    if constexpr (PIPE >= 2) {
+    if constexpr (PIPE >= 2 && PIPE < 6) {
         // PIPE 2: fragments are requested from LDS one k-step AHEAD of the MFMAs that use them (two register sets), across
         // chunk boundaries too, so no MFMA ever waits on a read it has just issued.  Reading chunk ch+1 while chunk ch is still
         // being multiplied needs chunk ch+1 landed one step early: the ring keeps {ch, ch+1, DMA target ch+2}, i.e. the DMA
@@ -736,11 +792,27 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     // prologue: fill NBUF-1 buffers
     stage(std::integral_constant<int, 0>{});
     if constexpr (NBUF == 3) { if (nchunks > 1) stage(std::integral_constant<int, 1>{}); }
-    for (int ch = 0; ch < nchunks; ch += NBUF) {
-        ring_step(std::integral_constant<int, 0>{}, ch);
-        if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1);
-        if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2); }
-    }
+    auto main_loop = [&](auto latec) {
+        for (int ch = 0; ch < nchunks; ch += NBUF) {
+            ring_step(std::integral_constant<int, 0>{}, ch, latec);
+            if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1, latec);
+            if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2, latec); }
+        }
+    };
+    if constexpr (SPLIT) {
+        // two copies of the loop (wave-uniform scalar branch): inside each the instruction order is fixed, nothing merges per chunk
+        if (late) {
+#pragma unroll
+            for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) haf[ks][i] = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) hbf[ks][j] = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+            }
+            main_loop(std::true_type{});
+            mfma_held();                                  // the late half still owes the last chunk
+        } else main_loop(std::false_type{});
+    } else main_loop(std::false_type{});
     }
 
 #ifdef WN_EPI_ABLATE
@@ -795,16 +867,16 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                     const float4 a0 = *reinterpret_cast<const float4*>(lds + rl * PITCH + ml * 4), a1 = *reinterpret_cast<const float4*>(lds + rl * PITCH + ml * 4 + 16);
                     const float4 b0 = *reinterpret_cast<const float4*>(lds + rl * PITCH + (ml + 32) * 4), b1 = *reinterpret_cast<const float4*>(lds + rl * PITCH + (ml + 32) * 4 + 16);
                     const float za[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, zb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                    uint32_t pt[4], ps[4], pu[4];
+                    uint32_t ps[4], pu[4];
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const float t0_ = fast_tanh(za[2 * p] + gb[g + 2 * p]), t1_ = fast_tanh(za[2 * p + 1] + gb[g + 2 * p + 1]);
                         const float s0_ = fast_sigmoid(zb[2 * p] + gb[e.GH + g + 2 * p]), s1_ = fast_sigmoid(zb[2 * p + 1] + gb[e.GH + g + 2 * p + 1]);
-                        pt[p] = pack_bf2(t0_, t1_); ps[p] = pack_bf2(s0_, s1_); pu[p] = pack_bf2(t0_ * s0_, t1_ * s1_);
+                        ps[p] = pack_bf2(s0_, s1_); pu[p] = pack_bf2(t0_ * s0_, t1_ * s1_);
                     }
                     const int64_t row = rowbase + t;
-                    *reinterpret_cast<uint4*>(TS + row * e.ld_out0 + g) = make_uint4(pt[0], pt[1], pt[2], pt[3]);
-                    *reinterpret_cast<uint4*>(TS + row * e.ld_out0 + e.GH + g) = make_uint4(ps[0], ps[1], ps[2], ps[3]);
+                    // saved for backward: sigmoid + u (tanh is recovered as u / sigmoid, gate_tanh_from)
+                    *reinterpret_cast<uint4*>(TS + row * e.ld_out0 + g) = make_uint4(ps[0], ps[1], ps[2], ps[3]);
                     *reinterpret_cast<uint4*>(U + row * e.ld_out1 + g) = make_uint4(pu[0], pu[1], pu[2], pu[3]);
                 }
             } else {
@@ -848,14 +920,14 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                             *reinterpret_cast<uint4*>((bf16_t*)e.out1 + row * e.ld_out1 + m) = pack8(dd);
                         }
                     } else if constexpr (EPI == EPI_DGATE) {
-                        const bf16_t* TS = (const bf16_t*)e.in0;
-                        float ta[8], sg[8], da[8], db[8];
-                        unpack8(*reinterpret_cast<const uint4*>(TS + row * e.ld_in0 + m), ta);
-                        unpack8(*reinterpret_cast<const uint4*>(TS + row * e.ld_in0 + e.GH + m), sg);
+                        float uu[8], sg[8], da[8], db[8];
+                        unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in1 + row * e.ld_in0 + m), uu);      // u = tanh * sigmoid
+                        unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), sg);      // sigmoid
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
-                            da[r] = v[r] * sg[r] * (1.0f - ta[r] * ta[r]);
-                            db[r] = v[r] * ta[r] * sg[r] * (1.0f - sg[r]);
+                            const float ta = gate_tanh_from(uu[r], sg[r]);
+                            da[r] = v[r] * sg[r] * (1.0f - ta * ta);
+                            db[r] = v[r] * uu[r] * (1.0f - sg[r]);
                         }
                         bf16_t* DZ = (bf16_t*)e.out0;
                         *reinterpret_cast<uint4*>(DZ + row * e.ld_out0 + m) = pack8(da);
@@ -910,7 +982,8 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             a.stagger = grid >= 1024 ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
             if constexpr (EPI == EPI_GATE || EPI == EPI_DX) {
-                if (a.taps == 3) {       // K-interleaved taps (packs built with kil = 32)
+                if (a.taps == 3) {       // K-interleaved taps (packs built with kil = 32).  PIPE 6 (wave halves half a chunk apart) measured +1.5 .. 2 % in
+                                         // the harness without the tap offsets (profiles/r2_gemm_harness_b{4,8}.txt) but needs 128 VGPRs + 3 spills with them: not used
                     hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1, 3>), dim3(grid), dim3(512), 0, st, a);
                     WN_LAUNCH_CHECK(ctx);
                     return WN_OK;

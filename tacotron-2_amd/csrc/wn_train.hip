@@ -53,6 +53,40 @@ extern "C" int wn_profile_result(wn_ctx* c, double* total_ms, int64_t* launches)
 static void wgrad_common(wn_ctx* c, WgBatchArgs& w, int ng, int B, int T) {
     memset(&w, 0, sizeof w); w.ngroups = ng; w.B = B; w.T = T;
 }
+// multi-A weight-gradient workgroups (wn_wgrad.h): WN_WGRAD_MULTI=0 restores one A tile per workgroup (A/B switch)
+static bool wgrad_multi() {
+    static const int v = [] { const char* e = getenv("WN_WGRAD_MULTI"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+// d W_dil of the layers [l0, l0 + ng): the three taps of one 128-channel block of the layer input share ONE workgroup and ONE staged
+// d z tile (A = xd(t-2d) | xd(t-d) | xd(t), B = d z); the conditioning kernel's gradient is its own (single-A) launch, wgrad_cin_args.
+static void wgrad_taps_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int T) {
+    const int64_t NT = c->NT; const int R = c->R, G = c->G;
+    wgrad_common(c, w, ng, B, T);
+    w.nseg = 3;
+    for (int s = 0; s < 3; ++s) { w.seg_base[s] = c->XD + (size_t)l0 * NT * R; w.seg_gstride[s] = NT * R; w.seg_ld[s] = R; w.seg_nk[s] = R; }
+    w.Bm = c->DZ + (size_t)l0 * NT * G; w.b_gstride = NT * G; w.ldb = G; w.N = G; w.ldw = G;
+    w.na = 3; w.hblocks = R / 128; w.a_colstep = 128;
+    for (int x = 0; x < 3; ++x) { w.a_seg[x] = x; w.a_col0[x] = 0; w.a_mrow[x] = x * R; }
+    for (int g = 0; g < ng; ++g) {
+        const int l = l0 + g, d = c->dil[l];
+        WgGroup& q = w.g[g];
+        q.out_off = c->lay[l].dil_k; q.bias_off = -1; q.bias2_off = 0; q.has_bias2 = 0;        // (bias gradients: wgrad_cin_args)
+        q.shift[0] = -2 * d; q.shift[1] = -d; q.shift[2] = 0; q.shift[3] = 0; q.scale = 1.0f;
+    }
+}
+static void wgrad_cin_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int T) {
+    const int64_t NT = c->NT; const int G = c->G, C = c->C;
+    wgrad_common(c, w, ng, B, T);
+    w.nseg = 1; w.seg_base[0] = c->cbt; w.seg_gstride[0] = 0; w.seg_ld[0] = C; w.seg_nk[0] = C;
+    w.Bm = c->DZ + (size_t)l0 * NT * G; w.b_gstride = NT * G; w.ldb = G; w.N = G; w.ldw = G;
+    for (int g = 0; g < ng; ++g) {
+        WgGroup& q = w.g[g];
+        const int l = l0 + g;      // d (dil bias) = d (cin bias) = column sums of d z: both written from this launch
+        q.out_off = c->lay[l].cin_k; q.bias_off = c->lbias ? c->lay[l].dil_b : -1; q.bias2_off = c->lbias ? c->lay[l].cin_b : 0; q.has_bias2 = c->lbias ? 1 : 0; q.scale = 1.0f;
+    }
+}
+static bool wgrad_taps_ok(wn_ctx* c) { return wgrad_multi() && c->R % 128 == 0 && c->G % 256 == 0; }
 static void wgrad_w1_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int T) {
     const int64_t NT = c->NT; const int R = c->R, G = c->G, C = c->C;
     wgrad_common(c, w, ng, B, T);
@@ -95,6 +129,10 @@ static void wgrad_skipout_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B,
     w.nseg = 1; w.seg_base[0] = c->U + (size_t)l0 * NT * GH; w.seg_gstride[0] = NT * GH; w.seg_ld[0] = GH; w.seg_nk[0] = GH;
     w.Bm = c->DSKIP; w.b_gstride = 0; w.ldb = S; w.N = S + R; w.ldw = S;
     w.Bm_hi = c->GXall + (size_t)(l0 + 1) * NT * R; w.b_gstride_hi = NT * R; w.ldb_hi = R; w.split_n = S; w.ldw_hi = R;
+    if (wgrad_multi() && GH % 256 == 0) {      // both 128-channel halves of a 256-channel block of u_l share the staged [d skip | d h] tile
+        w.na = 2; w.hblocks = GH / 256; w.a_colstep = 256;
+        for (int x = 0; x < 2; ++x) { w.a_seg[x] = 0; w.a_col0[x] = 128 * x; w.a_mrow[x] = 128 * x; }
+    }
     for (int g = 0; g < ng; ++g) {
         const int l = l0 + g; WgGroup& q = w.g[g];
         q.out_off = c->lay[l].skip_k; q.bias_off = c->lbias ? c->lay[l].skip_b : -1; q.bias2_off = 0; q.has_bias2 = 0; q.scale = c->skip_scale[l];
@@ -108,6 +146,10 @@ size_t wn_wgrad_partial_need(wn_ctx* c) {
     for (int B = 1; B <= c->maxB; ++B) {
         WgBatchArgs w;
         wgrad_w1_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
+        if (wgrad_taps_ok(c)) {
+            wgrad_taps_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
+            wgrad_cin_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
+        }
         wgrad_skip_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
         wgrad_out_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
         wgrad_skipout_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
@@ -150,7 +192,7 @@ static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
         a.taps = c->packs[l].w1.kil ? 3 : 0;
         if (c->gin > 0) { a.e.bias = c->gbias + (size_t)l * c->fB * G; a.e.bias_bstride = G; }      // + W_g^T g + b_g per utterance
         else a.e.bias = c->b1sum + (size_t)l * G;
-        a.e.out0 = c->TS + (size_t)l * NT * G; a.e.ld_out0 = G;
+        a.e.out0 = c->TS + (size_t)l * NT * GH; a.e.ld_out0 = GH;      // sigmoid half only (tanh = u / sigmoid in the backward)
         a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
         if (prof) prof_mark(c, st);
         if ((rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st))) return rc;
@@ -256,7 +298,7 @@ static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
             a.nseg = 2;
             a.seg[0] = seg(gx_up, R, 0, R, 0, 0);
             a.seg[1] = seg(c->DSKIP, S, 0, S, 0, 0);
-            a.e.in0 = c->TS + (size_t)l * NT * G; a.e.ld_in0 = G; a.e.out0 = DZl; a.e.ld_out0 = G;
+            a.e.in0 = c->TS + (size_t)l * NT * (G / 2); a.e.in1 = c->U + (size_t)l * NT * (G / 2); a.e.ld_in0 = G / 2; a.e.out0 = DZl; a.e.ld_out0 = G;
             if ((rc = wn_launch_gemm<EPI_DGATE>(c, a, c->packs[l].w2T.M, st))) return rc;
         }
         {   // d h_l = dropout-mask * conv^T(dz) + residual path   (modules.py:484, 517-520)
@@ -312,7 +354,8 @@ void wn_plan_buckets(wn_ctx* c) {
     const int L = c->L;
     c->nbuckets_early = 0; c->nbuckets = 0;
     const int64_t tail0 = (c->emb_off >= 0) ? c->emb_off : (c->up_k.empty() ? c->n_params : c->up_k[0]);
-    static const int want = [] { const char* e = getenv("WN_BWD_BUCKETS"); return e ? atoi(e) : 4; }();
+    static const int env_want = [] { const char* e = getenv("WN_BWD_BUCKETS"); return e ? atoi(e) : 0; }();      // A/B override
+    const int want = env_want > 0 ? env_want : (c->cfg.grad_buckets > WN_MAX_BUCKETS ? WN_MAX_BUCKETS : c->cfg.grad_buckets);
     const bool early = !c->wnorm && c->gin == 0 && want > 1 && L >= 2 * want;
     if (!early) {      // weight normalisation maps the effective gradients to (v, g) in a final pass; global conditioning adds per-layer
         c->bucket_off[0] = 0; c->bucket_cnt[0] = c->n_raw; c->nbuckets = 1;          // tensors late: ONE bucket, final when the call ends
@@ -349,7 +392,16 @@ extern "C" int wn_bwd_wait_bucket(wn_ctx* c, int32_t i, void* stream) {
 static int stack_wgrads(wn_ctx* c, float* grads, int l0, int ng, bool fused, hipStream_t st) {
     const int L = c->L;
     int rc;
-    {   // d [W_dil; W_cin], d biases:  A = [xd(t-2d) | xd(t-d) | xd(t) | c(t)],  B = d z
+    if (wgrad_taps_ok(c)) {
+        {   // d W_dil, d (dil + cin) biases: the three taps of a channel block in one workgroup, sharing the d z tile
+            WgBatchArgs w; wgrad_taps_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
+            if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+        }
+        {   // d W_cin:  A = c(t),  B = d z
+            WgBatchArgs w; wgrad_cin_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
+            if ((rc = launch_wgrad_batch(c, w, st))) return rc;
+        }
+    } else {   // d [W_dil; W_cin], d biases:  A = [xd(t-2d) | xd(t-d) | xd(t) | c(t)],  B = d z
         WgBatchArgs w; wgrad_w1_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
         if ((rc = launch_wgrad_batch(c, w, st))) return rc;
     }

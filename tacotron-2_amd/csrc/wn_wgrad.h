@@ -192,6 +192,10 @@ struct WgBatchArgs {
     // fused launch (same A operand, two B operands side by side): columns [split_n, N) come from Bm_hi and go to *_hi targets
     const bf16_t* Bm_hi; int64_t b_gstride_hi; int32_t ldb_hi, split_n, ldw_hi, pad0_;
     float* grads; int32_t ldw;
+    // multi-A launches (NA > 1): ONE workgroup multiplies `na` A tiles (the three dilated taps of the layer input, or the two
+    // channel halves of u_l) with the SAME staged B tile: B is read na x less often and the DMA issue per MFMA drops accordingly.
+    // A tile a of column block h (< hblocks): segment a_seg[a], channels [a_col0[a] + a_colstep h, +128), output rows a_mrow[a] + a_colstep h.
+    int32_t na, hblocks, a_colstep, a_seg[3], a_col0[3], a_mrow[3];
     float* partial;                     // [unit][mtiles*128 + 8][N] fp32; row mtiles*128 = bias partial
     int32_t B, T, slab, spu, Mrows, mtiles, ntiles, nunits;
     const bf16_t* zero;
@@ -200,21 +204,23 @@ struct WgBatchArgs {
 #define WG2_KT 32
 #define WG2_AB (WG2_KT * 256)     // A stage bytes: 32 rows x 128 bf16
 #define WG2_BB (WG2_KT * 512)     // B stage bytes: 32 rows x 256 bf16
-template <int NBUF>
-__global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs a) {
-    constexpr int BUFB = WG2_AB + WG2_BB;
-    constexpr int LPC = 3;                       // DMAs per wave per chunk: 1 (A) + 2 (B)
+template <int NBUF, int NA = 1>
+__global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(const WgBatchArgs a) {
+    constexpr int BUFB = NA * WG2_AB + WG2_BB;
+    constexpr int LPC = NA + 2;                  // DMAs per wave per chunk: NA (A tiles) + 2 (B)
+    static_assert(NBUF * BUFB <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) char lds[NBUF * BUFB];
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave >> 2, wn = wave & 3;
     // XCD-aware decode
-    const int tpu = a.mtiles * a.ntiles;
+    const int mt_u = (NA == 1) ? a.mtiles : a.hblocks;            // A-tile positions per unit
+    const int tpu = mt_u * a.ntiles;
     const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
     const int tile = q % tpu, u = (q / tpu) * 8 + xcd;
     if (u >= a.nunits) return;
-    const int mblk = tile % a.mtiles, nblk = tile / a.mtiles;
+    const int mblk = tile % mt_u, nblk = tile / mt_u;
     const int upg = a.B * a.spu;
     const int grp = u / upg, b = (u - grp * upg) / a.spu, sl = (u - grp * upg) % a.spu;
     const int T = a.T;
@@ -222,16 +228,24 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
     const int nchunks = max(0, (ts1 - ts0 + WG2_KT - 1) / WG2_KT);
     const int64_t rowbase = (int64_t)b * T;
 
-    // A tile -> (segment, first channel, valid channels); segments are multiples of 8 channels
-    const bf16_t* a_base = a.zero; int a_ld = 0, a_shift = 0, a_valid = 0;
-    {
+    // A tile(s) -> (segment, first channel, valid channels, first output row); segments are multiples of 8 channels
+    const bf16_t* a_base[NA]; int a_ld[NA], a_shift[NA], a_valid[NA], a_mrow[NA];
+    if constexpr (NA == 1) {
+        a_base[0] = a.zero; a_ld[0] = 0; a_shift[0] = 0; a_valid[0] = 0; a_mrow[0] = mblk * 128;
         int m0 = 0; const int mcol = mblk * 128;
         for (int s = 0; s < a.nseg; ++s) {
             if (mcol >= m0 && mcol < m0 + a.seg_nk[s]) {
-                a_base = a.seg_base[s] + (int64_t)grp * a.seg_gstride[s] + (mcol - m0); a_ld = a.seg_ld[s]; a_shift = a.g[grp].shift[s];
-                a_valid = min(128, a.seg_nk[s] - (mcol - m0));
+                a_base[0] = a.seg_base[s] + (int64_t)grp * a.seg_gstride[s] + (mcol - m0); a_ld[0] = a.seg_ld[s]; a_shift[0] = a.g[grp].shift[s];
+                a_valid[0] = min(128, a.seg_nk[s] - (mcol - m0));
             }
             m0 += a.seg_nk[s];
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < NA; ++x) {
+            const int sg = a.a_seg[x], col = a.a_col0[x] + mblk * a.a_colstep;
+            a_base[x] = a.seg_base[sg] + (int64_t)grp * a.seg_gstride[sg] + col; a_ld[x] = a.seg_ld[sg]; a_shift[x] = a.g[grp].shift[sg];
+            a_valid[x] = max(0, min(128, a.seg_nk[sg] - col)); a_mrow[x] = a.a_mrow[x] + mblk * a.a_colstep;
         }
     }
     const int n0 = nblk * 256;
@@ -240,14 +254,19 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
     const bf16_t* const b_lo = a.Bm + (int64_t)grp * a.b_gstride;
     const bf16_t* const b_hi = a.split_n > 0 ? a.Bm_hi + (int64_t)grp * a.b_gstride_hi : nullptr;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[NA][2][2];
+#pragma unroll
+    for (int x = 0; x < NA; ++x)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const bool do_bias = (mblk == 0);
+            for (int r = 0; r < 16; ++r) acc[x][i][j][r] = 0.0f;
+    // bias gradients = column sums of the B tile.  The three-tap workgroups (192 accumulator registers) leave them to the
+    // conditioning-kernel launch of the same layers, which reads the same d z (wgrad_cin_args).
+    constexpr bool BIAS = (NA != 3);
+    const bool do_bias = BIAS && (mblk == 0);
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.0f;
@@ -255,15 +274,16 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
     auto stage = [&](auto bufc, int ch) {
         constexpr int BUF = decltype(bufc)::value;
         char* const abuf = lds + BUF * BUFB;
-        char* const bbuf = abuf + WG2_AB;
+        char* const bbuf = abuf + NA * WG2_AB;
         const int tc = ts0 + ch * WG2_KT;
-        {   // A: piece `wave` = rows wave*4 .. +3, 16 slots of 16 B each
+#pragma unroll
+        for (int x = 0; x < NA; ++x) {   // A tile x: piece `wave` = rows wave*4 .. +3, 16 slots of 16 B each
             const int row = wave * 4 + (lane >> 4);
             const int c = (lane & 15) ^ ((row & 3) << 2);
-            const int t = tc + row, ts = t + a_shift;
-            const bool ok = (c * 8 < a_valid) && (t < ts1) && (ts >= 0) && (ts < T);
-            const bf16_t* src = ok ? a_base + (rowbase + ts) * a_ld + c * 8 : a.zero;
-            wg_lds_dma16(src, __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(abuf + wave * 1024)));
+            const int t = tc + row, ts = t + a_shift[x];
+            const bool ok = (c * 8 < a_valid[x]) && (t < ts1) && (ts >= 0) && (ts < T);
+            const bf16_t* src = ok ? a_base[x] + (rowbase + ts) * a_ld[x] + c * 8 : a.zero;
+            wg_lds_dma16(src, __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(abuf + x * WG2_AB + wave * 1024)));
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {   // B: piece g = rows g*2, g*2+1, 32 slots each
@@ -284,10 +304,12 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
     auto compute = [&](auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
         const char* const abuf = lds + BUF * BUFB;
-        const char* const bbuf = abuf + WG2_AB;
+        const char* const bbuf = abuf + NA * WG2_AB;
 #pragma unroll
         for (int ks = 0; ks < WG2_KT / 16; ++ks) {
-            bf16x8_t af[2], bfr[2];
+            bf16x8_t af[NA][2], bfr[2];
+#pragma unroll
+            for (int x = 0; x < NA; ++x)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 s16x4 h[2];
@@ -295,10 +317,10 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
                 for (int jj = 0; jj < 2; ++jj) {
                     const int row = ks * 16 + tr_row + 4 * jj;
                     const int cb = ((wk * 2 + i) * 64 + tr_colb) ^ ((row & 3) << 6);
-                    h[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(abuf + row * 256 + cb));
+                    h[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(abuf + x * WG2_AB + row * 256 + cb));
                 }
                 struct { s16x4 lo, hi; } pk = {h[0], h[1]};
-                af[i] = __builtin_bit_cast(bf16x8_t, pk);
+                af[x][i] = __builtin_bit_cast(bf16x8_t, pk);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -313,12 +335,14 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
                 bfr[j] = __builtin_bit_cast(bf16x8_t, pk);
             }
 #pragma unroll
+            for (int x = 0; x < NA; ++x)
+#pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[x][i], bfr[j], acc[x][i][j], 0, 0, 0);
         }
-        if (do_bias) {   // column sums of the B tile: thread -> 8 columns x 2 rows
+        if constexpr (BIAS) if (do_bias) {   // column sums of the B tile: thread -> 8 columns x 2 rows
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int row = (tid >> 5) * 2 + rr;
@@ -352,11 +376,13 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
 #ifdef WN_EPI_ABLATE
     if (a.ldw != -7777) {
 #pragma unroll
+        for (int x = 0; x < NA; ++x)
+#pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[x][i][j][r]));
 #pragma unroll
         for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(bsum[e]));
         return;
@@ -367,18 +393,20 @@ __global__ __launch_bounds__(512, 4) void wn_wgrad_lds_kernel(const WgBatchArgs 
     const int rows_p = a.mtiles * 128 + 8;
     float* const P = a.partial + (int64_t)u * rows_p * a.N;
 #pragma unroll
+    for (int x = 0; x < NA; ++x)
+#pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + (wn * 2 + j) * 32 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mblk * 128 + (wk * 2 + i) * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                P[(int64_t)m * a.N + n] = acc[i][j][r];
+                const int m = a_mrow[x] + (wk * 2 + i) * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                P[(int64_t)m * a.N + n] = acc[x][i][j][r];
             }
         }
     }
-    if (do_bias) {      // 16 row-groups hold partial column sums of the same 8 columns: combine through LDS
+    if constexpr (BIAS) if (do_bias) {      // 16 row-groups hold partial column sums of the same 8 columns: combine through LDS
         __syncthreads();
         float* red = reinterpret_cast<float*>(lds);          // [16][256]
 #pragma unroll
@@ -431,8 +459,12 @@ __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(const WgBatchArgs 
 static inline void wn_wgrad_plan(WgBatchArgs& a) {
     a.Mrows = 0; for (int s = 0; s < a.nseg; ++s) a.Mrows += a.seg_nk[s];
     a.mtiles = cdiv(a.Mrows, 128); a.ntiles = a.N / 256;
-    const int tpu = a.mtiles * a.ntiles;
-    int spu = cdiv(1024, (int64_t)tpu * a.B * a.ngroups);
+    if (a.na <= 1) { a.na = 1; a.hblocks = a.mtiles; }
+    const int tpu = a.hblocks * a.ntiles;
+    // time slabs per utterance: multi-A workgroups are alone on their CU (one round = 256 workgroups) and every extra slab costs a
+    // full fp32 output tile in the partial buffer, so launches are split only until one round is full (256 multi-A workgroups, or
+    // 2 x 256 single-A ones)
+    int spu = cdiv(a.na > 1 ? 256 : 512, (int64_t)tpu * a.B * a.ngroups);
     const int max_spu = a.T / 256 > 0 ? a.T / 256 : 1;
     if (spu > max_spu) spu = max_spu;
     if (spu < 1) spu = 1;
@@ -450,8 +482,10 @@ static int launch_wgrad_batch(wn_ctx* c, WgBatchArgs& a, hipStream_t st) {
     wn_wgrad_plan(a);
     if (wn_wgrad_partial_bytes(a) > c->wg_partial_bytes) WN_FAIL(c, WN_E_STATE, "wgrad partial buffer too small (%zu > %zu)", wn_wgrad_partial_bytes(a), c->wg_partial_bytes);
     a.partial = c->wg_partial; a.zero = c->zero_page;
-    const int grid = cdiv(a.nunits, 8) * a.mtiles * a.ntiles * 8;
-    hipLaunchKernelGGL(wn_wgrad_lds_kernel<3>, dim3(grid), dim3(512), 0, st, a);
+    const int grid = cdiv(a.nunits, 8) * a.hblocks * a.ntiles * 8;
+    if (a.na == 3) hipLaunchKernelGGL((wn_wgrad_lds_kernel<3, 3>), dim3(grid), dim3(512), 0, st, a);
+    else if (a.na == 2) hipLaunchKernelGGL((wn_wgrad_lds_kernel<3, 2>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wn_wgrad_lds_kernel<3, 1>), dim3(grid), dim3(512), 0, st, a);
     WN_LAUNCH_CHECK(c);
     const int64_t items = (int64_t)(a.Mrows + 1) * (a.N / 4) * a.ngroups;
     hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3(cdiv(items, 256)), dim3(256), 0, st, a);

@@ -82,6 +82,7 @@ MI355 = dict(
     mi355_steps_per_graph=0,       # synthesis path: 0 = the persistent dataflow pipeline (real time at 22.05 kHz) whenever the model fits it, else the
                                    # launch-per-layer path with 32 steps per hipGraph replay; N > 0 = that path with N steps per replay
     mi355_synthetic_data=False,    # train on LJSpeech-shaped synthetic tensors (no dataset on disk)
+    mi355_grad_buckets=3,          # data-parallel training: pieces of the flat gradient that are all-reduced while the backward is still running
     mi355_synthesize_with_ema=False,   # Synthesizer.load: pack the EMA shadow weights instead of the raw ones
 )
 

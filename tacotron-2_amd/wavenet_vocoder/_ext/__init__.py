@@ -44,6 +44,7 @@ class WnConfig(ctypes.Structure):
         ('gin_channels', ctypes.c_int32), ('use_speaker_embedding', ctypes.c_int32), ('n_speakers', ctypes.c_int32),
         ('weight_normalization', ctypes.c_int32),
         ('inference_only', ctypes.c_int32),
+        ('grad_buckets', ctypes.c_int32),
     ]
 
 
@@ -121,7 +122,7 @@ def exported_symbols():
     return list(load_library()._wn_symbols)
 
 
-def config_from_hparams(hp, max_batch, max_time, inference_only=False):
+def config_from_hparams(hp, max_batch, max_time, inference_only=False, grad_buckets=None):
     """hparams (reference keys, hparams.py:187-233, 309-327) -> wn_config."""
     cfg = WnConfig()
     cfg.abi_version = WN_ABI_VERSION
@@ -164,6 +165,11 @@ def config_from_hparams(hp, max_batch, max_time, inference_only=False):
     cfg.n_speakers = int(getattr(hp, 'n_speakers', 0) or 0)
     cfg.weight_normalization = int(bool(getattr(hp, 'wavenet_weight_normalization', False)))      # hparams.py:323
     cfg.inference_only = int(bool(inference_only))
+    if grad_buckets is None:      # data parallel: 3 pieces (two early layer groups + the rest) overlap the all-reduce with the backward; single GPU: 1
+        import torch
+        dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        grad_buckets = int(getattr(hp, 'mi355_grad_buckets', 3)) if dp else 1
+    cfg.grad_buckets = int(grad_buckets)
     return cfg
 
 
@@ -190,10 +196,11 @@ def _check(t, dtype, name):
 class Engine:
     """One wn_ctx: owns packed weights + workspace on the current device."""
 
-    def __init__(self, hp, max_batch, max_time, inference_only=False):
-        """inference_only: synthesis-only context (no training workspace, every synthesis buffer pre-sized: wn_config.inference_only)."""
+    def __init__(self, hp, max_batch, max_time, inference_only=False, grad_buckets=None):
+        """inference_only: synthesis-only context (no training workspace, every synthesis buffer pre-sized: wn_config.inference_only).
+        grad_buckets: pieces of the flat gradient train_bwd completes early (None: 3 under torch.distributed with > 1 rank, else 1)."""
         self.lib = load_library()
-        self.cfg = config_from_hparams(hp, max_batch, max_time, inference_only)
+        self.cfg = config_from_hparams(hp, max_batch, max_time, inference_only, grad_buckets)
         h = ctypes.c_void_p()
         rc = self.lib.wn_create(ctypes.byref(self.cfg), ctypes.byref(h))
         if rc != 0:

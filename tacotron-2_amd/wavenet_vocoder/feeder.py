@@ -72,9 +72,13 @@ class Feeder(object):
             assert hparams.wavenet_test_batches == self.test_steps
         self.local_condition = hparams.cin_channels > 0
         self.global_condition = hparams.gin_channels > 0                     # reference feeder.py:353
+        # feeder.py:267-268 (the reference asserts it while building the queue): fail at construction, not inside a thread
+        if hparams.wavenet_batch_size % self._world != 0:
+            raise ValueError('wavenet_batch_size ({}) must be divisible by the number of GPUs ({})'.format(hparams.wavenet_batch_size, self._world))
         self._train_q = queue.Queue(maxsize=8)
         self._eval_q = queue.Queue(maxsize=1)
         self._threads = []
+        self._error = None
 
     # ------------------------------------------------------------------ threads
     def start_threads(self, session=None):
@@ -86,21 +90,58 @@ class Feeder(object):
     def _should_stop(self):
         return self._coord is not None and self._coord.should_stop()
 
+    def _producer(self, train, q):
+        """Body of a background thread.  Any error (missing .npy, audio / mel length mismatch, '<no_g>' speaker column ...) stops
+        the coordinator and travels through the queue, so that next_*_batch re-raises it in the training loop instead of blocking
+        forever on a dead producer (and, data parallel, leaving the other ranks inside an all-reduce until the RCCL timeout)."""
+        try:
+            while not self._should_stop():
+                for batch in self._iter_group(train=train):
+                    if self._put(q, self._prepare_batch(batch)):
+                        return
+        except BaseException as e:          # noqa: BLE001 -- forwarded, not swallowed
+            self._error = e
+            if self._coord is not None:
+                self._coord.request_stop(e)
+            for qq in (self._train_q, self._eval_q):
+                try:
+                    qq.put_nowait(_FeederError(e))
+                except queue.Full:
+                    pass                      # the consumer finds self._error after draining what is queued
+
+    def _put(self, q, item):
+        """Blocking put that gives up when the coordinator stops (returns True then)."""
+        while True:
+            try:
+                q.put(item, timeout=0.5)
+                return False
+            except queue.Full:
+                if self._should_stop():
+                    return True
+
     def _enqueue_next_train_group(self):
-        while not self._should_stop():
-            for batch in self._next_group(train=True):
-                self._train_q.put(self._prepare_batch(batch))
+        self._producer(True, self._train_q)
 
     def _enqueue_next_test_group(self):
-        while not self._should_stop():
-            for batch in self._next_group(train=False):
-                self._eval_q.put(self._prepare_batch(batch))
+        self._producer(False, self._eval_q)
+
+    def _get(self, q):
+        while True:
+            try:
+                item = q.get(timeout=1.0)
+            except queue.Empty:
+                if self._error is not None:
+                    raise RuntimeError('feeder thread failed: {!r}'.format(self._error)) from self._error
+                continue
+            if isinstance(item, _FeederError):
+                raise RuntimeError('feeder thread failed: {!r}'.format(item.error)) from item.error
+            return item
 
     def next_train_batch(self):
-        return self._to_device(self._train_q.get())
+        return self._to_device(self._get(self._train_q))
 
     def next_eval_batch(self):
-        return self._to_device(self._eval_q.get())
+        return self._to_device(self._get(self._eval_q))
 
     def _to_device(self, batch):
         dev = self._device or torch.device('cuda', torch.cuda.current_device())
@@ -108,23 +149,30 @@ class Feeder(object):
 
     # ------------------------------------------------------------------ examples
     def _next_group(self, train):
+        """The batches (this rank's slices, arrays loaded) of the next group as a list."""
+        return list(self._iter_group(train))
+
+    def _iter_group(self, train):
         hp = self._hparams
-        n = hp.wavenet_batch_size               # GLOBAL batch, divisible by the number of ranks (feeder.py:267-268)
-        assert n % self._world == 0, 'wavenet_batch_size must be divisible by the number of GPUs'
+        n = hp.wavenet_batch_size               # GLOBAL batch, divisible by the number of ranks (checked in __init__)
+        # Every rank walks the SAME sequence of utterances (shared shuffles) but only reads the .npy HEADERS of the whole group
+        # (length bucketing needs the lengths); the arrays themselves are loaded for this rank's slice of each batch only, so disk
+        # and host work per step do not grow with the number of ranks.
         if train:
-            examples = [self._get_example(self._train_meta, True) for _ in range(n * _batches_per_group)]
-            examples.sort(key=lambda e: len(e[0]))                 # bucket by length
-            batches = [examples[i:i + n] for i in range(0, len(examples), n)]
+            metas = [self._next_meta(self._train_meta, True) for _ in range(n * _batches_per_group)]
+            metas.sort(key=lambda m: m[1])                          # bucket by length (stable, like the reference's sort on len(x))
+            batches = [metas[i:i + n] for i in range(0, len(metas), n)]
             # same order on every rank: at each step the ranks hold the disjoint slices of ONE length bucket (equal padding => equal step time)
             self._order_rng.shuffle(batches)
         else:
-            examples = [self._get_example(self._test_meta, False) for _ in range(len(self._test_meta))]
-            batches = [examples[i:i + n] for i in range(0, len(examples), n)]
+            metas = [self._next_meta(self._test_meta, False) for _ in range(len(self._test_meta))]
+            batches = [metas[i:i + n] for i in range(0, len(metas), n)]
         per = n // self._world
-        return [b[self._rank * per:(self._rank + 1) * per] for b in batches]
+        for b in batches:
+            yield [self._load_example(m) for m, _ in b[self._rank * per:(self._rank + 1) * per]]
 
-    def _get_example(self, meta_list, train):
-        hp = self._hparams
+    def _next_meta(self, meta_list, train):
+        """(metadata row, audio length) of the next utterance; the length comes from the .npy header (no data read)."""
         if train:
             if self._train_offset >= len(meta_list):
                 self._train_offset = 0
@@ -134,11 +182,17 @@ class Feeder(object):
             if self._test_offset >= len(meta_list):
                 self._test_offset = 0
             meta = meta_list[self._test_offset]; self._test_offset += 1
+        return meta, int(np.load(self._resolve(meta[0]), mmap_mode='r').shape[0])
+
+    def _load_example(self, meta):
+        hp = self._hparams
         mel_file = meta[2] if hp.train_with_GTA else meta[1]
         audio_file = meta[0]
         input_data = np.load(self._resolve(audio_file))
         local_feats = np.load(self._resolve(mel_file)) if self.local_condition else None
-        assert len(input_data) == len(local_feats) * audio.get_hop_size(hp), 'audio / mel length mismatch in %s' % audio_file
+        if len(input_data) != len(local_feats) * audio.get_hop_size(hp):
+            raise ValueError('audio / mel length mismatch in %s (%d samples vs %d frames x hop %d)'
+                             % (audio_file, len(input_data), len(local_feats), audio.get_hop_size(hp)))
         g = None
         if self.global_condition:                                      # reference feeder.py:254-257: speaker id column of map.txt
             g = meta[3]
@@ -187,6 +241,13 @@ class Feeder(object):
         # global conditions: int32 speaker ids [B, 1] (reference feeder.py:342-349)
         g = np.array([b[2] for b in batch]).astype(np.int32).reshape(-1, 1) if self.global_condition else None
         return (np.ascontiguousarray(inputs), np.ascontiguousarray(targets), input_lengths, c, g)
+
+
+class _FeederError(object):
+    """Queue item that carries a producer thread's exception to the consumer."""
+
+    def __init__(self, error):
+        self.error = error
 
 
 def _limit_time(batch, hparams, rng):

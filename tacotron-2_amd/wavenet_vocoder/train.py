@@ -85,7 +85,10 @@ def save_checkpoint(model, save_dir, checkpoint_path, max_to_keep=20):
     hist = []
     if os.path.exists(index):
         with open(index) as f:
-            hist = json.load(f).get('all_model_checkpoint_paths', [])
+            try:
+                hist = json.load(f).get('all_model_checkpoint_paths', [])
+            except ValueError:
+                hist = []          # the reference's TensorFlow text-proto index (get_checkpoint_state reads it): start a new history
     hist.append(os.path.basename(path))
     for old in hist[:-max_to_keep]:
         p = os.path.join(save_dir, old)
@@ -226,6 +229,17 @@ def train(log_dir, args, hparams, input_path):
             if ckpt and os.path.exists(ckpt):
                 log('Loading checkpoint {}'.format(ckpt), slack=True)
                 model.load_state_dict(torch.load(ckpt, map_location='cpu'))
+                step = model.global_step
+            elif ckpt and os.path.exists(ckpt + '.index'):
+                # a checkpoint written by the reference (TensorFlow tensor bundle, train.py:67-87): parameters by name; its Adam slots
+                # are not stored under names this optimiser could use, so the moments restart from zero
+                from wavenet_vocoder.tf_checkpoint import load_reference_checkpoint
+                log('Loading TensorFlow checkpoint {}'.format(ckpt), slack=True)
+                flat, tf_step, missing = load_reference_checkpoint(ckpt, model.engine.layout)
+                if missing:
+                    raise RuntimeError('TensorFlow checkpoint {} lacks {} of the model\'s tensors, e.g. {}'.format(ckpt, len(missing), missing[:3]))
+                p = torch.from_numpy(flat)
+                model.load_state_dict({'params': p, 'ema': p.clone(), 'adam_m': torch.zeros_like(p), 'adam_v': torch.zeros_like(p), 'global_step': tf_step or 0})
                 step = model.global_step
             else:
                 log('No model to load at {}'.format(save_dir), slack=True)

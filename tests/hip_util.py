@@ -108,3 +108,28 @@ def synth_batch(cfg, B, T, seed=0):
     wav = wav.clamp(-0.999, 0.999)
     c = torch.rand(B, cfg.cin_channels, Tc, generator=g)
     return wav, c
+
+
+# ---- device noise stream mirror (csrc/wn_misc.hip: wn_philox4x32_10 / wn_u01 / wn_noise_kernel) -----------------------------
+def philox4x32_10(counter, key):
+    """counter: uint64 array (group indices), key: 64-bit seed -> uint32 [n, 4] (Philox4x32-10, counter words (lo, hi, 0, 0))."""
+    c = [(counter & 0xffffffff).astype(np.uint64), (counter >> 32).astype(np.uint64), np.zeros_like(counter, dtype=np.uint64), np.zeros_like(counter, dtype=np.uint64)]
+    k0, k1 = int(key) & 0xffffffff, (int(key) >> 32) & 0xffffffff
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        n0 = (p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0)
+        n1 = p1 & np.uint64(0xffffffff)
+        n2 = (p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1)
+        n3 = p0 & np.uint64(0xffffffff)
+        c = [n0, n1, n2, n3]
+        k0 = (k0 + 0x9E3779B9) & 0xffffffff; k1 = (k1 + 0xBB67AE85) & 0xffffffff
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def device_uniform_noise(n, seed):
+    """The first n elements of the device's uniform noise stream (float32, bit-exact)."""
+    g = np.arange((n + 3) // 4, dtype=np.uint64)
+    w = philox4x32_10(g, seed).reshape(-1)[:n]
+    u01 = ((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return np.minimum(np.maximum(u01, np.float32(1e-5)), np.float32(1.0) - np.float32(1e-5))

@@ -58,12 +58,12 @@ TOL_GRAD_TENSOR = 1e-2      # residual stack + head + input conv tensors (measur
 TOL_GRAD_UPSAMPLE = 1.2e-1  # the 6 upsample-net tensors (<= 55 elements each; every element sums bf16 d z over all layers and rows: measured <= 3.9e-2)
 
 
-def _case(over, B, T, lengths, check_layers, chunk=1, seed=1234, report=None, batch_parts=0):
+def _case(over, B, T, lengths, check_layers, chunk=1, seed=1234, report=None, batch_parts=0, grad_buckets=None):
     from wavenet_vocoder import _ext
     hp = make_hp(**over)
     cfg = oracle_cfg(hp)
     assert T % cfg.hop == 0
-    eng = _ext.Engine(hp, B, T)
+    eng = _ext.Engine(hp, B, T, grad_buckets=grad_buckets)
     params = O.init_params(cfg, seed=5339, bias_scale=0.05)
     g = torch.Generator().manual_seed(7)
     for k in params:                                   # frequency taps of the upsample kernels away from the NN-init zeros
@@ -175,7 +175,7 @@ def _assert_case(r):
 def test_c2_bench_geometry_b2_two_streams():
     """BASELINE configs[1] engine configuration, B = 2 (so the two-stream split puts one utterance on each stream), ragged second
     utterance: X/U at layers {0, 10, 11, 12, 22, 23} (d = 1, 1024, 2048, 1, 1024, 2048), y_hat, all 204 gradient tensors."""
-    r = _case(PAPER, 2, 11000, [11000, 9377], [0, 10, 11, 12, 22, 23], report='c2_b2')
+    r = _case(PAPER, 2, 11000, [11000, 9377], [0, 10, 11, 12, 22, 23], report='c2_b2', grad_buckets=3)      # the data-parallel backward order (weight gradients per bucket, under the chain)
     _assert_case(r)
     # and against the fp32 oracle (reference arithmetic): the documented bf16 deviation
     y_fp = O.step(r['params'], r['cfg'], r['wav'][:1].view(1, 1, -1), r['c'][:1],
@@ -211,11 +211,11 @@ def test_gradient_buckets_are_final_when_their_event_fires():
     hp = make_hp(**PAPER)
     cfg = oracle_cfg(hp)
     B, T = 4, 11000
-    eng = _ext.Engine(hp, B, T)
+    eng = _ext.Engine(hp, B, T, grad_buckets=3)              # what a data-parallel run creates
     params = O.init_params(cfg, seed=5339, bias_scale=0.05)
     eng.pack_weights(upload_params(eng, params))
     buckets = eng.grad_buckets()
-    assert len(buckets) >= 4
+    assert len(buckets) >= 4      # 2 early layer groups + [input conv, lowest layers] + tail (upsample net)
     cover = np.zeros(eng.n_params, dtype=np.int32)
     for off, n in buckets:
         cover[off:off + n] += 1

@@ -162,3 +162,25 @@ def test_shim_convolutions_against_naive_loops():
     # batch_to_space_nd: out[b', i*r + j] = in[j*n + b', i]
     x = torch.arange(2 * 3 * 4).float().reshape(6, 4); y = S.batch_to_space_nd(x, [3], [[0, 0]])
     assert y.shape == (2, 12) and all(float(y[bp, i * 3 + j]) == float(x[j * 2 + bp, i]) for bp in range(2) for i in range(4) for j in range(3))
+
+
+def test_reference_weightnorm_data_dependent_init_is_recorded(golden_dir):
+    """the reference's data-dependent weight-norm initialisation (modules.py:110-126 driven by train.py:287-298),
+    executed with the reference's own files on the TF stand-in by oracle/check_weightnorm_init.py.  Finding pinned by the fixture:
+    the init forward pass raises a shape error in the first wrapped layer (moments over the kernel's leading axes of a channels-first
+    activation have shape [T], g has [filters]) and no variable changes -- there is no initialisation arithmetic to reproduce; a
+    weight-normalised model starts from g = ||v|| (WeightNorm.build, modules.py:164-170), which is what this tree does."""
+    g = np.load(os.path.join(golden_dir, 'weightnorm_datadep_init.npz'))
+    assert bool(g['raised']) and 'must match' in str(g['error'])
+    assert int(g['time_steps']) != int(g['first_layer_filters'])
+    assert float(g['max_abs_change']) == 0.0 and int(g['n_variables']) > 20 and int(g['n_wrappers']) > 10
+    assert float(g['y_train_model_after_vs_before']) == 0.0
+    # our initialiser for weight-normalised models: g = ||v|| over all axes but the last, kernel == v at step 0
+    from oracle import wavenet_oracle as O
+    cfg = O.OracleConfig(layers=2, stacks=1, residual_channels=8, gate_channels=16, skip_out_channels=8, cin_channels=4,
+                         upsample_type='2D', upsample_scales=[2, 2], wavenet_weight_normalization=True)
+    p = O.init_params(cfg, seed=1)
+    eff = O.effective_params(p, cfg)
+    for k, v in p.items():
+        if k.endswith('/kernel'):
+            assert torch.allclose(eff[k], v, atol=1e-6)

@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
         bf16_t* TS2 = dev_zero<bf16_t>(NT_ * G); bf16_t* U2 = dev_zero<bf16_t>(NT_ * GH);
         GemmArgs a; base(a, Apk, K); a.nseg = 4;
         a.seg[0] = mkseg(XD, R, 0, R, -2 * d); a.seg[1] = mkseg(XD, R, 0, R, -d); a.seg[2] = mkseg(XD, R, 0, R, 0); a.seg[3] = mkseg(cbt, C, 0, C, 0);
-        a.e.bias = bias; a.e.ld_out0 = G; a.e.ld_out1 = GH; a.e.M_valid = M;
+        a.e.bias = bias; a.e.ld_out0 = GH; a.e.ld_out1 = GH; a.e.M_valid = M;      // saved: sigmoid [rows][GH] + u [rows][GH]
         GemmArgs a1 = a; a1.e.out0 = TS1; a1.e.out1 = U1;
         GemmArgs a2 = a; a2.e.out0 = TS2; a2.e.out1 = U2;
         const double fl = 2.0 * M * K * (double)NT_;
@@ -107,10 +107,12 @@ int main(int argc, char** argv) {
         float t2 = time_ms([&] { launch_v2<MT_, NT_, WM_, WN_, BK_, NB_, EPI_GATE, PP_>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
         bool ok = same({TS1, (size_t)NT_ * G * 2}, {TS2, (size_t)NT_ * G * 2}, "TS") & same({U1, (size_t)NT_ * GH * 2}, {U2, (size_t)NT_ * GH * 2}, "U"); \
         printf("gate   v2 MT%d NT%d WM%d WN%d BK%d NBUF%d PIPE%d : %8.1f us  %7.1f TF  %s\n", MT_, NT_, WM_, WN_, BK_, NB_, PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
-        TRY_GATE2(2, 2, 4, 2, 32, 3) TRY_GATE2(2, 2, 4, 2, 32, 2) 
-        TRY_GATE2(4, 2, 2, 4, 32, 3) TRY_GATE2(2, 4, 4, 2, 32, 3)
-        TRY_GATE3(2, 2, 4, 2, 32, 3, 1) TRY_GATE3(2, 2, 4, 2, 32, 3, 2) TRY_GATE3(4, 2, 2, 4, 32, 3, 2) TRY_GATE3(2, 4, 4, 2, 32, 3, 2) TRY_GATE3(2, 2, 4, 2, 64, 3, 2)
-        for (int sg : {0, 16000, 0}) { a2.stagger = sg; printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 4, 32, 4, 3) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 4, 32, 4, 2) printf("  stagger %5d: ", sg); TRY_GATE3(4, 2, 2, 4, 32, 4, 3) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 1) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 2) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 3) printf("  stagger %5d: ", sg); TRY_GATE3(4, 2, 2, 4, 32, 3, 3) }
+        // round 2: PIPE 1 (production) vs PIPE 6 / 7 (wave halves half a chunk apart, 7 = + s_setprio around the MFMA block), interleaved rounds
+        for (int rnd = 0; rnd < 3; ++rnd) {
+            for (int sg : {0, 8000}) { a2.stagger = sg; printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 1) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 6) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 7) }
+        }
+        a2.stagger = 0;
+        TRY_GATE3(2, 2, 4, 2, 32, 2, 1) TRY_GATE3(2, 2, 4, 2, 64, 3, 1) TRY_GATE3(2, 2, 4, 2, 64, 3, 6) TRY_GATE3(2, 2, 4, 2, 64, 2, 6) TRY_GATE3(2, 4, 4, 2, 32, 3, 6) TRY_GATE3(4, 2, 2, 4, 32, 3, 6)
 #ifdef WN_EPI_ABLATE
         {   // main-loop timeline of the first workgroups (wave 0 and wave 5): stamps [before vmcnt wait, after it, after barrier, after DMA issue]
             unsigned long long* tr; const size_t trn = (size_t)1024 * 2 * 64 * 4;
@@ -183,7 +185,12 @@ int main(int argc, char** argv) {
         float t2 = time_ms([&] { launch_v2<2, 2, WM_, WN_, BK_, NB_, EPI_STORE_BF16>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
         bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "X") & same({D1, (size_t)NT_ * R * 2}, {D2, (size_t)NT_ * R * 2}, "XD"); \
         printf("out    v2 WM%d WN%d BK%d NBUF%d   : %8.1f us  %7.1f TF  %s\n", WM_, WN_, BK_, NB_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
-        TRY_OUT(4, 2, 64, 3) TRY_OUT(4, 2, 32, 3) TRY_OUT(2, 4, 32, 3) TRY_OUT(4, 2, 32, 2)
+        TRY_OUT(4, 2, 32, 3)
+#define TRY_OUTP(PP_) { CK(hipMemset(O2, 0xff, NT_ * R * 2)); CK(hipMemset(D2, 0xff, NT_ * R * 2)); \
+        float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_STORE_BF16, PP_>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+        bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "X") & same({D1, (size_t)NT_ * R * 2}, {D2, (size_t)NT_ * R * 2}, "XD"); \
+        printf("out    v2 PIPE%d   : %8.1f us  %7.1f TF  %s\n", PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        for (int rnd = 0; rnd < 2; ++rnd) { TRY_OUTP(1) TRY_OUTP(6) TRY_OUTP(7) }
     }
     {   // ---------------- skip sum: M = 256, K = L*256 via nrep
         const int M = S, K = L * GH;
@@ -214,9 +221,10 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * M * K * (double)NT_;
         float t1 = time_ms([&] { launch_v1<2, 2, 2, 2, EPI_DX>(a1, M, 0); });
         printf("dx     v1 128x128            : %8.1f us  %7.1f TF\n", t1 * 1e3, fl / t1 / 1e9);
-        { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 64, 3, EPI_DX>(a2, M, 0); }); CK(hipDeviceSynchronize());
-          bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "GX");
-          printf("dx     v2 WM4 WN2 BK64 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+#define TRY_DXP(PP_) { CK(hipMemset(O2, 0xff, NT_ * R * 2)); float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DX, PP_>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+          bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "GX"); \
+          printf("dx     v2 PIPE%d   : %8.1f us  %7.1f TF  %s\n", PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        for (int rnd = 0; rnd < 2; ++rnd) { TRY_DXP(1) TRY_DXP(6) TRY_DXP(7) }
         { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DX>(a2, M, 0); }); CK(hipDeviceSynchronize());
           bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "GX");
           printf("dx     v2 WM4 WN2 BK32 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
@@ -226,14 +234,15 @@ int main(int argc, char** argv) {
         bf16_t* Apk = dev_bf16_random((size_t)M * K, 0.05f);
         bf16_t* O1 = dev_zero<bf16_t>(NT_ * G); bf16_t* O2 = dev_zero<bf16_t>(NT_ * G);
         GemmArgs a; base(a, Apk, K); a.nseg = 2; a.seg[0] = mkseg(X, R, 0, R, 0); a.seg[1] = mkseg(XD, S, 0, S, 0);
-        a.e.in0 = TSin; a.e.ld_in0 = G; a.e.ld_out0 = G; a.e.M_valid = M;
+        a.e.in0 = TSin; a.e.in1 = U; a.e.ld_in0 = GH; a.e.ld_out0 = G; a.e.M_valid = M;      // sigmoid + u of the forward
         GemmArgs a1 = a; a1.e.out0 = O1; GemmArgs a2 = a; a2.e.out0 = O2;
         const double fl = 2.0 * M * K * (double)NT_;
         float t1 = time_ms([&] { launch_v1<2, 2, 2, 2, EPI_DGATE>(a1, M, 0); });
         printf("dgate  v1 128x128            : %8.1f us  %7.1f TF\n", t1 * 1e3, fl / t1 / 1e9);
-        { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 64, 3, EPI_DGATE>(a2, M, 0); }); CK(hipDeviceSynchronize());
-          bool ok = same({O1, (size_t)NT_ * G * 2}, {O2, (size_t)NT_ * G * 2}, "DZ");
-          printf("dgate  v2 WM4 WN2 BK64 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+#define TRY_DGP(PP_) { CK(hipMemset(O2, 0xff, NT_ * G * 2)); float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DGATE, PP_>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+          bool ok = same({O1, (size_t)NT_ * G * 2}, {O2, (size_t)NT_ * G * 2}, "DZ"); \
+          printf("dgate  v2 PIPE%d   : %8.1f us  %7.1f TF  %s\n", PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        for (int rnd = 0; rnd < 2; ++rnd) { TRY_DGP(1) TRY_DGP(6) TRY_DGP(7) }
         { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DGATE>(a2, M, 0); }); CK(hipDeviceSynchronize());
           bool ok = same({O1, (size_t)NT_ * G * 2}, {O2, (size_t)NT_ * G * 2}, "DZ");
           printf("dgate  v2 WM4 WN2 BK32 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
