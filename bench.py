@@ -72,10 +72,10 @@ def alg_bytes_per_sample(hp, e=2):
     return 3 * e * (L * (2 * R + C + 2 * S) + cin + O) + 2 * e * L * (G + G // 2)
 
 
-# measured HBM-side traffic of the gate-GEMM launches at C2, scaled to B=8 x T=11000 rows: the production half-batch launch (44 000 rows) fetches
-# 2 x 23.16e3 KiB (profiles/r1g_pmc_fetch_tile_order1.md; 2 x 30.13e3 KiB with the interleaved tile order) and writes 66.0e3 KiB
-# (profiles/r1f_pmc_write.md)
-GATE_TRAFFIC_BYTES = 2.0 * (2 * 23.16e3 + 66.0e3) * 1024.0
+# measured HBM-side traffic of the gate-GEMM launches at C2 (profiles/r2e_pmc_fetch.md + r2e_pmc_write.md, 48 half-batch launches of 44 000 rows per
+# step): 2 x FETCH_SIZE = 2.27 GB and WRITE_SIZE = 2.16 GB per step => 92.3 MB per launch (algorithmic: 29.6 MB of activations read + 45.1 MB written:
+# sigmoid + gate output); scaled to 8 x 11 000 rows below
+GATE_TRAFFIC_BYTES = 2.0 * (2.27e9 + 2.16e9) / 48.0
 
 
 def synthetic_batch(hp, B, T, seed, device):
@@ -265,8 +265,8 @@ class SmiSampler:
 
 # HBM-side traffic of one C2 training step, ALL kernels: sum over the kernels of (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3
 # PMC passes of this round (separate passes; FETCH_SIZE doubled as the gfx950 calibration in DESIGN 4 prescribes), per step.
-STEP_TRAFFIC_BYTES = {'c2': None}
-STEP_TRAFFIC_SOURCE = 'profiles/r2_pmc_fetch.md + profiles/r2_pmc_write.md'
+STEP_TRAFFIC_BYTES = {'c2': 35.18e9}          # 26.18 GB fetched + 9.00 GB written (round 1: 36.99 + 10.18 = 47.17 GB)
+STEP_TRAFFIC_SOURCE = 'profiles/r2e_pmc_fetch.md + profiles/r2e_pmc_write.md'
 
 
 def main():
@@ -409,9 +409,9 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1> (dilated conv + cond GEMM + gate, fwd)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
                          'traffic': GATE_TRAFFIC_BYTES * rows_launch / (8 * 11000.0) if args.workload == 'c2' and T == 11000 else None,
-                         'traffic_source': 'profiles/r1g_pmc_fetch_tile_order1.md + r1f_pmc_write.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC in separate passes, gfx950 correction), scaled by rows per launch',
+                         'traffic_source': 'profiles/r2e_pmc_fetch.md + r2e_pmc_write.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC in separate passes, gfx950 correction), scaled by rows per launch',
                          'launches_timed': int(prof_n), 'avg_launch_ms': avg_s * 1e3 if prof_n else None,
-                         'alg_flops_per_launch': flops_launch, 'alg_bytes_per_launch': float(rows_launch) * (2 * R + 2 * C + 2 * G + G),
+                         'alg_flops_per_launch': flops_launch, 'alg_bytes_per_launch': float(rows_launch) * (2 * R + 2 * C + 2 * G),
                          'rows_per_launch': rows_launch,
                          'note': 'each launch covers one half-batch; its duration includes time shared with the HBM-bound out-conv launches of the other half-batch running concurrently on a second stream'},
             'roofline_exclusive': {'what': 'same kernel, whole batch on one stream (no concurrent kernels), 2 untimed steps after the timed region',

@@ -313,8 +313,8 @@ def split(x, num_or_size_splits, axis=0):
     return list(torch.split(x, list(n), dim=axis))
 
 
-def concat(xs, axis):
-    return torch.cat(list(xs), dim=axis)
+def concat(values, axis=0, name=None):          # tf.concat(values, axis); wavenet.py:574 calls it with keywords
+    return torch.cat(list(values), dim=axis)
 
 
 def pad(x, paddings):

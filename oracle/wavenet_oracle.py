@@ -20,8 +20,11 @@ That variant is used for tight kernel-logic checks; the plain fp32 variant is th
 reference arithmetic.
 
 Pinned (see oracle/__init__.py): step / upsample / training_loss / incremental reproduce, to fp32 round-off, the outputs
-of the reference's own wavenet.py + modules.py executed on the eager TF-1 stand-in (tests/golden/stack_*.npz); the
-optimiser row (TF library semantics) is parity unpinned.
+of the reference's own wavenet.py + modules.py executed on the eager TF-1 stand-in (tests/golden/stack_*.npz); train_step
+reproduces three steps of the reference's own add_loss + add_optimizer executed there (tests/golden/optim_golden.npz: gradient
+set, tower mean, per-variable clip_by_norm -> clip_by_value, Adam on the clipped gradients, EMA after the update, LR schedule).
+The arithmetic INSIDE TensorFlow's library calls (ApplyAdam, clip_by_norm, assign_moving_average, exponential_decay) is restated
+from TF 1.x's documented formulas (oracle/gen_golden_optim.py lists them) -- that part stays parity unpinned: TF is not installable.
 """
 import math
 from collections import OrderedDict
@@ -681,7 +684,7 @@ def adam_ema_update(p, g, m, v, ema, step, lr, beta1=0.9, beta2=0.999, eps=1e-6,
 
 
 def train_step(params, opt_state, cfg: OracleConfig, x, c, y, lengths, step_idx, dropout_masks=None,
-               lr_kwargs=None, clip=True, max_norm=100.0, max_value=5.0, world_grads=None):
+               lr_kwargs=None, clip=True, max_norm=100.0, max_value=5.0, world_grads=None, adam_kwargs=None):
     """One full training step: fwd + loss + autograd bwd + clip + TF-Adam + EMA.
     opt_state: dict name -> (m, v, ema).  ``world_grads``: optional list of per-"tower" grad dicts
     to average with (wavenet.py:560-575)."""
@@ -699,7 +702,7 @@ def train_step(params, opt_state, cfg: OracleConfig, x, c, y, lengths, step_idx,
     for k, p in params.items():
         g = clip_gradient(grads[k], max_norm, max_value) if clip else grads[k]
         m, v, e = opt_state[k]
-        np_, m, v, e = adam_ema_update(p, g, m, v, e, step_idx + 1, lr)
+        np_, m, v, e = adam_ema_update(p, g, m, v, e, step_idx + 1, lr, **(adam_kwargs or {}))
         new_p[k] = np_
         new_s[k] = (m, v, e)
     return loss.detach(), grads, new_p, new_s

@@ -133,3 +133,14 @@ def device_uniform_noise(n, seed):
     w = philox4x32_10(g, seed).reshape(-1)[:n]
     u01 = ((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
     return np.minimum(np.maximum(u01, np.float32(1e-5)), np.float32(1.0) - np.float32(1e-5))
+
+
+def device_normal_noise(n, seed):
+    """Mirror of the device's Gaussian stream (Box-Muller on the word pairs (w0, w1), (w2, w3) of each Philox group), float64."""
+    g = np.arange((n + 3) // 4, dtype=np.uint64)
+    w = philox4x32_10(g, seed)
+    u = ((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    u = u.astype(np.float64)
+    r0, r1 = np.sqrt(-2 * np.log(u[:, 0])), np.sqrt(-2 * np.log(u[:, 2]))
+    p0, p1 = 2 * np.pi * u[:, 1], 2 * np.pi * u[:, 3]
+    return np.stack([r0 * np.cos(p0), r0 * np.sin(p0), r1 * np.cos(p1), r1 * np.sin(p1)], 1).reshape(-1)[:n]

@@ -14,7 +14,8 @@ wavenet.py:476-495 (loss alignment + mask), optimizer.compute_gradients wavenet.
 The oracle runs utterance by utterance (forward activations compared and freed per chunk, gradients accumulated with the
 chunk's share of the masked-mean denominator), so its memory stays ~6 GB at any batch size.
 
-Tolerances: <= 3x the values measured on MI355X (profiles/r2_pytest_gpu_verbose.log keeps the `-s` output).
+Tolerances: <= 3x the values measured on MI355X (profiles/r2*_pytest_gpu_verbose.log keeps the `-s` output,
+profiles/r2*_parity_*.json the per-case numbers).
 """
 import json
 import os
@@ -38,7 +39,7 @@ C5 = dict(layers=30, stacks=3, residual_channels=512, gate_channels=1024, skip_o
           hop_size=300, legacy=True, residual_legacy=True, wavenet_dropout=0.05, log_scale_min_gauss=float(np.log(1e-7)),
           cdf_loss=False, NN_scaler=0.1, upsample_activation='Relu', freq_axis_kernel_size=3)
 
-# Tolerances = (measured on MI355X, round 2: profiles/r2_pytest_gpu_verbose.log) x <= 3.
+# Tolerances = (measured on MI355X, round 2: profiles/r2e_pytest_gpu_verbose.log, r2e_parity_*.json) x <= 3.
 # Two kinds of activation checks:
 #  * layer-LOCAL: the oracle's layer l applied to the DEVICE's own input of layer l (same dropout mask, same conditioning) vs the
 #    device's outputs of that layer (gate output U_l, next input X_{l+1}).  Only fp32 summation order and the occasional bf16
@@ -49,12 +50,12 @@ C5 = dict(layers=30, stacks=3, residual_channels=512, gate_channels=1024, skip_o
 #    ~1 ulp-noise per layer and grows like sqrt(depth): measured 5.6e-3 at layer 11, 9.7e-3 at layer 23 / y_hat (the same in the
 #    2-stack, the 4-stack and the synthesis pipeline; 3.6e-3 flat with residual_legacy's sqrt(.5) damping).  Not tightenable by
 #    construction, hence the layer-local check.
-TOL_LOCAL = 1.2e-3      # layer-local U_l / X_{l+1}
-TOL_ACT = 3e-2          # end-to-end per-layer X / U vs the emulating oracle, rel-L2
-TOL_YHAT = 3e-2         # end-to-end y_hat vs the emulating oracle
+TOL_LOCAL = 6e-4        # layer-local U_l / X_{l+1}                                   (measured <= 1.9e-4)
+TOL_ACT = 3e-2          # end-to-end per-layer X / U vs the emulating oracle, rel-L2  (measured <= 1.0e-2)
+TOL_YHAT = 3e-2         # end-to-end y_hat vs the emulating oracle                    (measured <= 1.0e-2)
 TOL_YHAT_FP32 = 3e-2    # y_hat vs the fp32 oracle (the stated price of bf16 operands)
-TOL_GRAD_GLOBAL = 4.5e-3
-TOL_GRAD_TENSOR = 1e-2      # residual stack + head + input conv tensors (measured <= 4.4e-3)
+TOL_GRAD_GLOBAL = 5e-3      # all gradients as one vector                               (measured <= 1.7e-3)
+TOL_GRAD_TENSOR = 1.4e-2    # residual stack + head + input conv tensors                (measured <= 4.7e-3)
 TOL_GRAD_UPSAMPLE = 1.2e-1  # the 6 upsample-net tensors (<= 55 elements each; every element sums bf16 d z over all layers and rows: measured <= 3.9e-2)
 
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from hip_util import SMALL, device_uniform_noise, make_hp, oracle_cfg, rel_err, synth_batch, upload_params
+from hip_util import SMALL, device_normal_noise, device_uniform_noise, make_hp, oracle_cfg, rel_err, synth_batch, upload_params
 from oracle import wavenet_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -31,11 +31,12 @@ def test_device_noise_stream_is_philox_bit_exact():
     # Gaussian head: Box-Muller on the same words -> standard normal statistics
     kw = dict(SMALL); kw.update(out_channels=2, log_scale_min_gauss=float(np.log(1e-7)))
     eng2 = _engine(make_hp(**kw), 2, 64)
-    z = torch.empty(4096, 2, 1, device='cuda')
-    eng2.fill_noise(z, 2, 4096, seed=7)
+    z = torch.empty(16384, 2, 1, device='cuda')
+    eng2.fill_noise(z, 2, 16384, seed=8)
     z = z.cpu().double().flatten()
-    assert abs(float(z.mean())) < 0.05 and abs(float(z.std()) - 1.0) < 0.05
-    assert abs(float((z ** 3).mean())) < 0.15 and abs(float((z ** 4).mean()) - 3.0) < 0.4
+    np.testing.assert_allclose(z.numpy(), device_normal_noise(32768, 8), rtol=0, atol=2e-5)       # same draws as the mirror (libm log / cos differ in the last bits)
+    assert abs(float(z.mean())) < 0.03 and abs(float(z.std()) - 1.0) < 0.03                        # ... and standard normal
+    assert abs(float((z ** 3).mean())) < 0.1 and abs(float((z ** 4).mean()) - 3.0) < 0.3
 
 
 def test_inference_only_context_and_default_path():

@@ -86,8 +86,8 @@ def test_pipe_incremental_equals_batch_forward_on_device(B, kw):
 # ---- C4 scale (BASELINE configs[3]): the 24-layer / 2-stack paper model, against the ORACLE (not against another HIP path) ------
 PAPER_FULL = dict(PAPER_WIDTH, layers=24, stacks=2, out_channels=30, upsample_type='2D', upsample_scales=[5, 5, 11], hop_size=275,
                   legacy=False, residual_legacy=False, NN_scaler=0.1, log_scale_min=float(np.log(1e-14)))
-TOL_RAW_EMUL = 1.2e-2     # raw network outputs vs the bf16-emulating oracle  (<= 3x measured, profiles/r2_pytest_gpu_verbose.log)
-TOL_RAW_FP32 = 2.5e-2     # ... vs the fp32 oracle (reference arithmetic)
+TOL_RAW_EMUL = 2.5e-2     # raw network outputs vs the bf16-emulating oracle  (measured 1.03e-2: the sqrt(depth) rounding-decorrelation floor, see test_hip_bench_geometry.py)
+TOL_RAW_FP32 = 2.5e-2     # ... vs the fp32 oracle (reference arithmetic)       (measured 8.7e-3; profiles/r2e_pytest_gpu_verbose.log)
 
 
 def _oracle_teacher_forced(params, cfg, wav, c, emulate):

@@ -496,3 +496,34 @@ def test_dropout_seed_is_per_rank_and_single_gpu_compatible():
     assert dropout_seed(5339, 17) == 5339 * 1000003 + 17 == dropout_seed(5339, 17, rank=0)
     seeds = {dropout_seed(5339, s, r) for s in range(100) for r in range(8)}
     assert len(seeds) == 800 and all(0 <= v < 2 ** 64 for v in seeds)
+
+
+def test_tf_checkpoint_reader_on_independent_fixture(golden_dir, tmp_path):
+    """the TF-1 tensor-bundle reader against a fixture assembled from the format documents by an independent script
+    (oracle/gen_tf_bundle_fixture.py -- shares no code with the reader or its writer), incl. checksum verification and the mapping of
+    the reference's EMA-shadow variable names (train.py:75-83) onto engine tensor names."""
+    import shutil
+    from wavenet_vocoder import tf_checkpoint as T
+    # CRC-32C known answers (RFC 3720 B.4) and LevelDB's mask
+    assert T.crc32c(b'123456789') == 0xE3069283 and T.crc32c(bytes(32)) == 0x8A9136AA and T.crc32c(bytes([0xff] * 32)) == 0x62A8AB43
+    assert T._mask_crc(0) == 0xa282ead8
+    src = os.path.join(golden_dir, 'tf_bundle')
+    exp = np.load(os.path.join(src, 'expected.npz'))
+    got = T.load_checkpoint(os.path.join(src, 'fixture.ckpt-7'))
+    assert set(got) == set(exp.files)
+    for k in exp.files:
+        assert got[k].dtype == exp[k].dtype and got[k].shape == exp[k].shape and np.array_equal(got[k], exp[k]), k
+    assert int(got['global_step']) == 7
+    layout = {'final_convolution_1/kernel': ((1, 8, 8), 0), 'final_convolution_1/bias': ((8,), 64)}
+    flat, step, missing = T.load_reference_checkpoint(os.path.join(src, 'fixture.ckpt-7'), layout)
+    assert step == 7 and not missing
+    assert np.array_equal(flat[:64], exp['WaveNet_model/inference/final_convolution_1/kernel/ExponentialMovingAverage'].reshape(-1))
+    assert np.array_equal(flat[64:72], exp['WaveNet_model/inference/final_convolution_1/bias/ExponentialMovingAverage'])
+    # corruption is detected: one flipped bit in the index, one in the data shard
+    for name, pos in (('fixture.ckpt-7.index', 40), ('fixture.ckpt-7.data-00000-of-00001', 17)):
+        d = tmp_path / ('bad_' + name.split('.')[-1].split('-')[0])
+        shutil.copytree(src, str(d))
+        b = bytearray(open(os.path.join(str(d), name), 'rb').read()); b[pos] ^= 0x10
+        open(os.path.join(str(d), name), 'wb').write(bytes(b))
+        with pytest.raises(ValueError, match='checksum mismatch'):
+            T.load_checkpoint(os.path.join(str(d), 'fixture.ckpt-7'))

@@ -184,3 +184,36 @@ def test_reference_weightnorm_data_dependent_init_is_recorded(golden_dir):
     for k, v in p.items():
         if k.endswith('/kernel'):
             assert torch.allclose(eff[k], v, atol=1e-6)
+
+
+def test_train_step_reproduces_reference_add_optimizer(golden_dir):
+    """three training steps of the reference's own WaveNet.add_loss + add_optimizer (wavenet.py:476-613), executed on
+    the TF stand-in by oracle/gen_golden_optim.py with clip thresholds that bite, vs oracle.train_step -- the function the device
+    optimiser (wn_norm2_kernel + wn_adam_kernel) is compared with in tests/test_hip_parity.py.  Pins the composition: the gradient
+    set, per-variable clip_by_norm THEN clip_by_value, Adam on the clipped gradients at the scheduled rate, EMA after the update."""
+    import json
+    g = np.load(os.path.join(golden_dir, 'optim_golden.npz'))
+    hpj = json.loads(str(g['hparams_json']))
+    cfg = O.OracleConfig(layers=4, stacks=2, residual_channels=16, gate_channels=32, skip_out_channels=16, out_channels=6, cin_channels=8,
+                         upsample_type='2D', upsample_scales=[2, 3], NN_init=False, NN_scaler=0.3, wavenet_dropout=0.0)
+    names = [k[3:] for k in g.files if k.startswith('p0/')]
+    assert set(names) == set(O.param_shapes(cfg))
+    params = {k: torch.from_numpy(g['p0/' + k]) for k in O.param_shapes(cfg)}
+    state = O.init_opt_state(params)
+    x, c, wav, lengths = torch.from_numpy(g['x']), torch.from_numpy(g['c']), torch.from_numpy(g['wav']), [int(v) for v in g['lengths']]
+    B, T = wav.shape
+    lrk = dict(init_lr=hpj['wavenet_learning_rate'], schedule='exponential', decay_rate=hpj['wavenet_decay_rate'], decay_steps=hpj['wavenet_decay_steps'])
+    adk = dict(beta1=hpj['wavenet_adam_beta1'], beta2=hpj['wavenet_adam_beta2'], eps=hpj['wavenet_adam_epsilon'], ema_decay=hpj['wavenet_ema_decay'])
+    n_clipped = 0
+    for s in range(3):
+        assert abs(float(O.learning_rate(s, **lrk)) - float(g['lr/%d' % s])) <= 1e-9
+        loss, grads, params, state = O.train_step(params, state, cfg, x, c, wav.view(B, T, 1), lengths, s, lr_kwargs=lrk,
+                                                  max_norm=hpj['wavenet_gradient_max_norm'], max_value=hpj['wavenet_gradient_max_value'], adam_kwargs=adk)
+        assert abs(float(loss) - float(g['loss/%d' % s])) <= 2e-6 * abs(float(g['loss/%d' % s]))
+        for k in names:
+            ref_g = torch.from_numpy(g['g%d/%s' % (s, k)])
+            assert torch.allclose(grads[k], ref_g, rtol=2e-4, atol=2e-7), (s, k)             # same gradient set (before clipping)
+            n_clipped += int(float(ref_g.norm()) > hpj['wavenet_gradient_max_norm']) + int(float(ref_g.abs().max()) > hpj['wavenet_gradient_max_value'])
+            assert torch.allclose(params[k], torch.from_numpy(g['p%d/%s' % (s + 1, k)]), rtol=1e-5, atol=2e-7), (s, k)
+            assert torch.allclose(state[k][2], torch.from_numpy(g['ema%d/%s' % (s + 1, k)]), rtol=1e-5, atol=2e-7), (s, k)
+    assert n_clipped > 60                                                                  # both clips were active in the fixture
