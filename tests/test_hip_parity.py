@@ -1,11 +1,15 @@
 """HIP path vs oracle on identical seeded inputs (run on the GPU box: pytest -m gpu).
 
-Tolerances (stated per SURVEY.md 8c):
-  * vs the bf16-emulating oracle (same rounding points, fp32 contraction): activations rel-L2 <= 2e-2,
-    loss rtol 5e-3  -- checks kernel LOGIC tightly;
-  * vs the pure fp32 oracle (the reference arithmetic): loss rtol 2e-2, y_hat rel-L2 <= 5e-2 -- the
-    documented price of bf16 MFMA operands;
-  * gradients vs autograd of the emulating oracle: per-tensor rel-L2 <= 6e-2 (bf16 backward signals);
+Tolerances = (values measured on MI355X in round 2, profiles/r2f_pytest_gpu_all_verbose.log) x <= 3:
+  * vs the bf16-emulating oracle (same rounding points, fp32 contraction) -- the check of kernel LOGIC: per-layer activations
+    rel-L2 <= 8e-3 (measured <= 2.7e-3), y_hat <= 2.4e-2 (measured <= 7.9e-3: the 512-channel legacy config; <= 3e-3 elsewhere),
+    device loss vs the oracle's loss on the device's own y_hat rtol 2e-4;
+  * vs the pure fp32 oracle (the reference arithmetic): y_hat rel-L2 <= 2.6e-2 (measured <= 8.7e-3), loss rtol 5e-3 -- the stated
+    price of bf16 MFMA operands;
+  * gradients vs autograd of the emulating oracle: all tensors as one vector <= 7e-3 (measured <= 2.4e-3), every residual-stack /
+    head tensor <= 1.4e-2 (measured <= 4.5e-3), the input convolution and the upsample-net tensors (a few hundred elements each,
+    at the far end of the bf16 backward signals) <= 4.5e-2 (measured <= 1.4e-2); the mu-law / softmax configuration, whose one-hot
+    input and 256-way head concentrate the signal in few elements: 4.5e-2 / 1e-1 / 1.2e-1 (measured 1.5e-2 / 3.2e-2 / 4.1e-2);
   * integer outputs (mu-law indices, argmax, categorical samples given identical logits+noise): bit-exact.
 """
 import os
@@ -140,12 +144,14 @@ def test_train_forward(name):
     print('\n[%s] ' % name + '  '.join('%s=%.2e' % kv for kv in rep))
     print('[%s] loss dev=%.6f oracle(dev y_hat)=%.6f emul=%.6f fp32=%.6f' % (name, ld, loss_same, loss_em, loss_fp))
     assert np.isfinite(ld)
-    for k, v in rep[:-1]:
-        assert v < 2e-2, (k, v)
-    assert rep[-1][1] < 5e-2
+    for k, v in rep[:-2]:
+        assert v < 8e-3, (k, v)                      # per-layer activations vs the emulating oracle
+    assert rep[-2][1] < 2.4e-2, rep[-2]              # y_hat vs the emulating oracle
+    assert rep[-1][1] < 2.6e-2, rep[-1]              # y_hat vs the fp32 oracle
     assert abs(ld - loss_same) <= 2e-4 * max(1.0, abs(loss_same)), 'loss kernel vs oracle on identical y_hat'
-    assert abs(ld - loss_em) <= 5e-3 * max(1.0, abs(loss_em))
-    assert abs(ld - loss_fp) <= 2e-2 * max(1.0, abs(loss_fp))
+    # (secondary signals: a loss moves little even under a gross activation error)
+    assert abs(ld - loss_em) <= 2e-3 * max(1.0, abs(loss_em))
+    assert abs(ld - loss_fp) <= 5e-3 * max(1.0, abs(loss_fp))
 
 
 def test_ragged_lengths_and_tail_tile():
@@ -153,7 +159,7 @@ def test_ragged_lengths_and_tail_tile():
     r = _run_fwd('mol_2d', B=3, T=336, lengths=[336, 200, 17])
     cfg = r['cfg']
     y_em = O.step(r['params'], cfg, r['x_or'], r['c'], emulate_bf16=True)
-    assert rel_err(r['yhat_dev'].cpu(), y_em) < 2e-2
+    assert rel_err(r['yhat_dev'].cpu(), y_em) < 5e-3
     loss_same = float(O.training_loss(cfg, r['yhat_dev'].cpu(), r['y_or'], r['lengths']))
     assert abs(float(r['loss_dev'].item()) - loss_same) <= 2e-4 * max(1.0, abs(loss_same))
 
@@ -183,9 +189,11 @@ def test_train_backward(name):
         print('   %-70s rel=%.3e |g|=%.3e' % (k, e, n))
     total = torch.cat([g_dev[k].flatten() for k in g_or]), torch.cat([g_or[k].flatten() for k in g_or])
     print('[%s] global grad rel err %.3e' % (name, rel_err(*total)))
-    assert rel_err(*total) < 4e-2
+    soft = name == 'softmax_c1'
+    assert rel_err(*total) < (4.5e-2 if soft else 7e-3)
     for e, k, n in worst:
-        assert e < 8e-2, (k, e, n)
+        far = k.startswith(('input_convolution', 'local_conditioning_upsampling', 'gc_embedding'))
+        assert e < ((1.2e-1 if far else 1e-1) if soft else (4.5e-2 if far else 1.4e-2)), (k, e, n)
 
 
 def test_optimizer_step_matches_tf_adam():
@@ -321,7 +329,7 @@ def test_training_reduces_loss_and_tracks_oracle_trajectory():
     print('\ndevice losses', ['%.4f' % l for l in dev_losses]); print('oracle losses', ['%.4f' % l for l in or_losses])
     assert dev_losses[-1] < dev_losses[0] - 0.05 and or_losses[-1] < or_losses[0] - 0.05
     for a, b in zip(dev_losses, or_losses):
-        assert abs(a - b) <= 2e-2 * max(1.0, abs(b))                   # bf16 path vs fp32 oracle, compounding over the steps
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b))                   # bf16 path vs fp32 oracle, compounding over the steps (measured <= 2.5e-4)
     # parameters after 12 updates stay close to the oracle's
     p_or = torch.cat([params[k].reshape(-1) for k in eng.layout])
     p_dev = torch.cat([flat.cpu()[off:off + int(np.prod(shape))] for _, (shape, off) in eng.layout.items()])

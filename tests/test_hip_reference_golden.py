@@ -1,8 +1,9 @@
 """HIP path vs golden vectors produced by executing the REFERENCE's own wavenet.py / modules.py (oracle/gen_golden_stack.py,
 eager TF-1 stand-in): the device results are compared with the reference's outputs directly, not via the oracle.
 
-Tolerances (bf16 MFMA operands, fp32 accumulation -- DESIGN.md section 5): y_hat rel-L2 <= 5e-2, loss rtol 2e-2,
-upsampled conditioning (fp32 kernels) rtol 1e-4; synthesis raw outputs rel-L2 <= 5e-2 teacher-forced."""
+Tolerances (bf16 MFMA operands, fp32 accumulation -- DESIGN.md section 5) = measured x <= 3 (profiles/r2f_pytest_gpu_all_verbose.log):
+y_hat rel-L2 <= 1.3e-2 (measured 3.2 - 4.3e-3), loss rtol 1e-3 (measured <= 3e-4), upsampled conditioning (fp32 kernels) rtol 1e-4;
+synthesis raw outputs rel-L2 <= 1.4e-2 teacher-forced (measured 3.4 - 4.5e-3)."""
 import glob
 import json
 import os
@@ -63,8 +64,8 @@ def test_device_matches_reference_execution(path):
     np.testing.assert_allclose(cup.numpy(), g['c_up'], rtol=1e-4, atol=1e-5)                   # wavenet.py:680-702
     e = rel_err(y_hat.cpu(), torch.from_numpy(g['y_hat']))
     print('\n[%s] y_hat rel-L2 vs reference execution %.3e; loss dev %.6f ref %.6f' % (os.path.basename(path), e, float(loss), float(g['loss'][0])))
-    assert e < 5e-2
-    assert abs(float(loss) - float(g['loss'][0])) <= 2e-2 * max(1.0, abs(float(g['loss'][0])))
+    assert e < 1.3e-2
+    assert abs(float(loss) - float(g['loss'][0])) <= 1e-3 * max(1.0, abs(float(g['loss'][0])))
     if 'inc_tf_raw' not in g.files:
         return
     # synthesis, teacher-forced with the reference's own sampler noise: raw network outputs per step (wavenet.py:724-911)
@@ -77,4 +78,4 @@ def test_device_matches_reference_execution(path):
     torch.cuda.synchronize()
     e2 = rel_err(raw.cpu(), torch.from_numpy(g['inc_tf_raw']))
     print('[%s] incremental raw rel-L2 vs reference execution %.3e' % (os.path.basename(path), e2))
-    assert e2 < 5e-2
+    assert e2 < 1.4e-2

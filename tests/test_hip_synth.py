@@ -65,7 +65,7 @@ def test_teacher_forced_matches_oracle(kw):
     o_or, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=ti_or, formulation='reference', g=g)
     e = rel_err(raw.cpu(), r_or)
     print('\nteacher-forced raw rel err %.3e' % e)
-    assert e < 3e-2
+    assert e < 1.4e-2                                  # measured 3.3 - 4.4e-3 (profiles/r2f_pytest_gpu_all_verbose.log)
     # sampler on the device's own raw outputs == device samples
     if cfg.input_type == 'mulaw-quantize':
         exp = torch.stack([O.sample_categorical(raw.cpu()[:, :, t], nz_or['gumbel_u'][t]) for t in range(T)], 1)
@@ -93,7 +93,7 @@ def test_free_running_feedback_path():
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
     _, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=out.cpu().unsqueeze(-1), formulation='ring')
-    assert rel_err(raw.cpu(), r_or) < 3e-2
+    assert rel_err(raw.cpu(), r_or) < 1.4e-2
 
 
 def test_incremental_equals_batch_forward_on_device():
@@ -111,4 +111,4 @@ def test_incremental_equals_batch_forward_on_device():
     torch.cuda.synchronize()
     e = rel_err(raw, yhat)
     print('\nincremental vs batch (both HIP) rel err %.3e' % e)
-    assert e < 2e-2
+    assert e < 5e-3                                    # measured 1.3e-3

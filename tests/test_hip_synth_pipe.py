@@ -34,7 +34,7 @@ def test_pipe_teacher_forced_matches_oracle(kw):
     o_or, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=ti_or, formulation='reference')
     e = rel_err(raw.cpu(), r_or)
     print('\npipe teacher-forced raw rel err %.3e' % e)
-    assert e < 3e-2
+    assert e < 1.4e-2                                  # measured 3.3 - 4.4e-3
     if cfg.input_type == 'mulaw-quantize':
         exp = torch.stack([O.sample_categorical(raw.cpu()[:, :, t], nz_or['gumbel_u'][t]) for t in range(T)], 1)
         assert torch.equal(out.cpu().long(), exp)                                   # bit-exact class ids
@@ -48,7 +48,7 @@ def test_pipe_teacher_forced_matches_oracle(kw):
     out2 = torch.empty_like(out); raw2 = torch.empty_like(raw)
     eng.synthesize(c.cuda(), nz_dev.cuda(), out2, raw2, ti_dev, steps_per_graph=8)
     torch.cuda.synchronize()
-    assert rel_err(raw, raw2) < 2e-2
+    assert rel_err(raw, raw2) < 1.4e-2
 
 
 def test_pipe_free_running_feedback_path():
@@ -60,7 +60,7 @@ def test_pipe_free_running_feedback_path():
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
     _, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=out.cpu().unsqueeze(-1), formulation='ring')
-    assert rel_err(raw.cpu(), r_or) < 3e-2
+    assert rel_err(raw.cpu(), r_or) < 1.4e-2
 
 
 @pytest.mark.parametrize('B,kw', [(4, dict(layers=6, stacks=2)), (8, dict(layers=8, stacks=2)),
@@ -80,7 +80,7 @@ def test_pipe_incremental_equals_batch_forward_on_device(B, kw):
     torch.cuda.synchronize()
     e = rel_err(raw, yhat)
     print('\npipe incremental vs batch (both HIP) B=%d rel err %.3e' % (B, e))
-    assert e < 2e-2
+    assert e < 2.8e-2                                  # measured 3.8e-3 .. 9.3e-3 (24 layers: two independently rounded HIP paths)
 
 
 # ---- C4 scale (BASELINE configs[3]): the 24-layer / 2-stack paper model, against the ORACLE (not against another HIP path) ------
