@@ -27,6 +27,11 @@ import os
 import sys
 import time
 
+# The step runs on 3 streams (two batch parts + the weight-gradient stream), data parallel adds the all-reduce stream(s): more than the
+# runtime's default of 4 hardware queues, and streams that share a queue serialise (profiles/r2g_ab_batch_parts.txt).  Must be set before
+# the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'tacotron-2_amd')):
     if p not in sys.path:

@@ -258,7 +258,9 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->params_dev) hipFree(c->params_dev);
     if (c->st2) { (void)hipStreamSynchronize(c->st2); hipStreamDestroy(c->st2); }      // nothing of ours may still be running on it
     if (c->st3) { (void)hipStreamSynchronize(c->st3); hipStreamDestroy(c->st3); }
-    for (int p = 0; p < 2; ++p) for (int k = 0; k < WN_MAX_BUCKETS; ++k) if (c->ev_chain[p][k]) hipEventDestroy(c->ev_chain[p][k]);
+    for (int k = 2; k < WN_MAX_PARTS; ++k) if (c->stp[k]) { (void)hipStreamSynchronize(c->stp[k]); hipStreamDestroy(c->stp[k]); }
+    for (int k = 0; k < WN_MAX_PARTS; ++k) if (c->ev_pjoin[k]) hipEventDestroy(c->ev_pjoin[k]);
+    for (int p = 0; p < WN_MAX_PARTS; ++p) for (int k = 0; k < WN_MAX_BUCKETS; ++k) if (c->ev_chain[p][k]) hipEventDestroy(c->ev_chain[p][k]);
     for (int k = 0; k < WN_MAX_BUCKETS + 2; ++k) if (c->ev_bucket[k]) hipEventDestroy(c->ev_bucket[k]);
     if (c->ev_w0) hipEventDestroy(c->ev_w0);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);

@@ -134,11 +134,14 @@ struct wn_ctx {
     bool prof = false; std::vector<hipEvent_t> pev; size_t pev_used = 0;
     // batch parts: the serial layer chain of the two half-batches runs on two streams so that the MFMA/power-bound GEMMs of
     // one half overlap the HBM-bound kernels of the other (fwd: gate | out conv, bwd: dx | dgate); joined before the loss / wgrads
-    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int parts = 1; int parts_req = 0; int prof_rows = 0;
+#define WN_MAX_PARTS 4
+    hipStream_t st2 = nullptr;            // part 1 (and the "side" work of the backward tail)
+    hipStream_t stp[WN_MAX_PARTS] = {};   // stp[k], k >= 2: further batch parts (stp[1] aliases st2)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pjoin[WN_MAX_PARTS] = {}; int parts = 1; int parts_req = 0; int prof_rows = 0;
     // gradient buckets (wn_train.hip: wn_plan_buckets): weight gradients run bucket by bucket on a third, low-priority stream under
     // the serial backward chain; ev_bucket[k] = bucket k of the flat gradient is final (index WN_MAX_BUCKETS: the whole buffer)
 #define WN_MAX_BUCKETS 8
-    hipStream_t st3 = nullptr; hipEvent_t ev_chain[2][WN_MAX_BUCKETS] = {}; hipEvent_t ev_bucket[WN_MAX_BUCKETS + 2] = {}; hipEvent_t ev_w0 = nullptr;
+    hipStream_t st3 = nullptr; hipEvent_t ev_chain[WN_MAX_PARTS][WN_MAX_BUCKETS] = {}; hipEvent_t ev_bucket[WN_MAX_BUCKETS + 2] = {}; hipEvent_t ev_w0 = nullptr;
     int nbuckets = 0, nbuckets_early = 0; int bucket_lo[WN_MAX_BUCKETS + 2] = {}, bucket_hi[WN_MAX_BUCKETS + 2] = {};
     int64_t bucket_off[WN_MAX_BUCKETS + 2] = {}, bucket_cnt[WN_MAX_BUCKETS + 2] = {}; bool have_bwd = false;
     bool inference = false;               // cfg.inference_only: no training workspace, synthesis state pre-sized at wn_create

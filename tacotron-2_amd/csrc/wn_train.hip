@@ -158,20 +158,27 @@ size_t wn_wgrad_partial_need(wn_ctx* c) {
 }
 
 // ---- batch parts on two streams ---------------------------------------------------------------------------------------
-static int parts_setup(wn_ctx* c) {
+static int parts_setup(wn_ctx* c, int np) {
     if (!c->st2) {
         WN_HIP(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
         WN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         WN_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        c->stp[1] = c->st2;
+        for (int k = 0; k < WN_MAX_PARTS; ++k) WN_HIP(c, hipEventCreateWithFlags(&c->ev_pjoin[k], hipEventDisableTiming));
     }
+    // further part streams only on demand: the runtime multiplexes streams onto a few hardware queues (4 by default), and a stream
+    // that merely EXISTS can end up sharing a queue with -- i.e. serialising against -- one of the streams that carry the step
+    // (measured: two idle extra streams cost 1.2 ms per step)
+    for (int k = 2; k < np; ++k)
+        if (!c->stp[k]) WN_HIP(c, hipStreamCreateWithFlags(&c->stp[k], hipStreamNonBlocking));
     return WN_OK;
 }
 static int n_parts(wn_ctx* c) {
     static const int env = [] { const char* e = getenv("WN_BATCH_PARTS"); return e ? atoi(e) : 2; }();   // 1 disables the overlap (A/B switch)
     const int want = c->parts_req > 0 ? c->parts_req : env;
-    return (want >= 2 && c->fB >= 2) ? 2 : 1;
+    return std::max(1, std::min(std::min(want, WN_MAX_PARTS), c->fB));
 }
-extern "C" int wn_set_batch_parts(wn_ctx* c, int32_t parts) { if (!c || parts < 0 || parts > 2) return WN_E_ARG; c->parts_req = parts; return WN_OK; }
+extern "C" int wn_set_batch_parts(wn_ctx* c, int32_t parts) { if (!c || parts < 0 || parts > WN_MAX_PARTS) return WN_E_ARG; c->parts_req = parts; return WN_OK; }
 
 // layers + skip sum + head of the utterances [b0, b0 + nb) on stream st (wavenet.py:706-721)
 static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
@@ -237,16 +244,20 @@ static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
 template <class F> static int for_each_part(wn_ctx* c, hipStream_t st, F f) {
     const int np = n_parts(c);
     c->parts = np;
-    if (np == 1) return f(0, c->fB, st, true);
-    int rc = parts_setup(c);
+    if (np == 1) return f(0, c->fB, st, true, 0);
+    int rc = parts_setup(c, np);
     if (rc) return rc;
-    const int nb0 = (c->fB + 1) / 2;
+    // part k takes the utterances [k * fB / np, (k + 1) * fB / np): parts 1.. on the ctx-owned streams, part 0 on the caller's
     WN_HIP(c, hipEventRecord(c->ev_fork, st));
-    WN_HIP(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
-    if ((rc = f(nb0, c->fB - nb0, c->st2, false))) return rc;
-    WN_HIP(c, hipEventRecord(c->ev_join, c->st2));
-    if ((rc = f(0, nb0, st, true))) return rc;
-    WN_HIP(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    for (int k = np - 1; k >= 0; --k) {
+        const int b0 = (int)((int64_t)k * c->fB / np), b1 = (int)((int64_t)(k + 1) * c->fB / np);
+        if (k > 0) {
+            WN_HIP(c, hipStreamWaitEvent(c->stp[k], c->ev_fork, 0));
+            if ((rc = f(b0, b1 - b0, c->stp[k], false, k))) return rc;
+            WN_HIP(c, hipEventRecord(c->ev_pjoin[k], c->stp[k]));
+        } else if ((rc = f(b0, b1 - b0, st, true, 0))) return rc;
+    }
+    for (int k = 1; k < np; ++k) WN_HIP(c, hipStreamWaitEvent(st, c->ev_pjoin[k], 0));
     return WN_OK;
 }
 
@@ -255,7 +266,7 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
     if ((rc = wn_upsample_fwd(c, nullptr, c->fc, c->fB, c->fTc, st))) return rc;     // wavenet.py:680-702
     if ((rc = wn_first_conv(c, st))) return rc;                                      // wavenet.py:705
     if ((rc = wn_gbias_fwd(c, c->fB, st))) return rc;                                // wavenet.py:669-678
-    rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first) {
+    rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first, int) {
         if (first) c->prof_rows = nb * c->fT;      // rows of one timed gate-GEMM launch (wn_profile_result)
         return fwd_part(c, b0, nb, s, c->prof && first);
     });
@@ -342,7 +353,7 @@ static int buckets_setup(wn_ctx* c) {
     int lo_pri = 0, hi_pri = 0;
     WN_HIP(c, hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));            // (least, greatest)
     WN_HIP(c, hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, lo_pri));
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < WN_MAX_PARTS; ++p)
         for (int k = 0; k < WN_MAX_BUCKETS; ++k) WN_HIP(c, hipEventCreateWithFlags(&c->ev_chain[p][k], hipEventDisableTiming));
     for (int k = 0; k < WN_MAX_BUCKETS + 2; ++k) WN_HIP(c, hipEventCreateWithFlags(&c->ev_bucket[k], hipEventDisableTiming));
     WN_HIP(c, hipEventCreateWithFlags(&c->ev_w0, hipEventDisableTiming));
@@ -445,12 +456,11 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     hipStream_t wst = c->st3;
     WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
     // ---- the serial chain, per batch part (two streams)
-    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first) { return bwd_part(c, b0, nb, s, first ? 0 : 1); }))) return rc;
+    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;
     // ---- head weight gradients over the whole batch (wavenet.py:136-149): need DY / DPRE1 of BOTH parts (head of the chain)
     {   // (enqueued after the chain in host order, but gated only by the events of the first bucket)
         if (nearly > 0) {
-            WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[0][0], 0));
-            if (c->parts == 2) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[1][0], 0));
+            for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[pk][0], 0));
         } else {
             WN_HIP(c, hipEventRecord(c->ev_w0, st));
             WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
@@ -473,8 +483,7 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     // ---- weight gradients of the stack, each kind for all layers of a bucket in one grouped launch (wn_wgrad.h)
     for (int k = 0; k < nearly; ++k) {
         if (k > 0) {
-            WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[0][k], 0));
-            if (c->parts == 2) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[1][k], 0));
+            for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[pk][k], 0));
         }
         if ((rc = stack_wgrads(c, grads, c->bucket_lo[k], c->bucket_hi[k] - c->bucket_lo[k], fused, wst))) return rc;
         WN_HIP(c, hipEventRecord(c->ev_bucket[k], wst));
@@ -484,7 +493,7 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     WN_HIP(c, hipEventRecord(c->ev_w0, st));
     WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
     hipStream_t side = st;
-    if (c->parts == 2) {
+    if (c->parts >= 2) {
         WN_HIP(c, hipEventRecord(c->ev_fork, st));
         WN_HIP(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
         side = c->st2;

@@ -8,6 +8,10 @@ import argparse
 import os
 from time import sleep
 
+# the training step uses 3 HIP streams (+ the all-reduce streams under torch.distributed): more than the runtime's default of 4 hardware
+# queues once data parallel; streams sharing a queue serialise.  Must be set before the HIP runtime initialises (first torch.cuda call).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import infolog
 from hparams import hparams
 from infolog import log
