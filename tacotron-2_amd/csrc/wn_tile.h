@@ -78,6 +78,13 @@ __device__ __forceinline__ float gate_tanh_from(float u, float s) {
     const float t = u * __builtin_amdgcn_rcpf(s);
     return s > 0.0f ? fminf(fmaxf(t, -1.0f), 1.0f) : 0.0f;
 }
+// d a = g * sigmoid * (1 - tanh^2),  d b = g * tanh * sigmoid * (1 - sigmoid) = g * u * (1 - sigmoid)   (modules.py:510 differentiated).
+// The one contraction-prone expression is written as an explicit fma so that every instantiation rounds identically.
+__device__ __forceinline__ void gate_backward(float g, float u, float s, float& da, float& db) {
+    const float ta = gate_tanh_from(u, s);
+    da = g * s * __builtin_fmaf(-ta, ta, 1.0f);
+    db = g * u * (1.0f - s);
+}
 
 __device__ __forceinline__ bool drop_keep(uint32_t key_lo, uint32_t key_hi, uint32_t thresh16, uint32_t e) {
     uint32_t w = wn_drop_word(key_lo, key_hi, e >> 1);
@@ -195,11 +202,7 @@ __device__ __forceinline__ void wn_tile_epilogue(const GemmArgs& a, f32x16_t (&a
                         float sg[4] = {bf2f((bf16_t)(xb.x & 0xffff)), bf2f((bf16_t)(xb.x >> 16)), bf2f((bf16_t)(xb.y & 0xffff)), bf2f((bf16_t)(xb.y >> 16))};
                         float da[4], db[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float ta = gate_tanh_from(uu[r], sg[r]);
-                            da[r] = v[r] * sg[r] * (1.0f - ta * ta);
-                            db[r] = v[r] * uu[r] * (1.0f - sg[r]);
-                        }
+                        for (int r = 0; r < 4; ++r) gate_backward(v[r], uu[r], sg[r], da[r], db[r]);
                         bf16_t* DZ = (bf16_t*)e.out0;
                         *reinterpret_cast<uint2*>(DZ + row * e.ld_out0 + m) = make_uint2(pack_bf2(da[0], da[1]), pack_bf2(da[2], da[3]));
                         *reinterpret_cast<uint2*>(DZ + row * e.ld_out0 + e.GH + m) = make_uint2(pack_bf2(db[0], db[1]), pack_bf2(db[2], db[3]));
@@ -924,11 +927,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                         unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in1 + row * e.ld_in0 + m), uu);      // u = tanh * sigmoid
                         unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), sg);      // sigmoid
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const float ta = gate_tanh_from(uu[r], sg[r]);
-                            da[r] = v[r] * sg[r] * (1.0f - ta * ta);
-                            db[r] = v[r] * uu[r] * (1.0f - sg[r]);
-                        }
+                        for (int r = 0; r < 8; ++r) gate_backward(v[r], uu[r], sg[r], da[r], db[r]);
                         bf16_t* DZ = (bf16_t*)e.out0;
                         *reinterpret_cast<uint4*>(DZ + row * e.ld_out0 + m) = pack8(da);
                         *reinterpret_cast<uint4*>(DZ + row * e.ld_out0 + e.GH + m) = pack8(db);
@@ -972,6 +971,26 @@ static inline bool wn_tile_order_contiguous() {
 template <int EPI>
 static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st) {
     if (EPI == EPI_GATE && M % 64 != 0) WN_FAIL(ctx, WN_E_SHAPE, "gate GEMM needs gate_channels %% 64 == 0 (got M=%d)", M);
+    if constexpr (EPI == EPI_STORE_BF16) {
+        // Launches with fewer 256 x 128 tiles than workgroup slots (2 x 256) -- the out conv / head convs of a half batch: 344 --
+        // take 256 x 64 tiles instead (K-chunks of 64, 2-deep ring, still two workgroups per CU): twice the workgroups, half the
+        // work each.  Half-batch out conv 31.6 -> 27.7 us in the harness (profiles/r2h_gemm_harness_b4.txt); at full-batch size the
+        // 128-row tile is the faster one (46.6 vs 48.2 us), hence the rule.
+        bool k64 = a.nrep == 1 && a.taps == 0;
+        for (int sgi = 0; sgi < a.nseg; ++sgi) k64 = k64 && a.seg[sgi].nk % 64 == 0;
+        static const int small_tiles = [] { const char* e = getenv("WN_SMALL_TILES"); return e ? atoi(e) : 1; }();       // A/B switch
+        if (small_tiles && k64 && M % 256 == 0 && a.e.M_valid == M && a.zero && (int64_t)cdiv(a.T, 128) * a.B * (M / 256) < 512) {
+            a.mblocks = M / 256;
+            a.tiles_per_utt = cdiv(a.T, 64);
+            a.ntiles = a.tiles_per_utt * a.B;
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
+            const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+            a.stagger = 0;
+            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 1, 4, 2, 64, 2, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
+            WN_LAUNCH_CHECK(ctx);
+            return WN_OK;
+        }
+    }
     if constexpr (EPI != EPI_STORE_F32_BOT) {
         if (M % 256 == 0 && a.e.M_valid == M && a.zero) {
             // v2: 256 channels x 128 time rows per 8-wave workgroup, K-chunks of 32, 3-deep LDS-DMA ring, 2 workgroups per CU

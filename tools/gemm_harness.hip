@@ -191,6 +191,12 @@ int main(int argc, char** argv) {
         bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "X") & same({D1, (size_t)NT_ * R * 2}, {D2, (size_t)NT_ * R * 2}, "XD"); \
         printf("out    v2 PIPE%d   : %8.1f us  %7.1f TF  %s\n", PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
         for (int rnd = 0; rnd < 2; ++rnd) { TRY_OUTP(1) TRY_OUTP(6) TRY_OUTP(7) }
+        // 64-row time tiles (NT = 1): twice the workgroups, half the work each (balance of the HBM-bound launches at half-batch size)
+#define TRY_OUT64(NB_) { CK(hipMemset(O2, 0xff, NT_ * R * 2)); CK(hipMemset(D2, 0xff, NT_ * R * 2)); \
+        float t2 = time_ms([&] { launch_v2<2, 1, 4, 2, 64, NB_, EPI_STORE_BF16, 1>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+        bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "X") & same({D1, (size_t)NT_ * R * 2}, {D2, (size_t)NT_ * R * 2}, "XD"); \
+        printf("out    v2 256x64 BK64 NBUF%d : %8.1f us  %7.1f TF  %s\n", NB_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        for (int rnd = 0; rnd < 2; ++rnd) { TRY_OUTP(1) TRY_OUT64(2) }
     }
     {   // ---------------- skip sum: M = 256, K = L*256 via nrep
         const int M = S, K = L * GH;
@@ -243,6 +249,10 @@ int main(int argc, char** argv) {
           bool ok = same({O1, (size_t)NT_ * G * 2}, {O2, (size_t)NT_ * G * 2}, "DZ"); \
           printf("dgate  v2 PIPE%d   : %8.1f us  %7.1f TF  %s\n", PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
         for (int rnd = 0; rnd < 2; ++rnd) { TRY_DGP(1) TRY_DGP(6) TRY_DGP(7) }
+#define TRY_DG64(NB_) { CK(hipMemset(O2, 0xff, NT_ * G * 2)); float t2 = time_ms([&] { launch_v2<2, 1, 4, 2, 64, NB_, EPI_DGATE, 1>(a2, M, 0); }); CK(hipDeviceSynchronize()); \
+          bool ok = same({O1, (size_t)NT_ * G * 2}, {O2, (size_t)NT_ * G * 2}, "DZ"); \
+          printf("dgate  v2 256x64 BK64 NBUF%d : %8.1f us  %7.1f TF  %s\n", NB_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
+        for (int rnd = 0; rnd < 2; ++rnd) { TRY_DGP(1) TRY_DG64(2) }
         { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DGATE>(a2, M, 0); }); CK(hipDeviceSynchronize());
           bool ok = same({O1, (size_t)NT_ * G * 2}, {O2, (size_t)NT_ * G * 2}, "DZ");
           printf("dgate  v2 WM4 WN2 BK32 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }

@@ -13,7 +13,7 @@ cd $R
 ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) > $OUT/smoke.log
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; echo "rc=$?" >> $OUT/bench.err
 # A/B switches (same box, same process structure): multi-A weight-gradient workgroups, gradient buckets, batch parts
-for v in "base:" "wgrad1:WN_WGRAD_MULTI=0" "buckets1:WN_BWD_BUCKETS=1" "parts1:WN_BATCH_PARTS=1"; do
+for v in "base:" "wgrad1:WN_WGRAD_MULTI=0" "buckets3:WN_BWD_BUCKETS=3" "parts1:WN_BATCH_PARTS=1" "bigtiles:WN_SMALL_TILES=0" "base:"; do
   name=${v%%:*}; envs=${v#*:}
   ( env $envs timeout 200 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-synth --no-exclusive --sustained 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', '%.3f ms/step' % d['ms_per_step'], 'gate frac %.3f' % d['roofline']['frac'])" ) >> $OUT/ab.txt 2>&1
 done
