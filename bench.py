@@ -254,10 +254,14 @@ class SmiSampler:
             self._stop.wait(0.5)
 
     def __enter__(self):
-        self._t.start(); return self
+        if self.idx >= 0:           # (rank 0 only: eight ranks polling rocm-smi would only add noise)
+            self._t.start()
+        return self
 
     def __exit__(self, *a):
-        self._stop.set(); self._t.join(timeout=15)
+        self._stop.set()
+        if self.idx >= 0:
+            self._t.join(timeout=15)
 
     def summary(self):
         out = {'samples': len(self.power)}
@@ -284,6 +288,10 @@ def main():
     ap.add_argument('--no-synth', action='store_true')
     ap.add_argument('--no-exclusive', action='store_true', help='skip the untimed single-stream pass (keeps a rocprofv3 trace to the timed configuration)')
     ap.add_argument('--sustained', type=int, default=100, help='steps per block of the untimed-by-contract sustained measurement (3 blocks after the timed region; 0 = off)')
+    ap.add_argument('--emulate-allreduce-gbps', type=float, default=0.0,
+                    help='single-GPU model of the data-parallel exchange: after the backward, every gradient bucket occupies the communication stream for '
+                         'bytes / (this many GB/s) (a spin kernel gated on the bucket event, like the RCCL call would be); use with --grad-buckets 1 / 3')
+    ap.add_argument('--grad-buckets', type=int, default=None, help='override wn_config.grad_buckets (default: 3 under torch.distributed with > 1 rank, else 1)')
     ap.add_argument('--batch', type=int, default=None, help='override per-GPU batch (debug)')
     ap.add_argument('--time', type=int, default=None, help='override T (debug)')
     args = ap.parse_args()
@@ -310,7 +318,7 @@ def main():
     T = args.time or T
     hop = int(np.prod(hp.upsample_scales))
     T = T // hop * hop
-    eng = _ext.Engine(hp, B, T)
+    eng = _ext.Engine(hp, B, T, grad_buckets=args.grad_buckets)
     flat = initialize_parameters(hp, eng.layout).to(device)
     assert flat.numel() == eng.n_params
     if world > 1:
@@ -320,10 +328,32 @@ def main():
     loss = torch.zeros(1, device=device)
     x, c, y, lengths, _, _ = synthetic_batch(hp, B, T, seed=5339 + rank, device=device)   # disjoint utterances per rank
 
+    emu_stream = torch.cuda.Stream(device=device) if args.emulate_allreduce_gbps > 0 else None
+    emu_clock_hz = 100e6      # torch.cuda._sleep counts s_memrealtime-like ticks?  calibrated below
+    if emu_stream is not None:
+        # calibrate torch.cuda._sleep (cycles -> seconds) with device events, after a warm-up call
+        torch.cuda._sleep(1_000_000); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(50_000_000); e1.record(); torch.cuda.synchronize()
+        emu_clock_hz = 50_000_000 / (e0.elapsed_time(e1) * 1e-3)
+        _log('emulated all-reduce: _sleep runs at %.1f MHz; %.2f ms for the %.1f MB gradient at %.0f GB/s'
+             % (emu_clock_hz / 1e6, eng.n_params * 4 / (args.emulate_allreduce_gbps * 1e9) * 1e3, eng.n_params * 4 / 1e6, args.emulate_allreduce_gbps))
+
+    def emulated_allreduce():
+        """What allreduce_mean_buckets_ does, with the RCCL call replaced by a spin of bytes / bandwidth on the communication stream."""
+        cur = torch.cuda.current_stream(device)
+        for i_b, (off, n) in enumerate(eng.grad_buckets()):
+            eng.wait_bucket(i_b, emu_stream)
+            with torch.cuda.stream(emu_stream):
+                torch.cuda._sleep(int(n * 4 / (args.emulate_allreduce_gbps * 1e9) * emu_clock_hz))
+        cur.wait_stream(emu_stream)
+
     def one_step(i):
         eng.pack_weights(flat)
         eng.train_fwd(x, c, y, lengths, 1000 + i, loss)
         eng.train_bwd(grads)
+        if emu_stream is not None:
+            emulated_allreduce()
         allreduce_mean_buckets_(eng, grads)          # per gradient bucket on a side stream, under the rest of the backward
         lr = _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, i, hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
         eng.optim_step(flat, grads, m, v, ema, lr, i)
@@ -354,7 +384,7 @@ def main():
     sustained = None
     if args.sustained > 0:
         blocks = []
-        with SmiSampler(local_rank) as smi:
+        with SmiSampler(local_rank if rank == 0 else -1) as smi:
             step_i = args.warmup + args.steps
             for _ in range(3):
                 torch.cuda.synchronize()
@@ -430,6 +460,11 @@ def main():
                                         'traffic_per_step': STEP_TRAFFIC_BYTES.get(args.workload) if (B, T) == (8, 11000) else None,
                                         'traffic_source': STEP_TRAFFIC_SOURCE + ': sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE per step'},
             'sustained': sustained,
+            'grad_buckets': [list(b) for b in eng.grad_buckets()],
+            'emulated_allreduce': ({'gbps': args.emulate_allreduce_gbps, 'bytes': int(eng.n_params) * 4,
+                                    'serial_ms': int(eng.n_params) * 4 / (args.emulate_allreduce_gbps * 1e9) * 1e3,
+                                    'what': 'single-GPU model: each gradient bucket occupies the communication stream for bytes / bandwidth once its event fired'}
+                                   if args.emulate_allreduce_gbps > 0 else None),
         }
         if not args.no_synth and world == 1:      # replicas-only path: measured on one GPU, not while the other ranks wait
             _log('synthesis measurement ...')
