@@ -114,7 +114,7 @@ static int alloc_workspace_inference(wn_ctx* c) {
     c->scal = (float*)bump(p, 256);
     c->zero_page = (bf16_t*)bump(p, 256);
     c->X = c->XD = c->TS = c->U = c->R1 = c->H2 = c->DY = c->DPRE1 = c->DSKIP = c->DZ = c->GXall = c->GX0 = c->GX1 = nullptr;
-    c->YHAT = c->DC = c->DCUP[0] = c->DCUP[1] = c->CIN = nullptr; c->XIN = nullptr;
+    c->YHAT = c->DC = c->DCUP[0] = c->DCUP[1] = c->CIN = c->UPPART = nullptr; c->XIN = nullptr;
     if (hipMemset(c->zero_page, 0, 256) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
     return WN_OK;
 }
@@ -140,6 +140,13 @@ static int alloc_workspace(wn_ctx* c) {
     sz(NT * c->C * 4);                     // DC
     for (int i = 0; i <= c->cfg.n_upsample; ++i) sz(NT * c->C * 4);   // CUP (generous: every level sized for full rate)
     sz(NT * c->C * 4); sz(NT * c->C * 4);  // DCUP ping-pong
+    {   // per-workgroup partial sums of the upsample-kernel gradients (wn_up_bwd_params2): (rows + 2048 slices) x (taps + biases)
+        int ne = 1;
+        const int fk = c->cfg.freq_axis_kernel_size;
+        for (int i = 0; i < c->cfg.n_upsample; ++i) { const int s_ = c->cfg.upsample_scales[i]; ne = std::max(ne, c->cfg.upsample_type == WN_UP_2D ? fk * s_ + 1 : fk * 3 * s_ + s_); }
+        c->uppart_floats = ((int64_t)c->maxB * c->C + 2048) * ne;
+        sz((size_t)c->uppart_floats * 4);
+    }
     sz(NT * 4); sz(NT * c->C * 4);          // XIN, CIN
     sz(256);                               // scalars
     sz(256);                               // zero page
@@ -162,6 +169,7 @@ static int alloc_workspace(wn_ctx* c) {
     c->DC = (float*)bump(p, NT * c->C * 4);
     for (int i = 0; i <= c->cfg.n_upsample; ++i) c->CUP[i] = (float*)bump(p, NT * c->C * 4);
     c->DCUP[0] = (float*)bump(p, NT * c->C * 4); c->DCUP[1] = (float*)bump(p, NT * c->C * 4);
+    c->UPPART = (float*)bump(p, (size_t)c->uppart_floats * 4);
     c->XIN = (void*)bump(p, NT * 4); c->CIN = (float*)bump(p, NT * c->C * 4);
     c->scal = (float*)bump(p, 256);
     c->zero_page = (bf16_t*)bump(p, 256);

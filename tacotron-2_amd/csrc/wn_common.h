@@ -122,6 +122,7 @@ struct wn_ctx {
     bf16_t* XD;                           // [L][NT][R] dropout-applied layer inputs (aliases X when dropout == 0)
     bf16_t *cbt, *X, *TS, *U, *R1, *H2, *DY, *DPRE1, *DSKIP, *DZ, *GX0, *GX1;
     float *YHAT, *DC, *CUP[WN_MAX_UPSAMPLE + 1], *DCUP[2];
+    float* UPPART = nullptr; int64_t uppart_floats = 0;   // partial sums of the upsample-kernel gradients (two-stage, no atomics)
     void* XIN; float* CIN;                // ctx-owned copies of the step's x and c (pointers are borrowed per call)
     float* wg_partial = nullptr; size_t wg_partial_bytes = 0;   // split-K partial tiles of the grouped wgrad (wn_wgrad.h)
     bf16_t* GXall = nullptr;              // [L+1][NT][R] gradient wrt every layer input (kept for the grouped W_out wgrad)

@@ -514,6 +514,116 @@ __global__ __launch_bounds__(256) void wn_up_bwd_input(const float* __restrict__
     if (live && lj == 0) din[idx] = a;
 }
 
+// ---- round-2 replacements for types 1 / 2: no float atomics anywhere (bit-reproducible gradients), enough workgroups to fill the part.
+// Stage 1: workgroup (row = (b, f), time slice y) accumulates its taps in registers exactly like wn_up_bwd_params, folds the
+// threads of one phase j in a FIXED order through LDS and writes ne = nk + nb partial sums to part[block][e].
+// Stage 2 (wn_up_bwd_params_reduce): one workgroup per element sums the blocks in a fixed order and STORES dK / dbias.
+__global__ __launch_bounds__(256) void wn_up_bwd_params2(const float* __restrict__ in, const float* __restrict__ out, const float* __restrict__ dout,
+                                 float* __restrict__ part, int B, int C, int Tin, int s, int fk, int type, int act, float alpha, int tchunk) {
+    __shared__ float sh[(WN_UP_MAXTAP + 1) * 256];
+    const int nk = (type == 1) ? fk * s : fk * 3 * s;
+    const int nb = (type == 1) ? 1 : s;
+    const int Tout = Tin * s;
+    const int b = blockIdx.x / C, f = blockIdx.x % C;
+    const int groups = blockDim.x / s;
+    const int j = threadIdx.x % s, q0 = threadIdx.x / s;
+    const int pf = (fk - 1) / 2;
+    const int ntap = (type == 1) ? fk : fk * 3;
+    const int tlo = blockIdx.y * tchunk, thi = min(Tin, tlo + tchunk);
+    float dk[WN_UP_MAXTAP], db = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WN_UP_MAXTAP; ++i) dk[i] = 0.0f;
+    if (q0 < groups) {
+        const float* inb = in + (int64_t)b * C * Tin;
+        const int64_t rowo = ((int64_t)b * C + f) * Tout;
+        for (int t = tlo + q0; t < thi; t += groups) {
+            const int64_t o = rowo + (int64_t)t * s + j;
+            const float dp = dout[o] * act_grad(out[o], act, alpha);
+            db += dp;
+            if (type == 1) {
+#pragma unroll
+                for (int kf = 0; kf < 9; ++kf) {
+                    if (kf < fk) { const int fs = f - kf + pf; if (fs >= 0 && fs < C) dk[kf] += inb[(int64_t)fs * Tin + t] * dp; }
+                }
+            } else {
+#pragma unroll
+                for (int kf = 0; kf < 9; ++kf) {
+                    if (kf < fk) {
+                        const int fs = f + kf - pf;
+                        if (fs >= 0 && fs < C) {
+#pragma unroll
+                            for (int kt = 0; kt < 3; ++kt) { const int tsrc = t + kt - 1; if (tsrc >= 0 && tsrc < Tin) dk[kf * 3 + kt] += inb[(int64_t)fs * Tin + tsrc] * dp; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WN_UP_MAXTAP; ++i) if (i < ntap) sh[i * 256 + threadIdx.x] = dk[i];
+    sh[ntap * 256 + threadIdx.x] = db;
+    __syncthreads();
+    const int ne = nk + nb;
+    float* po = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ne;
+    for (int e = threadIdx.x; e < ne; e += blockDim.x) {
+        float a = 0.0f;
+        if (e < nk) { const int tap = e / s, jj = e - tap * s; for (int q = 0; q < groups; ++q) a += sh[tap * 256 + q * s + jj]; }
+        else if (type == 1) { for (int x = 0; x < groups * s; ++x) a += sh[ntap * 256 + x]; }
+        else { const int jj = e - nk; for (int q = 0; q < groups; ++q) a += sh[ntap * 256 + q * s + jj]; }
+        po[e] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void wn_up_bwd_params_reduce(const float* __restrict__ part, int nblk, int ne, int nk, float* __restrict__ dK, float* __restrict__ dbias) {
+    __shared__ float sh[256];
+    const int e = blockIdx.x;
+    float a = 0.0f;
+    for (int i = threadIdx.x; i < nblk; i += 256) a += part[(int64_t)i * ne + e];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { if (e < nk) dK[e] = sh[0]; else dbias[e - nk] = sh[0]; }
+}
+
+// din[b][f'][t0 .. t0+TB): the fk output rows this input row feeds (x act') are staged once, coalesced, into LDS ([fk][W],
+// W = (TB + 2 halo) s, halo = 1 frame for the 3-tap SubPixel kernel) together with the kernel; one thread per input frame.
+__global__ __launch_bounds__(256) void wn_up_bwd_input2(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ din,
+                                const float* __restrict__ K, int B, int C, int Tin, int s, int fk, int type, int act, float alpha, int TB) {
+    extern __shared__ float dsh[];
+    const int halo = (type == 2) ? 1 : 0;
+    const int W = (TB + 2 * halo) * s;
+    const int nk = (type == 1) ? fk * s : fk * 3 * s;
+    float* dp = dsh; float* Ks = dsh + fk * W;
+    const int Tout = Tin * s;
+    const int b = blockIdx.y / C, f = blockIdx.y % C;
+    const int t0 = blockIdx.x * TB;
+    const int pf = (fk - 1) / 2;
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) Ks[i] = K[i];
+    for (int kf = 0; kf < fk; ++kf) {
+        const int fo = (type == 1) ? f + kf - pf : f - kf + pf;
+        const bool rowok = fo >= 0 && fo < C;
+        const int64_t ro = ((int64_t)b * C + fo) * Tout;
+        const int to0 = (t0 - halo) * s;
+        for (int x = threadIdx.x; x < W; x += blockDim.x) {
+            const int to = to0 + x;
+            float v = 0.0f;
+            if (rowok && to >= 0 && to < Tout) v = dout[ro + to] * act_grad(out[ro + to], act, alpha);
+            dp[kf * W + x] = v;
+        }
+    }
+    __syncthreads();
+    for (int tl = threadIdx.x; tl < TB && t0 + tl < Tin; tl += blockDim.x) {
+        float a = 0.0f;
+        if (type == 1) {
+            for (int kf = 0; kf < fk; ++kf) { const float* d = dp + kf * W + tl * s; const float* k = Ks + kf * s; for (int j = 0; j < s; ++j) a += k[j] * d[j]; }
+        } else {
+            for (int kf = 0; kf < fk; ++kf)
+                for (int kt = 0; kt < 3; ++kt) { const float* d = dp + kf * W + (tl - kt + 2) * s; const float* k = Ks + (kf * 3 + kt) * s; for (int j = 0; j < s; ++j) a += k[j] * d[j]; }
+        }
+        din[((int64_t)b * C + f) * Tin + t0 + tl] = a;
+    }
+}
+
 static int up_type_code(const wn_ctx* c) {
     switch (c->cfg.upsample_type) { case WN_UP_NEAREST: return 0; case WN_UP_2D: return 1; case WN_UP_SUBPIXEL: return 2; case WN_UP_RESIZE: return 3; default: return 4; }
 }
@@ -580,15 +690,40 @@ int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t 
         const int64_t n = (int64_t)B * C * Tout;
         if (s > 256) WN_FAIL(c, WN_E_UNSUPPORTED, "upsample scale %d > 256", s);
         (void)n;
+        static const bool v1 = getenv("WN_UP_BWD_V1") != nullptr;          // A/B switch: the round-1 kernels (float atomics)
+        if (v1) {
         hipLaunchKernelGGL(wn_up_bwd_params, dim3(B * C), dim3(256), (nk + nb) * 4, st, in, c->CUP[i], dout,
                            grads + c->up_k[i], grads + c->up_b[i], B, C, Tin, s, fk, type, c->cfg.upsample_activation, c->cfg.leaky_alpha);
         WN_LAUNCH_CHECK(c);
+        } else {
+            const int rows = B * C, groups = 256 / s;
+            int Y = std::max(1, std::min(cdiv(2048, rows), cdiv(Tin, groups)));
+            const int tchunk = cdiv(Tin, Y); Y = cdiv(Tin, tchunk);
+            const int ne = nk + nb, nblk = rows * Y;
+            if ((int64_t)nblk * ne > c->uppart_floats) WN_FAIL(c, WN_E_STATE, "upsample partial buffer too small (%d x %d)", nblk, ne);
+            if ((type == 1 ? fk : fk * 3) > WN_UP_MAXTAP) WN_FAIL(c, WN_E_UNSUPPORTED, "freq_axis_kernel_size %d too large", fk);
+            hipLaunchKernelGGL(wn_up_bwd_params2, dim3(rows, Y), dim3(256), 0, st, in, c->CUP[i], dout, c->UPPART, B, C, Tin, s, fk, type,
+                               c->cfg.upsample_activation, c->cfg.leaky_alpha, tchunk);
+            WN_LAUNCH_CHECK(c);
+            hipLaunchKernelGGL(wn_up_bwd_params_reduce, dim3(ne), dim3(256), 0, st, c->UPPART, nblk, ne, nk, grads + c->up_k[i], grads + c->up_b[i]);
+            WN_LAUNCH_CHECK(c);
+        }
         if (i > 0) {
             float* din = c->DCUP[i & 1];
             const int64_t ni = (int64_t)B * C * Tin;
+            if (v1) {
             int GL = 1; while (GL < s && GL < 64) GL <<= 1;
             hipLaunchKernelGGL(wn_up_bwd_input, dim3(cdiv(ni, 256 / GL)), dim3(256), 0, st, c->CUP[i], dout, din, c->params_dev + c->up_k[i],
                                B, C, Tin, s, fk, type, c->cfg.upsample_activation, c->cfg.leaky_alpha, GL);
+            } else {
+                const int halo = (type == 2) ? 1 : 0;
+                int TB = std::min(256, 8192 / (fk * s) - 2 * halo);
+                if (TB < 1) WN_FAIL(c, WN_E_UNSUPPORTED, "upsample scale %d x freq kernel %d too large for the LDS stage", s, fk);
+                TB = std::min(TB, Tin);
+                const size_t lds = ((size_t)fk * (TB + 2 * halo) * s + nk) * 4;
+                hipLaunchKernelGGL(wn_up_bwd_input2, dim3(cdiv(Tin, TB), B * C), dim3(256), lds, st, c->CUP[i], dout, din, c->params_dev + c->up_k[i],
+                                   B, C, Tin, s, fk, type, c->cfg.upsample_activation, c->cfg.leaky_alpha, TB);
+            }
             WN_LAUNCH_CHECK(c);
             dout = din;
         }

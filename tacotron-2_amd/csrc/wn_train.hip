@@ -453,7 +453,8 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     // ---- weight-gradient stream: head weight gradients first (their operands exist since the forward / loss), then one bucket of
     // stack weight gradients whenever both chain streams have passed its lowest layer
     WN_HIP(c, hipEventRecord(c->ev_w0, st));
-    hipStream_t wst = c->st3;
+    static const bool serial = getenv("WN_SERIAL") != nullptr;      // profiling aid: every kernel on the caller's stream (with WN_BATCH_PARTS=1: exclusive kernel times)
+    hipStream_t wst = serial ? st : c->st3;
     WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
     // ---- the serial chain, per batch part (two streams)
     if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;

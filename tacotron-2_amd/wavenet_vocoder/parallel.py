@@ -41,7 +41,7 @@ def _comm_stream(device):
     return _COMM_STREAMS[key]
 
 
-def allreduce_mean_buckets_(engine, flat):
+def allreduce_mean_buckets_(engine, flat, single_rank_ok=False):
     """Tower-gradient mean (wavenet.py:564-575) overlapped with the backward pass.
 
     ``engine.train_bwd(flat)`` completes the flat gradient in ``engine.grad_buckets()`` contiguous pieces, top layers first, on
@@ -49,9 +49,10 @@ def allreduce_mean_buckets_(engine, flat):
     i.e. while the weight gradients of the layers below are still being computed; the caller's stream is ordered after the last
     piece.  xGMI is point-to-point (7 x ~153 GB/s per GPU): the pieces stay large (4-6 of ~10-15 MB for the paper model), never
     one call per tensor.  Must be called right after ``engine.train_bwd(flat)`` on the same stream.  CPU tensors (gloo tests) take
-    the same bucket walk without streams.
+    the same bucket walk without streams.  ``single_rank_ok`` runs the walk on a one-rank group too (GPU test of the stream /
+    event ordering against RCCL without a second GPU).
     """
-    if not is_distributed() or world_size() == 1:
+    if not is_distributed() or (world_size() == 1 and not single_rank_ok):
         return flat
     w = world_size()
     buckets = engine.grad_buckets()

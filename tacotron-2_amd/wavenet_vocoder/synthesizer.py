@@ -5,7 +5,7 @@ import os
 import numpy as np
 import torch
 
-from datasets.audio import get_hop_size, save_wavenet_wav
+from datasets.audio import get_hop_size, melspectrogram, save_wavenet_wav
 from infolog import log
 from wavenet_vocoder import util
 from wavenet_vocoder.models import create_model
@@ -96,12 +96,16 @@ class Synthesizer(object):
         generated_wavs = [w[:length] for w, length in zip(generated, audio_lengths)]
         upsampled_features = [f[:, :length] for f, length in zip(feats, audio_lengths)]
         audio_filenames = []
-        for i, (wav, feat) in enumerate(zip(generated_wavs, upsampled_features)):
+        for i, (wav, feat, input_mel) in enumerate(zip(generated_wavs, upsampled_features, mel_spectrograms)):
             audio_filename = os.path.join(out_dir, 'wavenet-audio-{}.wav'.format(basenames[i]))
             save_wavenet_wav(wav, audio_filename, sr=hparams.sample_rate, inv_preemphasize=hparams.preemphasize, k=hparams.preemphasis)
             audio_filenames.append(audio_filename)
             if log_dir is not None:
                 try:
+                    # generated-audio mel vs the conditioning mel (reference synthesizer.py:113-117)
+                    util.plot_spectrogram(melspectrogram(wav.astype(np.float64), hparams).T,
+                                          os.path.join(log_dir, 'wavenet-mel-spectrogram-{}.png'.format(basenames[i])),
+                                          title='Local Condition vs Reconstructed Audio Mel-Spectrogram analysis', target_spectrogram=input_mel)
                     util.plot_spectrogram(feat.T, os.path.join(log_dir, 'wavenet-upsampled_features-{}.png'.format(basenames[i])),
                                           title='Upmsampled Local Condition features', auto_aspect=True)
                     util.waveplot(os.path.join(log_dir, 'wavenet-waveplot-{}.png'.format(basenames[i])), wav, None, hparams,

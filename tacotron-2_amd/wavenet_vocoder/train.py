@@ -16,10 +16,10 @@ import numpy as np
 import torch
 
 import infolog
-from datasets.audio import save_wavenet_wav
+from datasets.audio import melspectrogram, save_wavenet_wav
 from hparams import hparams_debug_string
 from wavenet_vocoder import util
-from wavenet_vocoder.feeder import Feeder, SyntheticFeeder
+from wavenet_vocoder.feeder import Feeder, SyntheticFeeder, _interp
 from wavenet_vocoder.models import create_model
 
 log = infolog.log
@@ -122,6 +122,32 @@ def _scalars_writer(tensorboard_dir):
     return open(path, 'a')
 
 
+def add_embedding_stats(tensorboard_dir, embedding_names, paths_to_meta, tables, step):
+    """Speaker-embedding projector (reference train.py:26-39): TensorBoard's projector plugin reads ``projector_config.pbtxt``
+    from the event directory.  The reference points it at the TF checkpoint (``model_checkpoint_path`` + ``tensor_name``); there
+    is no TF checkpoint here, so every table is written as a TSV next to the config and referenced by ``tensor_path`` (the
+    plugin's documented alternative, also what projector.tensorflow.org loads), with the same metadata file."""
+    entries = []
+    for name, meta, table in zip(embedding_names, paths_to_meta, tables):
+        t = table.detach().float().cpu().numpy() if torch.is_tensor(table) else np.asarray(table, dtype=np.float32)
+        fname = '{}-{}.tsv'.format(name.replace('/', '_').replace(':', '_'), step)
+        np.savetxt(os.path.join(tensorboard_dir, fname), t.reshape(t.shape[0], -1), fmt='%.7g', delimiter='\t')
+        entries.append('embeddings {{\n  tensor_name: "{}"\n  tensor_path: "{}"\n  metadata_path: "{}"\n}}\n'.format(name, fname, meta))
+    with open(os.path.join(tensorboard_dir, 'projector_config.pbtxt'), 'w', encoding='utf-8') as f:
+        f.write(''.join(entries))
+
+
+def _plot_reconstruction_mel(wav, input_mel, path, hparams, title):
+    """Mel of the generated audio next to the conditioning it was generated from (reference train.py:110-116, 150-156):
+    both should agree on the low-frequency content.  ``input_mel``: [cin, Tc] or [Tc, cin]."""
+    T2_output_range = (-hparams.max_abs_value, hparams.max_abs_value) if hparams.symmetric_mels else (0, hparams.max_abs_value)
+    generated_mel = _interp(melspectrogram(np.asarray(wav, dtype=np.float64), hparams).T, T2_output_range)
+    m = input_mel.detach().float().cpu().numpy() if torch.is_tensor(input_mel) else np.asarray(input_mel)
+    if m.ndim == 2 and m.shape[0] == hparams.cin_channels and m.shape[1] != hparams.cin_channels:
+        m = m.T
+    util.plot_spectrogram(generated_mel, path, title=title, target_spectrogram=m)
+
+
 def save_log(model, batch, step, plot_dir, wav_dir, hparams, model_name):
     """Predicted-vs-target wav + plots for item 0 of the current batch (reference train.py:128-162)."""
     log('\nSaving intermediate states at step {}'.format(step))
@@ -152,6 +178,8 @@ def save_log(model, batch, step, plot_dir, wav_dir, hparams, model_name):
                       title='{}, {}, step={}'.format(model_name, time_string(), step))
         util.plot_spectrogram(feats[0].cpu().numpy().T, os.path.join(plot_dir, 'step-{}-upsampled-features.png'.format(step)),
                               title='Upsampled Local Condition features, step={}'.format(step), auto_aspect=True)
+        _plot_reconstruction_mel(pred, c[idx], os.path.join(plot_dir, 'step-{}-reconstruction-mel-spectrogram.png'.format(step)), hparams,
+                                 'Local Condition vs Reconst. Mel-Spectrogram, step={}'.format(step))
     except Exception as e:      # plotting must never kill a training run
         log('plotting skipped: {}'.format(e))
 
@@ -173,6 +201,11 @@ def eval_step(model, batch, step, plot_dir, wav_dir, scalars, hparams, model_nam
     try:
         util.waveplot(os.path.join(plot_dir, 'step-{}-waveplot.png'.format(step)), y_hat, y_target, hparams,
                       title='{}, {}, step={}, loss={:.5f}'.format(model_name, time_string(), step, loss))
+        _plot_reconstruction_mel(y_hat, model.tower_eval_c[0], os.path.join(plot_dir, 'step-{}-reconstruction-mel-spectrogram.png'.format(step)), hparams,
+                                 'Local Condition vs Reconst. Mel-Spectrogram, step={}, loss={:.5f}'.format(step, loss))
+        feats = model.tower_eval_upsampled_local_features[0]
+        util.plot_spectrogram(feats.float().cpu().numpy().T, os.path.join(plot_dir, 'step-{}-upsampled-features.png'.format(step)),
+                              title='Upsampled Local Condition features, step={}, loss={:.5f}'.format(step, loss), auto_aspect=True)
     except Exception as e:
         log('plotting skipped: {}'.format(e))
     log('Eval loss for global step {}: {:.3f}'.format(step, loss))
@@ -217,6 +250,17 @@ def train(log_dir, args, hparams, input_path):
     max_t = hparams.max_time_steps if hparams.max_time_sec is None else int(hparams.max_time_sec * hparams.sample_rate)
     eval_max_t = int(getattr(args, 'eval_max_time', 0) or max_t)
     model.build(max(hparams.wavenet_batch_size // world, 1), max(max_t, eval_max_t))
+
+    # speaker-embedding metadata for the projector (reference train.py:233-244)
+    if getattr(hparams, 'speakers_path', None) is not None:
+        speaker_embedding_meta = hparams.speakers_path
+    else:
+        speaker_embedding_meta = os.path.join(meta_folder, 'SpeakerEmbeddings.tsv')
+        if rank == 0 and not os.path.isfile(speaker_embedding_meta):
+            with open(speaker_embedding_meta, 'w', encoding='utf-8') as f:
+                for speaker in hparams.speakers:
+                    f.write('{}\n'.format(speaker))
+        speaker_embedding_meta = speaker_embedding_meta.replace(log_dir, '..')
 
     step = 0
     time_window = ValueWindow(100)
@@ -280,6 +324,11 @@ def train(log_dir, args, hparams, input_path):
             if step % args.eval_interval == 0 and rank == 0:
                 log('\nEvaluating at step {}'.format(step))
                 eval_step(model, feeder.next_eval_batch(), step, eval_plot_dir, eval_wav_dir, scalars, hparams=hparams, model_name=args.model)
+            if (hparams.gin_channels > 0 and model.embedding_table is not None and rank == 0
+                    and (step % args.embedding_interval == 0 or step == args.wavenet_train_steps or step == 1)):
+                log('\nSaving Model Speaker Embeddings visualization..')
+                add_embedding_stats(tensorboard_dir, ['WaveNet_model/inference/gc_embedding'], [speaker_embedding_meta], [model.embedding_table], step)
+                log('WaveNet Speaker embeddings have been updated on tensorboard!')
             if _dist() and (step % args.checkpoint_interval == 0 or step % args.eval_interval == 0):
                 _dist().barrier()
 

@@ -50,8 +50,16 @@ def test_train_checkpoint_restore_synthesize(tmp_path, gin):
     assert save_dir is not None and os.path.isdir(save_dir), 'the driver returns None when training raised'
     ckpt = get_checkpoint_state(save_dir)
     assert ckpt.endswith('wavenet_model.ckpt-6.pt') and os.path.exists(ckpt)
-    for f in ('wavs/step-3-pred.wav', 'wavs/step-3-real.wav', 'wavs/step-6-pred.wav', 'eval-dir/wavs/step-6-pred.wav', 'wavenet_events/scalars.jsonl'):
+    for f in ('wavs/step-3-pred.wav', 'wavs/step-3-real.wav', 'wavs/step-6-pred.wav', 'eval-dir/wavs/step-6-pred.wav', 'wavenet_events/scalars.jsonl',
+              'plots/step-3-waveplot.png', 'plots/step-3-upsampled-features.png', 'plots/step-3-reconstruction-mel-spectrogram.png',
+              'eval-dir/plots/step-6-waveplot.png', 'eval-dir/plots/step-6-reconstruction-mel-spectrogram.png', 'eval-dir/plots/step-6-upsampled-features.png'):
         assert os.path.exists(os.path.join(log_dir, f)), f
+    if gin:     # speaker-embedding projector (reference train.py:26-39, 327-334): config + table + metadata
+        cfgp = open(os.path.join(log_dir, 'wavenet_events', 'projector_config.pbtxt')).read()
+        assert 'gc_embedding' in cfgp and 'metadata_path: "../metas/SpeakerEmbeddings.tsv"' in cfgp
+        table = np.loadtxt(os.path.join(log_dir, 'wavenet_events', [l.split('"')[1] for l in cfgp.split('\n') if 'tensor_path' in l][0]), delimiter='\t')
+        assert table.shape == (3, 8)
+        assert len(open(os.path.join(log_dir, 'metas', 'SpeakerEmbeddings.tsv')).read().split()) == len(hp.speakers)
     rows = [json.loads(l) for l in open(os.path.join(log_dir, 'wavenet_events', 'scalars.jsonl'))]
     losses = [r['wavenet_loss'] for r in rows if 'wavenet_loss' in r]
     assert len(losses) == 3 and all(np.isfinite(losses))
@@ -74,6 +82,8 @@ def test_train_checkpoint_restore_synthesize(tmp_path, gin):
         os.chdir(cwd)
     wavs = sorted(glob.glob(os.path.join(root, 'wavenet_output', 'wavs', '*.wav')))
     assert len(wavs) == 3
+    plots = os.listdir(os.path.join(root, 'wavenet_output', 'plots'))
+    assert sum(p.startswith('wavenet-mel-spectrogram-') for p in plots) == 3 and sum(p.startswith('wavenet-waveplot-') for p in plots) == 3
     lines = open(os.path.join(root, 'wavenet_output', 'wavs', 'map.txt')).read().strip().split('\n')
     assert len(lines) == 3 and all(len(l.split('|')) == 3 for l in lines)
     from scipy.io import wavfile

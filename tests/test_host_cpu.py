@@ -527,3 +527,34 @@ def test_tf_checkpoint_reader_on_independent_fixture(golden_dir, tmp_path):
         open(os.path.join(str(d), name), 'wb').write(bytes(b))
         with pytest.raises(ValueError, match='checksum mismatch'):
             T.load_checkpoint(os.path.join(str(d), 'fixture.ckpt-7'))
+
+
+def test_reconstruction_mel_front_end():
+    """datasets/audio.py melspectrogram (reference datasets/audio.py:62-68; librosa's stft / filters.mel restated): STFT frames
+    against a direct DFT, librosa's frame count, Slaney filters of unit area, and a pure tone landing in the right mel band,
+    normalised into [-max_abs_value, max_abs_value]."""
+    import hparams as H
+    from datasets.audio import _build_mel_basis, _mel_to_hz, _hz_to_mel, _stft, melspectrogram
+    hp = H._build()
+    rng = np.random.RandomState(0)
+    y = rng.randn(3000)
+    D = _stft(y, hp)
+    n_fft, hop, win = hp.n_fft, hp.hop_size, hp.win_size
+    assert D.shape == (1 + n_fft // 2, 1 + len(y) // hop)                         # centred frames (librosa.stft)
+    from scipy.signal.windows import hann
+    w = np.zeros(n_fft); lp = (n_fft - win) // 2; w[lp:lp + win] = hann(win, sym=False)
+    yp = np.pad(y, n_fft // 2)
+    k = np.arange(n_fft // 2 + 1)[:, None]; n = np.arange(n_fft)[None, :]
+    for fr in (0, 5, D.shape[1] - 1):
+        ref = ((yp[fr * hop:fr * hop + n_fft] * w)[None, :] * np.exp(-2j * np.pi * k * n / n_fft)).sum(1)
+        assert np.abs(ref - D[:, fr]).max() < 1e-9
+    mb = _build_mel_basis(hp)
+    assert mb.shape == (hp.num_mels, 1 + n_fft // 2) and (mb >= 0).all()
+    area = mb.sum(1) * hp.sample_rate / n_fft
+    assert np.abs(area[10:] - 1.0).max() < 0.02                                   # 'slaney' normalisation: unit area per filter
+    assert np.allclose(_mel_to_hz(_hz_to_mel(np.array([55.0, 440.0, 1000.0, 7600.0]))), [55.0, 440.0, 1000.0, 7600.0])
+    centres = _mel_to_hz(np.linspace(_hz_to_mel(hp.fmin), _hz_to_mel(hp.fmax), hp.num_mels + 2))[1:-1]
+    t = np.arange(hp.sample_rate) / hp.sample_rate
+    m = melspectrogram(0.5 * np.sin(2 * np.pi * 1000.0 * t), hp)
+    assert m.shape[0] == hp.num_mels and m.min() >= -hp.max_abs_value and m.max() <= hp.max_abs_value
+    assert abs(int(m[:, 40].argmax()) - int(np.abs(centres - 1000.0).argmin())) <= 1
