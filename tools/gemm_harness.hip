@@ -112,6 +112,13 @@ int main(int argc, char** argv) {
             for (int sg : {0, 8000}) { a2.stagger = sg; printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 1) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 6) printf("  stagger %5d: ", sg); TRY_GATE3(2, 2, 4, 2, 32, 3, 7) }
         }
         a2.stagger = 0;
+        // fat waves: 4 waves per workgroup, 128 x 64 / 128 x 128 accumulator tiles per wave (fewer LDS fragment bytes per MFMA)
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            TRY_GATE3(2, 2, 4, 2, 32, 3, 1)
+            TRY_GATE3(4, 2, 2, 2, 32, 3, 1) TRY_GATE3(4, 2, 2, 2, 32, 3, 2) TRY_GATE3(2, 4, 2, 2, 32, 3, 1)
+            TRY_GATE3(4, 4, 2, 2, 32, 3, 1) TRY_GATE3(4, 4, 2, 2, 32, 3, 2) TRY_GATE3(4, 4, 2, 2, 64, 2, 1)
+            TRY_GATE3(4, 2, 2, 4, 32, 3, 1) TRY_GATE3(2, 4, 4, 2, 32, 3, 1) TRY_GATE3(4, 2, 2, 4, 32, 3, 2)
+        }
         TRY_GATE3(2, 2, 4, 2, 32, 2, 1) TRY_GATE3(2, 2, 4, 2, 64, 3, 1) TRY_GATE3(2, 2, 4, 2, 64, 3, 6) TRY_GATE3(2, 2, 4, 2, 64, 2, 6) TRY_GATE3(2, 4, 4, 2, 32, 3, 6) TRY_GATE3(4, 2, 2, 4, 32, 3, 6)
 #ifdef WN_EPI_ABLATE
         {   // main-loop timeline of the first workgroups (wave 0 and wave 5): stamps [before vmcnt wait, after it, after barrier, after DMA issue]
