@@ -42,14 +42,22 @@ __device__ inline uint32_t pack_bf2(float lo, float hi) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dropout mask: counter-based hash, one 32-bit word per PAIR of elements (16 bits each).
+// Dropout mask: counter-based hash, 64 bits per QUAD of elements (16 bits each).
 // element e (flat index in the [rows][R] layer input) of layer-key `key` is KEPT iff
-// bits16(e) >= thresh16, thresh16 = round(p * 65536).  Spec mirrored in python (tests) bit for bit.
+// bits16(e) >= thresh16, thresh16 = round(p * 65536).  Quad q = e >> 2:  a = mix(q ^ key_lo),  b = mix(a + key_hi);
+// elements 4q, 4q+1 take the low / high half of b, elements 4q+2, 4q+3 those of a ^ rotl(b, 16).  (Round 1 hashed every PAIR
+// twice: 4 quarter-rate v_mul_lo_u32 per two elements in the out-conv and dx epilogues; this is 4 per four.)
+// Spec mirrored in python (tests/hip_util.py) bit for bit.
 __host__ __device__ inline uint32_t wn_mix32(uint32_t x) {          // murmur3 finaliser
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; return x;
 }
-__host__ __device__ inline uint32_t wn_drop_word(uint32_t key_lo, uint32_t key_hi, uint32_t pair_index) {
-    return wn_mix32(wn_mix32(pair_index ^ key_lo) + key_hi);
+__host__ __device__ inline void wn_drop_quad(uint32_t key_lo, uint32_t key_hi, uint32_t quad_index, uint32_t& w0, uint32_t& w1) {
+    const uint32_t a = wn_mix32(quad_index ^ key_lo), b = wn_mix32(a + key_hi);
+    w0 = b; w1 = a ^ ((b << 16) | (b >> 16));
+}
+__host__ __device__ inline uint32_t wn_drop_word(uint32_t key_lo, uint32_t key_hi, uint32_t pair_index) {      // elements 2*pair_index, +1
+    uint32_t w0, w1; wn_drop_quad(key_lo, key_hi, pair_index >> 1, w0, w1);
+    return (pair_index & 1u) ? w1 : w0;
 }
 __host__ __device__ inline void wn_layer_key(uint64_t seed, int layer, uint32_t* lo, uint32_t* hi) {
     uint64_t k = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer + 1) * 0xD1B54A32D192ED03ull;

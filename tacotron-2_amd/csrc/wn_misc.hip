@@ -218,10 +218,11 @@ __global__ void wn_first_conv_fwd(const void* __restrict__ x, const float* __res
                                                                hb[4] | ((uint32_t)hb[5] << 16), hb[6] | ((uint32_t)hb[7] << 16));
     if (XD0) {      // layer-0 conv input with its dropout mask applied once (modules.py:484)
         const uint32_t e0 = (uint32_t)(row * R + c0);
-        uint32_t o[4];
+        uint32_t o[4], wq[4];        // e0 % 8 == 0 (c0 % 8 == 0, R % 8 == 0)
+        wn_drop_quad(key_lo, key_hi, e0 >> 2, wq[0], wq[1]); wn_drop_quad(key_lo, key_hi, (e0 >> 2) + 1, wq[2], wq[3]);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const uint32_t w = wn_drop_word(key_lo, key_hi, (e0 >> 1) + p);
+            const uint32_t w = wq[p];
             const float lo = ((w & 0xffffu) >= thresh16) ? bf2f(hb[2 * p]) * keep_scale : 0.0f;
             const float hi = ((w >> 16) >= thresh16) ? bf2f(hb[2 * p + 1]) * keep_scale : 0.0f;
             o[p] = pack_bf2(lo, hi);

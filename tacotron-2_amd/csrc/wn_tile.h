@@ -95,10 +95,11 @@ __device__ __forceinline__ bool drop_keep(uint32_t key_lo, uint32_t key_hi, uint
 // apply dropout to 8 consecutive bf16 elements starting at flat element index e0 (e0 % 8 == 0)
 __device__ __forceinline__ uint4 drop8(uint4 v, uint32_t key_lo, uint32_t key_hi, uint32_t thresh16, float ks, uint32_t e0) {
     uint32_t in[4] = {v.x, v.y, v.z, v.w};
-    uint32_t out[4];
+    uint32_t out[4], wq[4];
+    wn_drop_quad(key_lo, key_hi, e0 >> 2, wq[0], wq[1]); wn_drop_quad(key_lo, key_hi, (e0 >> 2) + 1, wq[2], wq[3]);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        uint32_t w = wn_drop_word(key_lo, key_hi, (e0 >> 1) + p);
+        const uint32_t w = wq[p];
         float lo = bf2f((bf16_t)(in[p] & 0xffffu)), hi = bf2f((bf16_t)(in[p] >> 16));
         lo = ((w & 0xffffu) >= thresh16) ? lo * ks : 0.0f;
         hi = ((w >> 16) >= thresh16) ? hi * ks : 0.0f;
@@ -447,13 +448,39 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     const unsigned long long wg_t_start = __builtin_amdgcn_s_memtime();
 #endif
 
+    // The accumulators START at the bias of their output channel (gate: b_dil + b_cin + global-conditioning row of this utterance;
+    // 1x1 convs: their bias), so the fused epilogues neither load nor add it: 4 x 16-B loads here, under the first DMAs, instead of
+    // 16 bias values per 8-channel item in the epilogue.  acc[i][j][r] is output row (wm*MT + i)*32 + (r/4)*8 + (lane>>5)*4 + r%4.
     f32x16_t acc[MT][NT];
+    if constexpr (EPI == EPI_GATE || EPI == EPI_STORE_BF16) {
+        const float* bp = a.e.bias;
+        if constexpr (EPI == EPI_GATE) bp += (int64_t)b * a.e.bias_bstride;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int ml = (wm * MT + i) * 32 + qd * 8 + (lane >> 5) * 4;       // row inside the workgroup's M tile
+                float4 bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (bp) {
+                    if constexpr (EPI == EPI_GATE) {
+                        // packed gate rows: 64-row groups of [32 tanh rows | 32 sigmoid rows] of the same 32 gate channels
+                        const int gl = (ml >> 6) * 32 + (ml & 31);
+                        bv = *reinterpret_cast<const float4*>(bp + ((ml & 32) ? a.e.GH : 0) + mblk * (Cfg::MTILE / 2) + gl);
+                    } else {
+                        bv = *reinterpret_cast<const float4*>(bp + mblk * Cfg::MTILE + ml);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { acc[i][j][qd * 4] = bv.x; acc[i][j][qd * 4 + 1] = bv.y; acc[i][j][qd * 4 + 2] = bv.z; acc[i][j][qd * 4 + 3] = bv.w; }
+            }
+    } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    }
 
     const int mtile_wg = mblk * (WM * MT);           // first 32-row m-tile of this workgroup
     const int mtile0 = mtile_wg + wm * MT;            // first m-tile of this wave
@@ -859,8 +886,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
             __syncthreads();
             if constexpr (EPI == EPI_GATE) {
                 constexpr int GT = Cfg::MTILE / 2, C8 = GT / 8, ITEMS = PROWS * C8;
-                const float* const gb = e.bias + (int64_t)b * e.bias_bstride;
-                bf16_t* TS = (bf16_t*)e.out0; bf16_t* U = (bf16_t*)e.out1;
+                bf16_t* TS = (bf16_t*)e.out0; bf16_t* U = (bf16_t*)e.out1;      // (the bias is already in the accumulators)
                 for (int it = tid; it < ITEMS; it += Cfg::NW * 64) {
                     const int rl = it / C8, c8 = it % C8;
                     const int t = t0 + ((rl >> 5) * NT + j) * 32 + (rl & 31);
@@ -873,8 +899,8 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                     uint32_t ps[4], pu[4];
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        const float t0_ = fast_tanh(za[2 * p] + gb[g + 2 * p]), t1_ = fast_tanh(za[2 * p + 1] + gb[g + 2 * p + 1]);
-                        const float s0_ = fast_sigmoid(zb[2 * p] + gb[e.GH + g + 2 * p]), s1_ = fast_sigmoid(zb[2 * p + 1] + gb[e.GH + g + 2 * p + 1]);
+                        const float t0_ = fast_tanh(za[2 * p]), t1_ = fast_tanh(za[2 * p + 1]);
+                        const float s0_ = fast_sigmoid(zb[2 * p]), s1_ = fast_sigmoid(zb[2 * p + 1]);
                         ps[p] = pack_bf2(s0_, s1_); pu[p] = pack_bf2(t0_ * s0_, t1_ * s1_);
                     }
                     const int64_t row = rowbase + t;
@@ -897,11 +923,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                         f[4] = bf2f((bf16_t)(x.z & 0xffff)); f[5] = bf2f((bf16_t)(x.z >> 16)); f[6] = bf2f((bf16_t)(x.w & 0xffff)); f[7] = bf2f((bf16_t)(x.w >> 16));
                     };
                     auto pack8 = [](const float* f) { return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7])); };
-                    if constexpr (EPI == EPI_STORE_BF16) {
-                        if (e.bias) {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] += e.bias[m + r];
-                        }
+                    if constexpr (EPI == EPI_STORE_BF16) {        // (bias: already in the accumulators)
                         if (e.in0) {
                             float x[8]; unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), x);
 #pragma unroll
@@ -913,10 +935,12 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                         *reinterpret_cast<uint4*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pk;
                         if (e.out1) {     // dropout of the next layer's conv input (tf.layers.dropout, modules.py:484), from the ROUNDED value
                             float x[8], dd[8]; unpack8(pk, x);
-                            const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);
+                            const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);      // % 8 == 0 (m % 8 == 0, drop_ld = R % 8 == 0): two whole quads
+                            uint32_t wq[4];
+                            wn_drop_quad(a.key_lo, a.key_hi, e0 >> 2, wq[0], wq[1]); wn_drop_quad(a.key_lo, a.key_hi, (e0 >> 2) + 1, wq[2], wq[3]);
 #pragma unroll
                             for (int p = 0; p < 4; ++p) {
-                                const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, (e0 >> 1) + p);
+                                const uint32_t w = wq[p];
                                 dd[2 * p] = ((w & 0xffffu) >= a.thresh16) ? x[2 * p] * a.keep_scale : 0.0f;
                                 dd[2 * p + 1] = ((w >> 16) >= a.thresh16) ? x[2 * p + 1] * a.keep_scale : 0.0f;
                             }
@@ -939,9 +963,11 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                     } else if constexpr (EPI == EPI_DX) {
                         if (a.thresh16 != 0) {
                             const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);
+                            uint32_t wq[4];
+                            wn_drop_quad(a.key_lo, a.key_hi, e0 >> 2, wq[0], wq[1]); wn_drop_quad(a.key_lo, a.key_hi, (e0 >> 2) + 1, wq[2], wq[3]);
 #pragma unroll
                             for (int p = 0; p < 4; ++p) {
-                                const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, (e0 >> 1) + p);
+                                const uint32_t w = wq[p];
                                 v[2 * p] = ((w & 0xffffu) >= a.thresh16) ? v[2 * p] * a.keep_scale : 0.0f;
                                 v[2 * p + 1] = ((w >> 16) >= a.thresh16) ? v[2 * p + 1] * a.keep_scale : 0.0f;
                             }

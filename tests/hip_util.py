@@ -58,7 +58,9 @@ def dropout_mask(seed, layer, rows, R, p):
     """{0,1} float mask [rows, R] identical to the device's (element e = row*R + r)."""
     lo, hi = layer_key(seed, layer)
     e = np.arange(rows * R, dtype=np.uint64)
-    w = _mix32((_mix32((e >> 1) ^ lo) + hi) & 0xffffffff)
+    a = _mix32((e >> 2) ^ lo)                                  # one double hash per QUAD of elements (wn_drop_quad)
+    b = _mix32((a + hi) & 0xffffffff)
+    w = np.where(((e >> 1) & 1) == 1, a ^ (((b << 16) | (b >> 16)) & 0xffffffff), b)
     bits = np.where((e & 1) == 1, w >> 16, w & 0xffff)
     thresh = int(np.rint(np.float32(p) * np.float32(65536.0)))
     return (bits >= thresh).astype(np.float32).reshape(rows, R)
@@ -67,20 +69,24 @@ def dropout_mask(seed, layer, rows, R, p):
 def dropout_mask_rows(seed, layer, row0, nrows, R, p):
     """rows [row0, row0 + nrows) of the device mask (element e = row*R + r, absolute rows); in-place uint32 arithmetic
     (wraps like the device's), ~0.1 s per 11000 x 256 layer."""
-    assert (row0 * R) % 2 == 0 and (nrows * R) % 2 == 0
+    assert (row0 * R) % 4 == 0 and (nrows * R) % 4 == 0
     lo, hi = layer_key(seed, layer)
-    w = np.arange((row0 * R) >> 1, ((row0 + nrows) * R) >> 1, dtype=np.uint32)
+    a = np.arange((row0 * R) >> 2, ((row0 + nrows) * R) >> 2, dtype=np.uint32)
 
     def mix(x):
         x ^= (x >> np.uint32(16)); x *= np.uint32(0x85ebca6b)
         x ^= (x >> np.uint32(13)); x *= np.uint32(0xc2b2ae35)
         x ^= (x >> np.uint32(16))
         return x
-    w ^= np.uint32(lo); w = mix(w); w += np.uint32(hi); w = mix(w)
+    a ^= np.uint32(lo); a = mix(a)
+    b = a + np.uint32(hi); b = mix(b)
+    w1 = a ^ ((b << np.uint32(16)) | (b >> np.uint32(16)))
     thresh = int(np.rint(np.float32(p) * np.float32(65536.0)))
-    out = np.empty((nrows * R // 2, 2), dtype=np.float32)
-    out[:, 0] = (w & np.uint32(0xffff)) >= thresh
-    out[:, 1] = (w >> np.uint32(16)) >= thresh
+    out = np.empty((nrows * R // 4, 4), dtype=np.float32)
+    out[:, 0] = (b & np.uint32(0xffff)) >= thresh
+    out[:, 1] = (b >> np.uint32(16)) >= thresh
+    out[:, 2] = (w1 & np.uint32(0xffff)) >= thresh
+    out[:, 3] = (w1 >> np.uint32(16)) >= thresh
     return out.reshape(nrows, R)
 
 
