@@ -379,6 +379,11 @@ __global__ __launch_bounds__(WM * WN * 64) void wn_gemm_tile_kernel(const GemmAr
 __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
 }
+// SGPR-base form: address = sbase (wave-uniform, 64 bit) + voff (per lane, 32 bit).  No per-lane 64-bit address arithmetic: the
+// weight panel's DMA source advances by a scalar add per chunk.
+__device__ __forceinline__ void lds_dma16_s(uint64_t sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -822,8 +827,80 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     // prologue: fill NBUF-1 buffers
     stage(std::integral_constant<int, 0>{});
     if constexpr (NBUF == 3) { if (nchunks > 1) stage(std::integral_constant<int, 1>{}); }
+    int ch0 = 0;
+    if constexpr (TAPS == 3 && PIPE == 1 && NBUF == 3) {
+        // ---- regular part of the K-interleaved taps (all k-blocks but the last): the generic staging iterator above costs ~80 mostly
+        // scalar, branchy instructions per chunk IN FRONT of the wave's MFMAs (in-order issue).  Here the three ring steps of one
+        // k-block are unrolled with everything they need in registers: the weight panel source is an SGPR base advanced by one
+        // scalar add per chunk (SGPR-base DMA form), the activation source one 64-bit add per lane and tap; no segment
+        // bookkeeping, no division, one loop branch per three chunks.  Same chunk order, same sums.
+        const int nkb = a.seg[0].nk / BK;
+        if (nkb >= 2 && dbg == 0 && nchunks > 3 * (nkb - 1) + 1) {
+            uint64_t sa[APW];
+#pragma unroll
+            for (int p = 0; p < APW; ++p) {
+                const int f = wave + p * NWD;
+                const uint64_t v = (uint64_t)(a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512);
+                sa[p] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            }
+            const uint32_t a_voff = lane * 16;
+            const bf16_t* tpb = a.seg[0].base + a.seg[0].col0;          // k-block of the chunk being staged (chunk 2 = tap 2 of k-block 0 is next)
+            auto fast_stage = [&](auto bufc) {
+                constexpr int BUF = decltype(bufc)::value;              // ring slot == tap
+                char* const abuf = lds + BUF * Cfg::BUF_BYTES;
+                char* const bbuf = abuf + Cfg::A_BYTES;
+                if constexpr (BUF == 0) tpb += BK;
+#pragma unroll
+                for (int p = 0; p < APW; ++p) {
+                    lds_dma16_s(sa[p], a_voff, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + (wave + p * NWD) * 1024)));
+                    sa[p] += Cfg::KS * 1024;
+                }
+#pragma unroll
+                for (int p = 0; p < BPW; ++p) {
+                    const bf16_t* src = b_offt[BUF][p] >= 0 ? tpb + b_offt[BUF][p] : a.zero;
+                    lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                }
+            };
+            auto fast_step = [&](auto bufc) {
+                constexpr int BUF = decltype(bufc)::value;
+                // chunk ch landed (only chunk ch+1 may still be in flight); lgkmcnt(0): this wave's fragment reads of chunk ch-1 have
+                // RETURNED before the barrier releases its ring slot to the next DMA -- the compiler is free to sink the (register-only)
+                // MFMAs of chunk ch-1 and the waits in front of them below the barrier, and does
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::LPC) : "memory");
+                __builtin_amdgcn_s_barrier();
+                const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+                bf16x8_t af[Cfg::KS][MT], bfr[Cfg::KS][NT];
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        af[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fast_stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+            };
+            for (int kb = 0; kb < nkb - 1; ++kb) {
+                fast_step(std::integral_constant<int, 0>{});
+                fast_step(std::integral_constant<int, 1>{});
+                fast_step(std::integral_constant<int, 2>{});
+            }
+            ch0 = 3 * (nkb - 1);
+            s_kstep += Cfg::KS * ch0; t_left -= ch0;
+        }
+    }
     auto main_loop = [&](auto latec) {
-        for (int ch = 0; ch < nchunks; ch += NBUF) {
+        for (int ch = ch0; ch < nchunks; ch += NBUF) {
             ring_step(std::integral_constant<int, 0>{}, ch, latec);
             if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1, latec);
             if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2, latec); }

@@ -51,6 +51,15 @@ static void launch_v2(GemmArgs a, int M, hipStream_t st) {
     const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
     hipLaunchKernelGGL((wn_gemm_lds_kernel<MT, NT, WM, WN, BK, NBUF, EPI, PIPE>), dim3(grid), dim3(WM * WN * 64), 0, st, a);
 }
+// the production launch of the gate / dx GEMMs: K-interleaved taps (ring slot == tap), contiguous tile run per XCD, staggered start
+template <int EPI, int PIPE>
+static void launch_prod(GemmArgs a, int M, hipStream_t st) {
+    a.mblocks = M / 256; a.tiles_per_utt = cdiv(a.T, 128); a.ntiles = a.tiles_per_utt * a.B;
+    a.xcd_span = cdiv(a.ntiles, 8); a.taps = 3;
+    const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+    a.stagger = grid >= 1024 ? 8000 : 0;
+    hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, PIPE, 3>), dim3(grid), dim3(512), 0, st, a);
+}
 static float time_ms(const std::function<void()>& f, int iters = 10) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     f(); CK(hipDeviceSynchronize());
@@ -243,6 +252,10 @@ int main(int argc, char** argv) {
           bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "GX"); \
           printf("dx     v2 PIPE%d   : %8.1f us  %7.1f TF  %s\n", PP_, t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
         for (int rnd = 0; rnd < 2; ++rnd) { TRY_DXP(1) TRY_DXP(6) TRY_DXP(7) }
+        for (int rnd = 0; rnd < 3; ++rnd) {      // production configuration (timing only)
+            float t0 = time_ms([&] { launch_prod<EPI_DX, 0>(a2, M, 0); }); float t1p = time_ms([&] { launch_prod<EPI_DX, 1>(a2, M, 0); });
+            printf("dx     production TAPS3 xcd_span: PIPE0 %8.1f us %7.1f TF   PIPE1 %8.1f us %7.1f TF\n", t0 * 1e3, fl / t0 / 1e9, t1p * 1e3, fl / t1p / 1e9);
+        }
         { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DX>(a2, M, 0); }); CK(hipDeviceSynchronize());
           bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "GX");
           printf("dx     v2 WM4 WN2 BK32 NBUF3   : %8.1f us  %7.1f TF  %s\n", t2 * 1e3, fl / t2 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok; }
