@@ -298,6 +298,46 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
             wg_lds_dma16(src, __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(bbuf + g * 1024)));
         }
     };
+    // ---- interior chunks of full tiles: every source address is (wave-uniform base) + (per-lane constant), no bounds to check.
+    // The generic stage() above recomputes five 64-bit row addresses with quarter-rate integer multiplies and four range tests per
+    // chunk (~130 instructions in front of the wave's MFMAs); this one is five scalar base computations and five SGPR-base DMAs.
+    bool fast_wg = (NA > 1) && (n0 + 256 <= a.N) && !(a.split_n > 0 && n0 < a.split_n && n0 + 256 > a.split_n);      // (single-A launches: 128 VGPRs, no room)
+    int sh_min = 0, sh_max = 0;
+#pragma unroll
+    for (int x = 0; x < NA; ++x) { fast_wg = fast_wg && a_valid[x] == 128 && a_ld[x] == a_ld[0]; sh_min = min(sh_min, a_shift[x]); sh_max = max(sh_max, a_shift[x]); }
+    const bool b_is_hi = a.split_n > 0 && n0 >= a.split_n;
+    const bf16_t* const fb_base = b_is_hi ? b_hi + (n0 - a.split_n) : b_lo + n0;
+    const int fb_ld = b_is_hi ? a.ldb_hi : a.ldb;
+    const uint32_t voffA = (uint32_t)(((lane >> 4) * a_ld[0] + (((lane & 15) ^ (((lane >> 4) & 3) << 2)) * 8)) * 2);
+    const uint32_t voffB = (uint32_t)(((lane >> 5) * fb_ld + (((lane & 31) ^ (((wave * 2 + (lane >> 5)) & 3) << 2)) * 8)) * 2);
+    auto sgpr64 = [](uint64_t v) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
+    auto fast_stage = [&](auto bufc, int ch) {
+        constexpr int BUF = decltype(bufc)::value;
+        char* const abuf = lds + BUF * BUFB;
+        char* const bbuf = abuf + NA * WG2_AB;
+        const int64_t r0 = rowbase + ts0 + ch * WG2_KT;
+        const uint32_t va = voffA, vb = voffB;
+#pragma unroll
+        for (int x = 0; x < NA; ++x) {
+            const uint64_t sb = sgpr64((uint64_t)(a_base[x] + (r0 + a_shift[x] + wave * 4) * a_ld[0]));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va), "s"(sb),
+                         "s"(__builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(abuf + x * WG2_AB + wave * 1024))) : "memory", "m0");
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int g = wave + p * 8;
+            const uint64_t sb = sgpr64((uint64_t)(fb_base + (r0 + g * 2) * fb_ld));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vb), "s"(sb),
+                         "s"(__builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(bbuf + g * 1024))) : "memory", "m0");
+        }
+    };
+    auto stage_any = [&](auto bufc, int ch) {
+        if constexpr (NA > 1) {
+            const int tc = ts0 + ch * WG2_KT;
+            if (fast_wg && tc + sh_min >= 0 && tc + WG2_KT + sh_max <= T && tc + WG2_KT <= ts1) { fast_stage(bufc, ch); return; }
+        }
+        stage(bufc, ch);
+    };
     // per-lane constants of the transposing reads: lane -> (row within a 4-row block, 8-B piece within the 16 channels)
     const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int tr_colb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;       // byte offset inside a 32-channel fragment
@@ -361,12 +401,12 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
         if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{}, ch + NBUF - 1);
+        if (ch + NBUF - 1 < nchunks) stage_any(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{}, ch + NBUF - 1);
         compute(bufc);
     };
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
-    if (nchunks > 0) stage(std::integral_constant<int, 0>{}, 0);
-    if constexpr (NBUF == 3) { if (nchunks > 1) stage(std::integral_constant<int, 1>{}, 1); }
+    if (nchunks > 0) stage_any(std::integral_constant<int, 0>{}, 0);
+    if constexpr (NBUF == 3) { if (nchunks > 1) stage_any(std::integral_constant<int, 1>{}, 1); }
     for (int ch = 0; ch < nchunks; ch += NBUF) {
         ring_step(std::integral_constant<int, 0>{}, ch);
         if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1);
