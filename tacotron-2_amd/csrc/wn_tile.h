@@ -575,6 +575,33 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                 return;
             }
         }
+        if constexpr (PIPE <= 1 && TAPS == 0) {
+            // full chunk inside the current segment (all but one chunk of every launch of the engine): no partial-k masks, the weight
+            // panel through the SGPR-base DMA form
+            if (s_left >= BK && s_rep < a.nrep && dbg == 0) {
+                if (dma_wave) {
+#pragma unroll
+                    for (int p = 0; p < APW; ++p) {
+                        const int f = wave + p * NWD;
+                        const uint64_t v = (uint64_t)(a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512);
+                        const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+                        lds_dma16_s(sb, lane * 16, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + f * 1024)));
+                    }
+#pragma unroll
+                    for (int p = 0; p < BPW; ++p) {
+                        const bf16_t* src = b_off[p] >= 0 ? s_ptr + b_off[p] : a.zero;
+                        lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                    }
+                }
+                s_kstep += Cfg::KS; s_left -= BK; s_ptr += BK;
+                if (s_left <= 0) {
+                    ++s_sg; if (s_sg == a.nseg) { s_sg = 0; ++s_rep; }
+                    s_left = a.seg[s_sg].nk; s_ptr = a.seg[s_sg].base + a.seg[s_sg].col0 + (int64_t)s_rep * a.rep_stride;
+                    enter_segment();
+                }
+                return;
+            }
+        }
         const int kc = (s_rep < a.nrep) ? min(BK, s_left) : 0;      // past the last chunk: an all-zero chunk (PIPE 2 pads the count)
         // A: fragment f = mt*KS + ks  <-  Apk[(mtile_wg + mt)][s_kstep + ks]; wave-uniform base + lane*16
         if (!(dbg & 1) && dma_wave) {
