@@ -269,6 +269,7 @@ extern "C" void wn_destroy(wn_ctx* c) {
     for (int k = 2; k < WN_MAX_PARTS; ++k) if (c->stp[k]) { (void)hipStreamSynchronize(c->stp[k]); hipStreamDestroy(c->stp[k]); }
     for (int k = 0; k < WN_MAX_PARTS; ++k) if (c->ev_pjoin[k]) hipEventDestroy(c->ev_pjoin[k]);
     for (int p = 0; p < WN_MAX_PARTS; ++p) for (int k = 0; k < WN_MAX_BUCKETS; ++k) if (c->ev_chain[p][k]) hipEventDestroy(c->ev_chain[p][k]);
+    for (int p = 0; p < WN_MAX_PARTS; ++p) if (c->ev_head[p]) hipEventDestroy(c->ev_head[p]);
     for (int k = 0; k < WN_MAX_BUCKETS + 2; ++k) if (c->ev_bucket[k]) hipEventDestroy(c->ev_bucket[k]);
     if (c->ev_w0) hipEventDestroy(c->ev_w0);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);

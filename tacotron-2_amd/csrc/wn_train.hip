@@ -290,6 +290,7 @@ static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
         a.nseg = 1; a.seg[0] = seg(c->DY, ldDY, 0, c->wh2T.K, 0, 0);
         a.e.in0 = c->H2; a.e.ld_in0 = S; a.e.out0 = c->DPRE1; a.e.ld_out0 = S;
         if ((rc = wn_launch_gemm<EPI_MASK_STORE>(c, a, c->wh2T.M, st))) return rc;
+        WN_HIP(c, hipEventRecord(c->ev_head[part], st));
     }
     {   // d skip = (W1 dpre1) * (skips > 0)
         GemmArgs a; base_args(c, a, c->wh1T, b0, nb);
@@ -355,6 +356,7 @@ static int buckets_setup(wn_ctx* c) {
     WN_HIP(c, hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, lo_pri));
     for (int p = 0; p < WN_MAX_PARTS; ++p)
         for (int k = 0; k < WN_MAX_BUCKETS; ++k) WN_HIP(c, hipEventCreateWithFlags(&c->ev_chain[p][k], hipEventDisableTiming));
+    for (int p = 0; p < WN_MAX_PARTS; ++p) WN_HIP(c, hipEventCreateWithFlags(&c->ev_head[p], hipEventDisableTiming));
     for (int k = 0; k < WN_MAX_BUCKETS + 2; ++k) WN_HIP(c, hipEventCreateWithFlags(&c->ev_bucket[k], hipEventDisableTiming));
     WN_HIP(c, hipEventCreateWithFlags(&c->ev_w0, hipEventDisableTiming));
     return WN_OK;
@@ -456,30 +458,32 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     static const bool serial = getenv("WN_SERIAL") != nullptr;      // profiling aid: every kernel on the caller's stream (with WN_BATCH_PARTS=1: exclusive kernel times)
     hipStream_t wst = serial ? st : c->st3;
     WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
-    // ---- the serial chain, per batch part (two streams)
-    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;
-    // ---- head weight gradients over the whole batch (wavenet.py:136-149): need DY / DPRE1 of BOTH parts (head of the chain)
-    {   // (enqueued after the chain in host order, but gated only by the events of the first bucket)
-        if (nearly > 0) {
-            for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[pk][0], 0));
-        } else {
-            WN_HIP(c, hipEventRecord(c->ev_w0, st));
-            WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
-        }
-    }
-    {   // d final_convolution_2 = H2^T dY
+    {   // d final_convolution_2 = H2^T dY: both operands exist since the forward / loss -- starts now, under the chain (low priority)
         WgArgs w; memset(&w, 0, sizeof w);
         w.nseg = 1; w.seg[0] = seg(c->H2, S, 0, S, 0, 0); w.ones_row = 1;
         w.Bm = c->DY; w.ldb = ldDY; w.colb0 = 0; w.N = O;
         w.out = grads + c->fin2_k; w.ldw = O; w.bias_out = grads + c->fin2_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
         if ((rc = launch_wgrad(c, w, wst))) return rc;
     }
-    {   // d final_convolution_1 = R1^T dpre1
+    // ---- the serial chain, per batch part (two streams)
+    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;
+    // ---- head weight gradients over the whole batch (wavenet.py:136-149): d final_convolution_1 = R1^T dpre1 needs d pre1 of every
+    // part, the first thing each chain stream computes (enqueued after the chain in host order, gated only by those events)
+    for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_head[pk], 0));
+    {
         WgArgs w; memset(&w, 0, sizeof w);
         w.nseg = 1; w.seg[0] = seg(c->R1, S, 0, S, 0, 0); w.ones_row = 1;
         w.Bm = c->DPRE1; w.ldb = S; w.N = S;
         w.out = grads + c->fin1_k; w.ldw = S; w.bias_out = grads + c->fin1_b; w.scale = 1.0f; w.B = c->fB; w.T = c->fT;
         if ((rc = launch_wgrad(c, w, wst))) return rc;
+    }
+    {   // the stack weight gradients below need the chain (all of it, or up to the first bucket's lowest layer)
+        if (nearly > 0) {
+            for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[pk][0], 0));
+        } else {
+            WN_HIP(c, hipEventRecord(c->ev_w0, st));
+            WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
+        }
     }
     // ---- weight gradients of the stack, each kind for all layers of a bucket in one grouped launch (wn_wgrad.h)
     for (int k = 0; k < nearly; ++k) {
