@@ -150,7 +150,6 @@ static int alloc_workspace(wn_ctx* c) {
     sz(NT * 4); sz(NT * c->C * 4);          // XIN, CIN
     sz(256);                               // scalars
     sz(256);                               // zero page
-    sz(256);                               // page of bf16 ones (weight-gradient bias row, wn_wgrad.h)
     c->ws_bytes = total;
     hipError_t e = hipMalloc((void**)&c->ws, total);
     if (e != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMalloc(%zu bytes workspace) failed: %s", total, hipGetErrorString(e));
@@ -175,11 +174,6 @@ static int alloc_workspace(wn_ctx* c) {
     c->scal = (float*)bump(p, 256);
     c->zero_page = (bf16_t*)bump(p, 256);
     if (hipMemset(c->zero_page, 0, 256) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
-    c->ones_page = (bf16_t*)bump(p, 256);
-    {
-        bf16_t ones[128]; for (auto& v : ones) v = 0x3F80;        // bf16 1.0
-        if (hipMemcpy(c->ones_page, ones, sizeof ones, hipMemcpyHostToDevice) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemcpy(ones page) failed");
-    }
     return WN_OK;
 }
 

@@ -145,7 +145,6 @@ struct wn_ctx {
     void* XIN; float* CIN;                // ctx-owned copies of the step's x and c (pointers are borrowed per call)
     float* wg_partial = nullptr; size_t wg_partial_bytes = 0;   // split-K partial tiles of the grouped wgrad (wn_wgrad.h)
     bf16_t* GXall = nullptr;              // [L+1][NT][R] gradient wrt every layer input (kept for the grouped W_out wgrad)
-    bf16_t* ones_page = nullptr;          // 256 B of bf16 1.0 (training contexts): the bias row of the merged weight-gradient launch
     bf16_t* zero_page = nullptr;          // 256 B of zeros: DMA source for out-of-range rows (wn_gemm_lds_kernel)
     float* scal;                          // device scalars: [0]=loss sum [1]=denominator [2]=1/denominator [3]=count
     // state of the last forward

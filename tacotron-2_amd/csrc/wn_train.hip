@@ -60,12 +60,6 @@ static bool wgrad_multi() {
 }
 // d W_dil of the layers [l0, l0 + ng): the three taps of one 128-channel block of the layer input share ONE workgroup and ONE staged
 // d z tile (A = xd(t-2d) | xd(t-d) | xd(t), B = d z); the conditioning kernel's gradient is its own (single-A) launch, wgrad_cin_args.
-// one launch reads d z for the dilated taps AND the conditioning kernel (extra tile position of the multi-A kernel); WN_WGRAD_CIN_MERGE=0
-// restores the separate conditioning launch (A/B switch).  Needs C < 128 (a free channel slot for the ones row) and C % 8 == 0.
-static bool wgrad_cin_merged(wn_ctx* c) {
-    static const int v = [] { const char* e = getenv("WN_WGRAD_CIN_MERGE"); return e ? atoi(e) : 1; }();
-    return v != 0 && c->C % 8 == 0 && c->C <= 120 && c->lay.size() > 0 && c->lay[0].cin_k == c->lay[0].dil_k + (int64_t)3 * c->R * c->G;
-}
 static void wgrad_taps_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, int T) {
     const int64_t NT = c->NT; const int R = c->R, G = c->G;
     wgrad_common(c, w, ng, B, T);
@@ -74,17 +68,10 @@ static void wgrad_taps_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B, in
     w.Bm = c->DZ + (size_t)l0 * NT * G; w.b_gstride = NT * G; w.ldb = G; w.N = G; w.ldw = G;
     w.na = 3; w.hblocks = R / 128; w.a_colstep = 128;
     for (int x = 0; x < 3; ++x) { w.a_seg[x] = x; w.a_col0[x] = 0; w.a_mrow[x] = x * R; }
-    const bool merge = wgrad_cin_merged(c);
-    if (merge) {   // + the conditioning kernel's gradient at the extra tile position: rows [3R, 3R + C) of the same [(3R + C), G] matrix (the cin
-                   // kernel follows the dilated kernel in the flat buffer), row 3R + C = column sums of d z = both bias gradients
-        w.nseg = 4; w.seg_base[3] = c->cbt; w.seg_gstride[3] = 0; w.seg_ld[3] = c->C; w.seg_nk[3] = c->C;
-        w.extra_on = 1; w.extra_seg = 3; w.extra_mrow = 3 * R;
-    }
     for (int g = 0; g < ng; ++g) {
         const int l = l0 + g, d = c->dil[l];
         WgGroup& q = w.g[g];
-        q.out_off = c->lay[l].dil_k; q.bias_off = -1; q.bias2_off = 0; q.has_bias2 = 0;        // (bias gradients: wgrad_cin_args, or the merged extra tile)
-        if (merge && c->lbias) { q.bias_off = c->lay[l].dil_b; q.bias2_off = c->lay[l].cin_b; q.has_bias2 = 1; }
+        q.out_off = c->lay[l].dil_k; q.bias_off = -1; q.bias2_off = 0; q.has_bias2 = 0;        // (bias gradients: wgrad_cin_args)
         q.shift[0] = -2 * d; q.shift[1] = -d; q.shift[2] = 0; q.shift[3] = 0; q.scale = 1.0f;
     }
 }
@@ -423,7 +410,7 @@ static int stack_wgrads(wn_ctx* c, float* grads, int l0, int ng, bool fused, hip
             WgBatchArgs w; wgrad_taps_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
             if ((rc = launch_wgrad_batch(c, w, st))) return rc;
         }
-        if (!wgrad_cin_merged(c)) {   // d W_cin:  A = c(t),  B = d z
+        {   // d W_cin:  A = c(t),  B = d z
             WgBatchArgs w; wgrad_cin_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
             if ((rc = launch_wgrad_batch(c, w, st))) return rc;
         }

@@ -196,12 +196,6 @@ struct WgBatchArgs {
     // channel halves of u_l) with the SAME staged B tile: B is read na x less often and the DMA issue per MFMA drops accordingly.
     // A tile a of column block h (< hblocks): segment a_seg[a], channels [a_col0[a] + a_colstep h, +128), output rows a_mrow[a] + a_colstep h.
     int32_t na, hblocks, a_colstep, a_seg[3], a_col0[3], a_mrow[3];
-    // extra single-A tile position per unit (multi-A launches): tile index hblocks multiplies segment extra_seg (< 128 channels, e.g. the
-    // conditioning features) with the same B tiles -- the d z tensor is then read by ONE launch instead of two.  Its workgroups run
-    // the main loop with one A tile; channel slot extra_nk/8 of their A image is DMA'd from a page of ones, so output row
-    // extra_mrow + extra_nk holds the column sums of B (= the bias gradients) and nobody adds them up on the vector ALU.
-    int32_t extra_seg, extra_mrow, extra_on, pad1_;
-    const bf16_t* ones;                 // >= 16 B of bf16 1.0
     float* partial;                     // [unit][mtiles*128 + 8][N] fp32; row mtiles*128 = bias partial
     int32_t B, T, slab, spu, Mrows, mtiles, ntiles, nunits;
     const bf16_t* zero;
@@ -221,7 +215,7 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave >> 2, wn = wave & 3;
     // XCD-aware decode
-    const int mt_u = (NA == 1) ? a.mtiles : a.hblocks + (a.extra_on ? 1 : 0);            // A-tile positions per unit
+    const int mt_u = (NA == 1) ? a.mtiles : a.hblocks;            // A-tile positions per unit
     const int tpu = mt_u * a.ntiles;
     const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
     const int tile = q % tpu, u = (q / tpu) * 8 + xcd;
@@ -250,20 +244,10 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
 #pragma unroll
         for (int x = 0; x < NA; ++x) {
             const int sg = a.a_seg[x], col = a.a_col0[x] + mblk * a.a_colstep;
-            a_base[x] = a.seg_base[sg] + (int64_t)grp * a.seg_gstride[sg] + col; a_shift[x] = a.g[grp].shift[sg];
-            // one row pitch and one valid width for all A tiles of a multi-A launch (the host builds them that way: equal segments,
-            // 128-channel blocks): kept in ONE scalar each -- this kernel is at the register limit
-            a_ld[x] = a.seg_ld[a.a_seg[0]]; a_valid[x] = max(0, min(128, a.seg_nk[a.a_seg[0]] - (a.a_col0[0] + mblk * a.a_colstep))); a_mrow[x] = 0;
-        }
-        if (mblk == a.hblocks) {        // the extra single-A position
-            const int sg = a.extra_seg;
-            a_base[0] = a.seg_base[sg] + (int64_t)grp * a.seg_gstride[sg]; a_shift[0] = a.g[grp].shift[sg];
-#pragma unroll
-            for (int x = 0; x < NA; ++x) { a_ld[x] = a.seg_ld[sg]; a_valid[x] = a.seg_nk[sg]; }      // (tiles 1.. are not multiplied at this position)
+            a_base[x] = a.seg_base[sg] + (int64_t)grp * a.seg_gstride[sg] + col; a_ld[x] = a.seg_ld[sg]; a_shift[x] = a.g[grp].shift[sg];
+            a_valid[x] = max(0, min(128, a.seg_nk[sg] - col)); a_mrow[x] = a.a_mrow[x] + mblk * a.a_colstep;
         }
     }
-    const bool extra_wg = (NA > 1) && (mblk == a.hblocks);
-    const int ones_slot = extra_wg ? a_valid[0] >> 3 : -1;          // 16-B channel slot of the A image that reads the page of ones
     const int n0 = nblk * 256;
     // B columns [0, split_n) come from Bm, [split_n, N) from Bm_hi (fused launches); the split may fall INSIDE a 256-column
     // tile (narrow models: S = R = 128), so the operand is chosen per 8-column slot, i.e. per lane of the DMA
@@ -287,21 +271,18 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.0f;
 
-    // (NAE = A tiles this workgroup actually multiplies: NA, or 1 at the extra single-A position)
-    auto stage = [&](auto bufc, int ch, auto naec) {
+    auto stage = [&](auto bufc, int ch) {
         constexpr int BUF = decltype(bufc)::value;
-        constexpr int NAE = decltype(naec)::value;
         char* const abuf = lds + BUF * BUFB;
         char* const bbuf = abuf + NA * WG2_AB;
         const int tc = ts0 + ch * WG2_KT;
 #pragma unroll
-        for (int x = 0; x < NAE; ++x) {   // A tile x: piece `wave` = rows wave*4 .. +3, 16 slots of 16 B each
+        for (int x = 0; x < NA; ++x) {   // A tile x: piece `wave` = rows wave*4 .. +3, 16 slots of 16 B each
             const int row = wave * 4 + (lane >> 4);
             const int c = (lane & 15) ^ ((row & 3) << 2);
             const int t = tc + row, ts = t + a_shift[x];
-            const bool inr = (t < ts1) && (ts >= 0) && (ts < T);
-            const bool ok = (c * 8 < a_valid[x]) && inr;
-            const bf16_t* src = ok ? a_base[x] + (rowbase + ts) * a_ld[x] + c * 8 : ((inr && c == ones_slot) ? a.ones : a.zero);
+            const bool ok = (c * 8 < a_valid[x]) && (t < ts1) && (ts >= 0) && (ts < T);
+            const bf16_t* src = ok ? a_base[x] + (rowbase + ts) * a_ld[x] + c * 8 : a.zero;
             wg_lds_dma16(src, __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(abuf + x * WG2_AB + wave * 1024)));
         }
 #pragma unroll
@@ -327,18 +308,17 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
     const bool b_is_hi = a.split_n > 0 && n0 >= a.split_n;
     const bf16_t* const fb_base = b_is_hi ? b_hi + (n0 - a.split_n) : b_lo + n0;
     const int fb_ld = b_is_hi ? a.ldb_hi : a.ldb;
-    // (the per-lane offsets of the fast path are recomputed per chunk: two persistent VGPRs this kernel does not have)
+    const uint32_t voffA = (uint32_t)(((lane >> 4) * a_ld[0] + (((lane & 15) ^ (((lane >> 4) & 3) << 2)) * 8)) * 2);
+    const uint32_t voffB = (uint32_t)(((lane >> 5) * fb_ld + (((lane & 31) ^ (((wave * 2 + (lane >> 5)) & 3) << 2)) * 8)) * 2);
     auto sgpr64 = [](uint64_t v) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
-    auto fast_stage = [&](auto bufc, int ch, auto naec) {
+    auto fast_stage = [&](auto bufc, int ch) {
         constexpr int BUF = decltype(bufc)::value;
-        constexpr int NAE = decltype(naec)::value;
         char* const abuf = lds + BUF * BUFB;
         char* const bbuf = abuf + NA * WG2_AB;
         const int64_t r0 = rowbase + ts0 + ch * WG2_KT;
-        const uint32_t va = (uint32_t)(((lane >> 4) * a_ld[0] + (((lane & 15) ^ (((lane >> 4) & 3) << 2)) * 8)) * 2);
-        const uint32_t vb = (uint32_t)(((lane >> 5) * fb_ld + (((lane & 31) ^ (((wave * 2 + (lane >> 5)) & 3) << 2)) * 8)) * 2);
+        const uint32_t va = voffA, vb = voffB;
 #pragma unroll
-        for (int x = 0; x < NAE; ++x) {
+        for (int x = 0; x < NA; ++x) {
             const uint64_t sb = sgpr64((uint64_t)(a_base[x] + (r0 + a_shift[x] + wave * 4) * a_ld[0]));
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va), "s"(sb),
                          "s"(__builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(abuf + x * WG2_AB + wave * 1024))) : "memory", "m0");
@@ -351,26 +331,25 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
                          "s"(__builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(bbuf + g * 1024))) : "memory", "m0");
         }
     };
-    auto stage_any = [&](auto bufc, int ch, auto naec) {
-        if constexpr (NA > 1 && decltype(naec)::value == NA) {
+    auto stage_any = [&](auto bufc, int ch) {
+        if constexpr (NA > 1) {
             const int tc = ts0 + ch * WG2_KT;
-            if (fast_wg && tc + sh_min >= 0 && tc + WG2_KT + sh_max <= T && tc + WG2_KT <= ts1) { fast_stage(bufc, ch, naec); return; }
+            if (fast_wg && tc + sh_min >= 0 && tc + WG2_KT + sh_max <= T && tc + WG2_KT <= ts1) { fast_stage(bufc, ch); return; }
         }
-        stage(bufc, ch, naec);
+        stage(bufc, ch);
     };
     // per-lane constants of the transposing reads: lane -> (row within a 4-row block, 8-B piece within the 16 channels)
     const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int tr_colb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;       // byte offset inside a 32-channel fragment
-    auto compute = [&](auto bufc, auto naec) {
+    auto compute = [&](auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
-        constexpr int NAE = decltype(naec)::value;
         const char* const abuf = lds + BUF * BUFB;
         const char* const bbuf = abuf + NA * WG2_AB;
 #pragma unroll
         for (int ks = 0; ks < WG2_KT / 16; ++ks) {
-            bf16x8_t af[NAE][2], bfr[2];
+            bf16x8_t af[NA][2], bfr[2];
 #pragma unroll
-            for (int x = 0; x < NAE; ++x)
+            for (int x = 0; x < NA; ++x)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 s16x4 h[2];
@@ -396,7 +375,7 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
                 bfr[j] = __builtin_bit_cast(bf16x8_t, pk);
             }
 #pragma unroll
-            for (int x = 0; x < NAE; ++x)
+            for (int x = 0; x < NA; ++x)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -416,30 +395,23 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
             }
         }
     };
-    auto ring_step = [&](auto bufc, int ch, auto naec) {
+    auto ring_step = [&](auto bufc, int ch) {
         constexpr int BUF = decltype(bufc)::value;
-        constexpr int LPCE = decltype(naec)::value + 2;       // DMAs per wave per chunk
         const int younger = min(NBUF - 2, nchunks - 1 - ch);
-        if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPCE) : "memory");
+        if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (ch + NBUF - 1 < nchunks) stage_any(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{}, ch + NBUF - 1, naec);
-        compute(bufc, naec);
+        if (ch + NBUF - 1 < nchunks) stage_any(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{}, ch + NBUF - 1);
+        compute(bufc);
     };
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
-    auto run = [&](auto naec) {
-        if (nchunks > 0) stage_any(std::integral_constant<int, 0>{}, 0, naec);
-        if constexpr (NBUF == 3) { if (nchunks > 1) stage_any(std::integral_constant<int, 1>{}, 1, naec); }
-        for (int ch = 0; ch < nchunks; ch += NBUF) {
-            ring_step(std::integral_constant<int, 0>{}, ch, naec);
-            if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1, naec);
-            if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2, naec); }
-        }
-    };
-    if constexpr (NA > 1) {
-        if (extra_wg) run(std::integral_constant<int, 1>{});          // wave-uniform: the whole workgroup sits at the extra position
-        else run(std::integral_constant<int, NA>{});
-    } else run(std::integral_constant<int, 1>{});
+    if (nchunks > 0) stage_any(std::integral_constant<int, 0>{}, 0);
+    if constexpr (NBUF == 3) { if (nchunks > 1) stage_any(std::integral_constant<int, 1>{}, 1); }
+    for (int ch = 0; ch < nchunks; ch += NBUF) {
+        ring_step(std::integral_constant<int, 0>{}, ch);
+        if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1);
+        if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2); }
+    }
 
 #ifdef WN_EPI_ABLATE
     if (a.ldw != -7777) {
@@ -464,14 +436,12 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
     for (int x = 0; x < NA; ++x)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        if (x > 0 && extra_wg) continue;           // the extra position multiplied one A tile (rows extra_mrow .. +127; row extra_nk = column sums)
-        const int mrow_x = (NA == 1) ? a_mrow[0] : extra_wg ? a.extra_mrow : a.a_mrow[x] + mblk * a.a_colstep;
         const int n = n0 + (wn * 2 + j) * 32 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mrow_x + (wk * 2 + i) * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                const int m = a_mrow[x] + (wk * 2 + i) * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
                 P[(int64_t)m * a.N + n] = acc[x][i][j][r];
             }
         }
@@ -502,7 +472,7 @@ __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(const WgBatchArgs 
     const int64_t rem = idx - (int64_t)grp * per_group;
     const int m = (int)(rem / n4), c4 = (int)(rem % n4);
     const bool is_bias = (m == a.Mrows);
-    const int prow = is_bias ? (a.extra_on ? a.extra_mrow + a.seg_nk[a.extra_seg] : a.mtiles * 128) : m;       // (extra position: the ones slot put the column sums there)
+    const int prow = is_bias ? a.mtiles * 128 : m;
     const int upg = a.B * a.spu;
     const float* p = a.partial + ((int64_t)grp * upg * rows_p + prow) * a.N + c4 * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -529,8 +499,8 @@ __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(const WgBatchArgs 
 static inline void wn_wgrad_plan(WgBatchArgs& a) {
     a.Mrows = 0; for (int s = 0; s < a.nseg; ++s) a.Mrows += a.seg_nk[s];
     a.mtiles = cdiv(a.Mrows, 128); a.ntiles = a.N / 256;
-    if (a.na <= 1) { a.na = 1; a.hblocks = a.mtiles; a.extra_on = 0; }
-    const int tpu = (a.hblocks + (a.extra_on ? 1 : 0)) * a.ntiles;
+    if (a.na <= 1) { a.na = 1; a.hblocks = a.mtiles; }
+    const int tpu = a.hblocks * a.ntiles;
     // time slabs per utterance: multi-A workgroups are alone on their CU (one round = 256 workgroups) and every extra slab costs a
     // full fp32 output tile in the partial buffer, so launches are split only until one round is full (256 multi-A workgroups, or
     // 2 x 256 single-A ones)
@@ -552,8 +522,7 @@ static int launch_wgrad_batch(wn_ctx* c, WgBatchArgs& a, hipStream_t st) {
     wn_wgrad_plan(a);
     if (wn_wgrad_partial_bytes(a) > c->wg_partial_bytes) WN_FAIL(c, WN_E_STATE, "wgrad partial buffer too small (%zu > %zu)", wn_wgrad_partial_bytes(a), c->wg_partial_bytes);
     a.partial = c->wg_partial; a.zero = c->zero_page;
-    const int grid = cdiv(a.nunits, 8) * (a.hblocks + (a.extra_on ? 1 : 0)) * a.ntiles * 8;
-    a.ones = c->ones_page;
+    const int grid = cdiv(a.nunits, 8) * a.hblocks * a.ntiles * 8;
     if (a.na == 3) hipLaunchKernelGGL((wn_wgrad_lds_kernel<3, 3>), dim3(grid), dim3(512), 0, st, a);
     else if (a.na == 2) hipLaunchKernelGGL((wn_wgrad_lds_kernel<3, 2>), dim3(grid), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((wn_wgrad_lds_kernel<3, 1>), dim3(grid), dim3(512), 0, st, a);

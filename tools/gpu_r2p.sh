@@ -15,6 +15,3 @@ for v in "base:" "base:" "base:"; do
   ( env $envs timeout 200 python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', '%.3f ms/step' % d['ms_per_step'])" ) >> $OUT/ab.txt 2>&1
 done
 cat $OUT/ab.txt; tail -4 $OUT/pytest_a.log; tail -8 $OUT/pytest_b.log; tail -25 $OUT/wgrad.txt
-( env WN_WGRAD_CIN_MERGE=0 timeout 200 python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cin_separate', '%.3f ms/step' % d['ms_per_step'])" ) >> $OUT/ab.txt 2>&1
-( timeout 200 python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('base', '%.3f ms/step' % d['ms_per_step'])" ) >> $OUT/ab.txt 2>&1
-tail -2 $OUT/ab.txt
