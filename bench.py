@@ -77,8 +77,8 @@ def alg_bytes_per_sample(hp, e=2):
     return 3 * e * (L * (2 * R + C + 2 * S) + cin + O) + 2 * e * L * (G + G // 2)
 
 
-# measured HBM-side traffic of the gate-GEMM launches at C2 (profiles/r2e_pmc_fetch.md + r2e_pmc_write.md, 48 half-batch launches of 44 000 rows per
-# step): 2 x FETCH_SIZE = 2.27 GB and WRITE_SIZE = 2.16 GB per step => 92.3 MB per launch (algorithmic: 29.6 MB of activations read + 45.1 MB written:
+# measured HBM-side traffic of the gate-GEMM launches at C2 (profiles/r2x_pmc_fetch.md + r2x_pmc_write.md, 48 half-batch launches of 44 000 rows per
+# step): 2 x FETCH_SIZE = 2.26 GB and WRITE_SIZE = 2.16 GB per step => 92.3 MB per launch (algorithmic: 29.6 MB of activations read + 45.1 MB written:
 # sigmoid + gate output); scaled to 8 x 11 000 rows below
 GATE_TRAFFIC_BYTES = 2.0 * (2.27e9 + 2.16e9) / 48.0
 
@@ -274,8 +274,8 @@ class SmiSampler:
 
 # HBM-side traffic of one C2 training step, ALL kernels: sum over the kernels of (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3
 # PMC passes of this round (separate passes; FETCH_SIZE doubled as the gfx950 calibration in DESIGN 4 prescribes), per step.
-STEP_TRAFFIC_BYTES = {'c2': 35.18e9}          # 26.18 GB fetched + 9.00 GB written (round 1: 36.99 + 10.18 = 47.17 GB)
-STEP_TRAFFIC_SOURCE = 'profiles/r2e_pmc_fetch.md + profiles/r2e_pmc_write.md'
+STEP_TRAFFIC_BYTES = {'c2': 35.28e9}          # 26.23 GB fetched + 9.05 GB written (round 1: 36.99 + 10.18 = 47.17 GB)
+STEP_TRAFFIC_SOURCE = 'profiles/r2x_pmc_fetch.md + profiles/r2x_pmc_write.md'
 
 
 def main():
@@ -444,7 +444,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1> (dilated conv + cond GEMM + gate, fwd)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
                          'traffic': GATE_TRAFFIC_BYTES * rows_launch / (8 * 11000.0) if args.workload == 'c2' and T == 11000 else None,
-                         'traffic_source': 'profiles/r2e_pmc_fetch.md + r2e_pmc_write.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC in separate passes, gfx950 correction), scaled by rows per launch',
+                         'traffic_source': 'profiles/r2x_pmc_fetch.md + r2x_pmc_write.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC in separate passes, gfx950 correction), scaled by rows per launch',
                          'launches_timed': int(prof_n), 'avg_launch_ms': avg_s * 1e3 if prof_n else None,
                          'alg_flops_per_launch': flops_launch, 'alg_bytes_per_launch': float(rows_launch) * (2 * R + 2 * C + 2 * G),
                          'rows_per_launch': rows_launch,
