@@ -401,6 +401,19 @@ def main():
         sustained = {'what': '3 blocks x %d steps right after the timed region, same step function; median block' % args.sustained,
                      'ms_per_step_blocks': blocks, 'ms_per_step': med, 'value': world * B * T / (med * 1e-3), 'unit': 'audio_samples/s', 'smi': smi.summary()}
         _log('sustained: %s ms/step' % ', '.join('%.2f' % b for b in blocks))
+    # untimed extra: host time to ENQUEUE one step (the four C-ABI calls + the exchange, no device wait inside) next to the device time
+    # of that step: the margin by which host launch cost hides behind the GPU (what a hipGraph capture of the step could remove)
+    host_enqueue = None
+    if rank == 0 or world > 1:
+        hs, ds = [], []
+        for i in range(10):
+            torch.cuda.synchronize()
+            th = time.time(); one_step(args.warmup + args.steps + 5000 + i); te = time.time()
+            torch.cuda.synchronize(); td = time.time()
+            hs.append((te - th) * 1e3); ds.append((td - th) * 1e3)
+        host_enqueue = {'what': 'median over 10 untimed steps: host wall time of the enqueue calls / of the whole step, device idle at the start',
+                        'host_ms': float(np.median(hs)), 'step_ms': float(np.median(ds))}
+        _log('host enqueue %.2f ms of a %.2f ms step' % (host_enqueue['host_ms'], host_enqueue['step_ms']))
     # untimed extra: the same kernel with the GPU to itself (whole batch on one stream), for the kernel-quality view
     excl_ms, excl_n, excl_rows = 0.0, 0, 0
     if not args.no_exclusive:
@@ -459,7 +472,7 @@ def main():
                                         'alg_bytes_per_step': alg_bytes_per_sample(hp) * B * T,
                                         'traffic_per_step': STEP_TRAFFIC_BYTES.get(args.workload) if (B, T) == (8, 11000) else None,
                                         'traffic_source': STEP_TRAFFIC_SOURCE + ': sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE per step'},
-            'sustained': sustained,
+            'sustained': sustained, 'host_enqueue': host_enqueue,
             'grad_buckets': [list(b) for b in eng.grad_buckets()],
             'emulated_allreduce': ({'gbps': args.emulate_allreduce_gbps, 'bytes': int(eng.n_params) * 4,
                                     'serial_ms': int(eng.n_params) * 4 / (args.emulate_allreduce_gbps * 1e9) * 1e3,
