@@ -1178,7 +1178,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.ntiles = a.tiles_per_utt * a.B;
             a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * 8;
-            hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 3, 3, 2, 32, 3, EPI>), dim3(grid), dim3(384), 0, st, a);
+            hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 3, 3, 2, 32, 3, EPI, 1>), dim3(grid), dim3(384), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
             return WN_OK;
         }
@@ -1188,7 +1188,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.ntiles = a.tiles_per_utt * a.B;
             a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
-            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 2, 4, 32, 3, EPI>), dim3(grid), dim3(512), 0, st, a);
+            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 2, 4, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
             return WN_OK;
         }
