@@ -294,7 +294,15 @@ def main():
     ap.add_argument('--grad-buckets', type=int, default=None, help='override wn_config.grad_buckets (default: 3 under torch.distributed with > 1 rank, else 1)')
     ap.add_argument('--batch', type=int, default=None, help='override per-GPU batch (debug)')
     ap.add_argument('--time', type=int, default=None, help='override T (debug)')
+    ap.add_argument('--force-dist', action='store_true', help='take the multi-rank code path (process group, bucketed RCCL exchange, barriers) even with one rank: '
+                    'a single-GPU rehearsal of what torch.distributed.run --nproc-per-node N executes')
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the result): native libraries that write to fd 1 (RCCL's version banner at the first
+    # collective, rocm tools) are sent to stderr for the whole run; the JSON line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -304,10 +312,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=device)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        if world > 1:
+            dist.init_process_group(backend='nccl', device_id=device)
+        else:
+            dist.init_process_group(backend='nccl', device_id=device, rank=0, world_size=1)
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from wavenet_vocoder import _ext
@@ -318,10 +331,10 @@ def main():
     T = args.time or T
     hop = int(np.prod(hp.upsample_scales))
     T = T // hop * hop
-    eng = _ext.Engine(hp, B, T, grad_buckets=args.grad_buckets)
+    eng = _ext.Engine(hp, B, T, grad_buckets=args.grad_buckets if args.grad_buckets is not None else (3 if args.force_dist and world == 1 else None))
     flat = initialize_parameters(hp, eng.layout).to(device)
     assert flat.numel() == eng.n_params
-    if world > 1:
+    if use_dist:
         dist.broadcast(flat, 0)
     grads = torch.zeros_like(flat)
     m, v, ema = torch.zeros_like(flat), torch.zeros_like(flat), flat.clone()
@@ -354,7 +367,7 @@ def main():
         eng.train_bwd(grads)
         if emu_stream is not None:
             emulated_allreduce()
-        allreduce_mean_buckets_(eng, grads)          # per gradient bucket on a side stream, under the rest of the backward
+        allreduce_mean_buckets_(eng, grads, single_rank_ok=args.force_dist)          # per gradient bucket on a side stream, under the rest of the backward
         lr = _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, i, hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
         eng.optim_step(flat, grads, m, v, ema, lr, i)
 
@@ -363,7 +376,7 @@ def main():
         one_step(i)
         torch.cuda.synchronize(); _log('warm-up step %d done' % i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     eng.profile(True)
@@ -371,7 +384,7 @@ def main():
     for i in range(args.steps):
         one_step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.time() - t0
@@ -388,13 +401,13 @@ def main():
             step_i = args.warmup + args.steps
             for _ in range(3):
                 torch.cuda.synchronize()
-                if world > 1:
+                if use_dist:
                     dist.barrier()
                 tb = time.time()
                 for _i in range(args.sustained):
                     one_step(step_i); step_i += 1
                 torch.cuda.synchronize()
-                if world > 1:
+                if use_dist:
                     dist.barrier()
                 blocks.append((time.time() - tb) / args.sustained * 1e3)
         med = float(np.median(blocks))
@@ -427,7 +440,7 @@ def main():
         eng.profile(False)
         eng.set_batch_parts(0)
     final_loss = float(loss.item())
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -473,7 +486,7 @@ def main():
                                         'traffic_per_step': STEP_TRAFFIC_BYTES.get(args.workload) if (B, T) == (8, 11000) else None,
                                         'traffic_source': STEP_TRAFFIC_SOURCE + ': sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE per step'},
             'sustained': sustained, 'host_enqueue': host_enqueue,
-            'grad_buckets': [list(b) for b in eng.grad_buckets()],
+            'grad_buckets': [list(b) for b in eng.grad_buckets()], 'force_dist': bool(args.force_dist),
             'emulated_allreduce': ({'gbps': args.emulate_allreduce_gbps, 'bytes': int(eng.n_params) * 4,
                                     'serial_ms': int(eng.n_params) * 4 / (args.emulate_allreduce_gbps * 1e9) * 1e3,
                                     'what': 'single-GPU model: each gradient bucket occupies the communication stream for bytes / bandwidth once its event fired'}
@@ -496,8 +509,9 @@ def main():
                     res['cpu_baseline_synthesis'] = {'value': None, 'sample': 'failed: ' + str(e)[:200]}
         else:
             res['cpu_baseline'] = None
-        print(json.dumps(res))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + '\n').encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
