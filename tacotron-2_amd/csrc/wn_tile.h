@@ -1097,6 +1097,12 @@ static inline bool wn_tile_order_contiguous() {
     return v != 0;
 }
 
+// grids of at least this many workgroups de-phase their second-resident workgroups (A/B switch WN_STAGGER_MIN_GRID)
+static inline int wn_stagger_min_grid() {
+    static const int v = [] { const char* e = getenv("WN_STAGGER_MIN_GRID"); return e ? atoi(e) : 1024; }();
+    return v;
+}
+
 // Host-side launcher: picks the main loop and workgroup shape from M.
 template <int EPI>
 static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st) {
@@ -1129,7 +1135,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.ntiles = a.tiles_per_utt * a.B;
             a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
-            a.stagger = grid >= 1024 ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
+            a.stagger = grid >= wn_stagger_min_grid() ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
             if constexpr (EPI == EPI_GATE || EPI == EPI_DX) {
                 if (a.taps == 3) {       // K-interleaved taps (packs built with kil = 32).  PIPE 6 (wave halves half a chunk apart) measured +1.5 .. 2 % in
                                          // the harness without the tap offsets (profiles/r2_gemm_harness_b{4,8}.txt) but needs 128 VGPRs + 3 spills with them: not used
@@ -1158,7 +1164,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.ntiles = a.tiles_per_utt * a.B;
             a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
-            a.stagger = grid >= 1024 ? 8000 : 0;
+            a.stagger = grid >= wn_stagger_min_grid() ? 8000 : 0;
             if constexpr (EPI == EPI_GATE || EPI == EPI_DX) {
                 if (a.taps == 3) {
                     hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 2, 4, 2, 32, 3, EPI, 1, 3>), dim3(grid), dim3(512), 0, st, a);
