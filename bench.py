@@ -417,7 +417,7 @@ def main():
     # untimed extra: host time to ENQUEUE one step (the four C-ABI calls + the exchange, no device wait inside) next to the device time
     # of that step: the margin by which host launch cost hides behind the GPU (what a hipGraph capture of the step could remove)
     host_enqueue = None
-    if rank == 0 or world > 1:
+    if not args.no_exclusive:          # (--no-exclusive keeps a profiler's view to the timed configuration: no extra steps)
         hs, ds = [], []
         for i in range(10):
             torch.cuda.synchronize()
