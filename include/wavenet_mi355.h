@@ -231,6 +231,10 @@ int64_t wn_profile_rows_per_launch(const wn_ctx* ctx);
 /* A/B switch of the stream structure.  0: default (2 when the batch has >= 2 utterances), 1: whole batch on the caller's stream,
  * 2: two half-batches on two streams */
 int wn_set_batch_parts(wn_ctx* ctx, int32_t parts);
+/* the dropout keep-mask of `layer` for the step seed, evaluated ON THE HOST by the very functions the kernels inline
+ * (wn_layer_key / wn_drop_quad): out[i] = 1 if element first + i of the [rows][R] layer input is kept, else 0.  No context, no GPU:
+ * pins the numpy mirror the parity tests hand to the oracle. */
+int wn_test_dropout_mask(uint64_t seed, int32_t layer, float p, int64_t first, int64_t n, uint8_t* out);
 #endif /* WN_NO_TEST_HOOKS */
 
 #ifdef __cplusplus

@@ -452,3 +452,18 @@ extern "C" int wn_debug_copy(wn_ctx* c, const char* name, int32_t layer, float* 
     else WN_HIP(c, hipMemcpyAsync(out, f, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     return WN_OK;
 }
+
+// ---- test hook: host evaluation of the dropout mask (same inline functions as the kernels)
+extern "C" int wn_test_dropout_mask(uint64_t seed, int32_t layer, float p, int64_t first, int64_t n, uint8_t* out) {
+    if (!out || n < 0 || first < 0 || !(p >= 0.0f && p < 1.0f)) return WN_E_ARG;
+    uint32_t lo, hi; wn_layer_key(seed, layer, &lo, &hi);
+    const uint32_t thresh16 = (uint32_t)lrintf(p * 65536.0f);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t e = (uint32_t)(first + i);
+        const uint32_t w = wn_drop_word(lo, hi, e >> 1);
+        const uint32_t bits = (e & 1u) ? (w >> 16) : (w & 0xffffu);
+        out[i] = bits >= thresh16 ? 1 : 0;
+    }
+    return WN_OK;
+}
+

@@ -108,6 +108,7 @@ def load_library():
         'wn_set_global_condition': (ctypes.c_int, [vp, vp, i32, vp]),
         'wn_workspace_bytes': (i64, [vp]),
         'wn_dominant_kernel_name': (ctypes.c_char_p, []),
+        'wn_test_dropout_mask': (ctypes.c_int, [ctypes.c_uint64, i32, ctypes.c_float, i64, i64, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)            # AttributeError here == ABI symbol missing

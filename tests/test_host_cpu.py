@@ -558,3 +558,24 @@ def test_reconstruction_mel_front_end():
     m = melspectrogram(0.5 * np.sin(2 * np.pi * 1000.0 * t), hp)
     assert m.shape[0] == hp.num_mels and m.min() >= -hp.max_abs_value and m.max() <= hp.max_abs_value
     assert abs(int(m[:, 40].argmax()) - int(np.abs(centres - 1000.0).argmin())) <= 1
+
+
+def test_dropout_mask_mirror_matches_the_library_hash():
+    """tests/hip_util.py's numpy mirrors of the device dropout mask (what the parity tests hand to the oracle) against the
+    library's own hash evaluated on the host (wn_test_dropout_mask: the same inline wn_layer_key / wn_drop_quad the kernels use):
+    whole masks, row windows that start inside the tensor, several layers / seeds / rates."""
+    import ctypes
+    from wavenet_vocoder import _ext
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from hip_util import dropout_mask, dropout_mask_rows
+    lib = _ext.load_library()
+    for seed, layer, p, rows, R in ((1234, 0, 0.05, 40, 256), (5339 * 1000003 + 17, 23, 0.05, 24, 64), (7, 5, 0.5, 16, 128), (2 ** 40 + 3, 11, 0.2, 8, 512)):
+        got = np.zeros(rows * R, dtype=np.uint8)
+        assert lib.wn_test_dropout_mask(ctypes.c_uint64(seed), layer, ctypes.c_float(p), 0, rows * R, got.ctypes.data) == 0
+        ref = dropout_mask(seed, layer, rows, R, p)
+        assert np.array_equal(got.reshape(rows, R).astype(np.float32), ref)
+        win = dropout_mask_rows(seed, layer, 4, rows - 6, R, p)
+        assert np.array_equal(win, ref[4:rows - 2])
+        assert abs(float(ref.mean()) - (1.0 - p)) < 0.03
+    bad = np.zeros(4, dtype=np.uint8)
+    assert lib.wn_test_dropout_mask(ctypes.c_uint64(1), 0, ctypes.c_float(1.0), 0, 4, bad.ctypes.data) == -1      # WN_E_ARG
