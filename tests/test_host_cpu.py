@@ -579,3 +579,28 @@ def test_dropout_mask_mirror_matches_the_library_hash():
         assert abs(float(ref.mean()) - (1.0 - p)) < 0.03
     bad = np.zeros(4, dtype=np.uint8)
     assert lib.wn_test_dropout_mask(ctypes.c_uint64(1), 0, ctypes.c_float(1.0), 0, 4, bad.ctypes.data) == -1      # WN_E_ARG
+
+
+def test_projector_and_reconstruction_mel_outputs(tmp_path):
+    """Host-side logging outputs of the train driver that need no GPU: the speaker-embedding projector files (reference
+    train.py:26-39: config + tensor + metadata) and the "Local Condition vs Reconst. Mel-Spectrogram" plot (train.py:110-116)."""
+    import hparams as H
+    from wavenet_vocoder.train import add_embedding_stats, _plot_reconstruction_mel
+    hp = H._build()
+    tb = str(tmp_path)
+    table = torch.arange(15, dtype=torch.float32).reshape(5, 3) * 0.25
+    add_embedding_stats(tb, ['WaveNet_model/inference/gc_embedding'], ['../metas/SpeakerEmbeddings.tsv'], [table], 42)
+    cfg = open(os.path.join(tb, 'projector_config.pbtxt')).read()
+    assert 'tensor_name: "WaveNet_model/inference/gc_embedding"' in cfg and 'metadata_path: "../metas/SpeakerEmbeddings.tsv"' in cfg
+    tsv = [l.split('"')[1] for l in cfg.split('\n') if 'tensor_path' in l][0]
+    assert tsv.endswith('-42.tsv')
+    np.testing.assert_allclose(np.loadtxt(os.path.join(tb, tsv), delimiter='\t'), table.numpy())
+    # mel plot: one second of a tone against a random conditioning of the same length, [cin, Tc] and [Tc, cin] orientations
+    t = np.arange(hp.sample_rate) / hp.sample_rate
+    wav = 0.4 * np.sin(2 * np.pi * 300.0 * t)
+    frames = 1 + len(wav) // hp.hop_size
+    cond = np.random.RandomState(0).uniform(0, 1, size=(hp.cin_channels, frames)).astype(np.float32)
+    for k, c in enumerate((cond, cond.T, torch.from_numpy(cond))):
+        path = os.path.join(tb, 'mel-%d.png' % k)
+        _plot_reconstruction_mel(wav, c, path, hp, 'title')
+        assert os.path.getsize(path) > 10000
