@@ -604,3 +604,18 @@ def test_projector_and_reconstruction_mel_outputs(tmp_path):
         path = os.path.join(tb, 'mel-%d.png' % k)
         _plot_reconstruction_mel(wav, c, path, hp, 'title')
         assert os.path.getsize(path) > 10000
+
+
+def test_bench_algorithmic_work_matches_the_scope_table():
+    """bench.py's per-sample work (the numerators of its roofline fields) against the figures SURVEY.md 8(d) states: MACs per sample
+    (C2 13 639 424, default hparams 3 047 808, C5 65 635 840) and algorithmic HBM bytes per sample in bf16 (232 890 / 101 778 /
+    567 378); train FLOPs = 6 x MAC (81.84 MFLOP at C2)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    want = {'c2': (13639424, 232890), 'default_hparams': (3047808, 101778), 'c5_stress': (65635840, 567378)}
+    for w, (mac, nbytes) in want.items():
+        hp, B, T = bench.build_hparams(w)
+        assert bench.mac_per_sample(hp) == mac, (w, bench.mac_per_sample(hp))
+        assert bench.alg_bytes_per_sample(hp) == nbytes, (w, bench.alg_bytes_per_sample(hp))
+    hp, B, T = bench.build_hparams('c2')
+    assert (B, T) == (8, 11000) and abs(6.0 * bench.mac_per_sample(hp) / 1e6 - 81.84) < 0.01
