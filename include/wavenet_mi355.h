@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 3
+#define WN_ABI_VERSION 4
 
 enum wn_status {
     WN_OK = 0,
@@ -196,6 +196,11 @@ int wn_fill_noise(wn_ctx* ctx, float* noise, int32_t B, int32_t T, uint64_t seed
  * 2 persistent pipeline. */
 int wn_synth_check(wn_ctx* ctx);
 int wn_synth_last_path(const wn_ctx* ctx);
+/* 1 if wn_synthesize(steps_per_graph <= 0) would run B streams of this model on the persistent pipeline (all of a CU's weights must
+ * fit its 160 KiB of LDS: one CU per 32 gate pairs, <= 8 CUs per layer, R, S <= 384, B <= 16), 0 if it would take the
+ * launch-per-layer hipGraph path.  Host helper: callers that split a large batch into groups of 8 streams only do so for the
+ * pipeline (the graph path's time per step is nearly independent of B up to 32). */
+int wn_synth_pipe_eligible(const wn_ctx* ctx, int32_t B);
 
 /* Stand-alone samplers on [B,O,T] parameters (train-time log path, wavenet.py:302-325). */
 int wn_sample(wn_ctx* ctx, const float* y_hat, int32_t B, int32_t T, const float* noise /*[T,B,nps]*/,

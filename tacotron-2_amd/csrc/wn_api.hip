@@ -148,6 +148,7 @@ static int alloc_workspace(wn_ctx* c) {
         sz((size_t)c->uppart_floats * 4);
     }
     sz(NT * 4); sz(NT * c->C * 4);          // XIN, CIN
+    sz((size_t)2 * 1024 * 2 * 1024 * 4);    // wn_colsum2 partials (2 regions)
     sz(256);                               // scalars
     sz(256);                               // zero page
     c->ws_bytes = total;
@@ -171,6 +172,7 @@ static int alloc_workspace(wn_ctx* c) {
     c->DCUP[0] = (float*)bump(p, NT * c->C * 4); c->DCUP[1] = (float*)bump(p, NT * c->C * 4);
     c->UPPART = (float*)bump(p, (size_t)c->uppart_floats * 4);
     c->XIN = (void*)bump(p, NT * 4); c->CIN = (float*)bump(p, NT * c->C * 4);
+    c->cs_part = (float*)bump(p, (size_t)2 * 1024 * 2 * 1024 * 4);
     c->scal = (float*)bump(p, 256);
     c->zero_page = (bf16_t*)bump(p, 256);
     if (hipMemset(c->zero_page, 0, 256) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
@@ -263,6 +265,9 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->skip_bias_total) hipFree(c->skip_bias_total);
     if (c->tensor_offsets_dev) hipFree(c->tensor_offsets_dev);
     if (c->norm2_dev) hipFree(c->norm2_dev);
+    if (c->norm_spans_dev) hipFree(c->norm_spans_dev);
+    if (c->norm_first_dev) hipFree(c->norm_first_dev);
+    if (c->norm_part_dev) hipFree(c->norm_part_dev);
     if (c->params_dev) hipFree(c->params_dev);
     if (c->st2) { (void)hipStreamSynchronize(c->st2); hipStreamDestroy(c->st2); }      // nothing of ours may still be running on it
     if (c->st3) { (void)hipStreamSynchronize(c->st3); hipStreamDestroy(c->st3); }
@@ -397,6 +402,12 @@ extern "C" int wn_fill_noise(wn_ctx* c, float* noise, int32_t B, int32_t T, uint
 }
 extern "C" int wn_synth_check(wn_ctx* c) { if (!c) return WN_E_ARG; return wn_pipe_check(c, true); }
 extern "C" int wn_synth_last_path(const wn_ctx* c) { return c ? c->synth_path : WN_E_ARG; }
+extern "C" int wn_synth_pipe_eligible(const wn_ctx* c, int32_t B) {
+    if (!c || B <= 0) return WN_E_ARG;
+    const char* m = getenv("WN_SYNTH_MODE");
+    if (m && strcmp(m, "graph") == 0) return 0;
+    return wn_pipe_eligible(c, B) ? 1 : 0;
+}
 
 int wn_noise_reserve(wn_ctx* c, int B, int T) {
     const size_t need = (size_t)B * T * wn_noise_per_step(c) * 4;

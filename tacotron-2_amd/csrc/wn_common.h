@@ -135,12 +135,14 @@ struct wn_ctx {
     int gB = 0; bool have_g = false;
     int32_t* tensor_offsets_dev = nullptr; // [ntensors+1] for the optimiser
     float* norm2_dev = nullptr;           // [ntensors]
+    int32_t* norm_spans_dev = nullptr; int32_t* norm_first_dev = nullptr; float* norm_part_dev = nullptr; int norm_nspans = 0;   // atomic-free clip norms
     // workspace
     char* ws = nullptr; size_t ws_bytes = 0;
     int maxB, maxT; int64_t NT;
     bf16_t* XD;                           // [L][NT][R] dropout-applied layer inputs (aliases X when dropout == 0)
     bf16_t *cbt, *X, *TS, *U, *R1, *H2, *DY, *DPRE1, *DSKIP, *DZ, *GX0, *GX1;
     float *YHAT, *DC, *CUP[WN_MAX_UPSAMPLE + 1], *DCUP[2];
+    float* cs_part = nullptr;             // partial sums of wn_colsum2 (two regions of WN_CS_MAXBLK x 2 x 1024 floats)
     float* UPPART = nullptr; int64_t uppart_floats = 0;   // partial sums of the upsample-kernel gradients (two-stage, no atomics)
     void* XIN; float* CIN;                // ctx-owned copies of the step's x and c (pointers are borrowed per call)
     float* wg_partial = nullptr; size_t wg_partial_bytes = 0;   // split-K partial tiles of the grouped wgrad (wn_wgrad.h)
@@ -163,7 +165,7 @@ struct wn_ctx {
 #define WN_MAX_BUCKETS 8
     hipStream_t st3 = nullptr; hipEvent_t ev_chain[WN_MAX_PARTS][WN_MAX_BUCKETS] = {}; hipEvent_t ev_bucket[WN_MAX_BUCKETS + 2] = {}; hipEvent_t ev_w0 = nullptr;
     hipEvent_t ev_head[WN_MAX_PARTS] = {};   // d pre1 of a batch part exists (the head weight gradients may start under the chain)
-    int nbuckets = 0, nbuckets_early = 0; int bucket_lo[WN_MAX_BUCKETS + 2] = {}, bucket_hi[WN_MAX_BUCKETS + 2] = {};
+    int nbuckets = 0, nbuckets_early = 0, nearly_live = 0; int bucket_lo[WN_MAX_BUCKETS + 2] = {}, bucket_hi[WN_MAX_BUCKETS + 2] = {};
     int64_t bucket_off[WN_MAX_BUCKETS + 2] = {}, bucket_cnt[WN_MAX_BUCKETS + 2] = {}; bool have_bwd = false;
     bool inference = false;               // cfg.inference_only: no training workspace, synthesis state pre-sized at wn_create
     float* noise_buf = nullptr; size_t noise_bytes = 0;      // device-drawn sampling noise [T][B][nps] (wn_synthesize with noise == NULL)
@@ -207,6 +209,7 @@ int wn_weightnorm_apply(wn_ctx* ctx, const float* raw_params, hipStream_t st);  
 int wn_weightnorm_grad(wn_ctx* ctx, float* raw_grads, hipStream_t st);             // deff (effective grads) -> raw grads
 int wn_gbias_fwd(wn_ctx* ctx, int B, hipStream_t st);                 // global-conditioning bias table of this batch
 int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st);           // d W_g, d b_g, d embedding
+int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const float* xw, int64_t rows, float* out_b, float* out_w, int slot, hipStream_t st);
 size_t wn_wgrad_partial_need(wn_ctx* ctx);
 void wn_plan_buckets(wn_ctx* ctx);
 int wn_sample_impl(wn_ctx* ctx, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st);

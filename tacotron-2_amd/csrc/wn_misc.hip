@@ -4,6 +4,7 @@
 #include "wn_common.h"
 #include "wn_mulaw_tables.h"
 #include <math.h>
+#include <algorithm>
 
 // =================================================================================== weight packing
 // Fragment order of v_mfma_f32_32x32x16_bf16's A operand:  out[((mtile*KS + ks)*64 + lane)*8 + j]
@@ -150,6 +151,22 @@ int wn_build_packs(wn_ctx* c) {
     WN_HIP(c, hipMalloc((void**)&c->tensor_offsets_dev, (nt + 1) * 4));
     WN_HIP(c, hipMemcpy(c->tensor_offsets_dev, offs.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
     WN_HIP(c, hipMalloc((void**)&c->norm2_dev, nt * 4));
+    // span table of the atomic-free clip norms (wn_norm2_span_kernel): spans of <= WN_NORM_SPAN floats that never cross a tensor;
+    // tensor i owns the spans [first[i], first[i + 1])
+    {
+        std::vector<int32_t> sp; std::vector<int32_t> first(nt + 1);
+        for (int i = 0; i < nt; ++i) {
+            first[i] = (int32_t)(sp.size() / 2);
+            for (int64_t o = offs[i]; o < offs[i + 1]; o += 4096) { sp.push_back((int32_t)o); sp.push_back((int32_t)std::min<int64_t>(offs[i + 1], o + 4096)); }
+        }
+        first[nt] = (int32_t)(sp.size() / 2);
+        c->norm_nspans = first[nt];
+        WN_HIP(c, hipMalloc((void**)&c->norm_spans_dev, sp.size() * 4 + 8));
+        WN_HIP(c, hipMemcpy(c->norm_spans_dev, sp.data(), sp.size() * 4, hipMemcpyHostToDevice));
+        WN_HIP(c, hipMalloc((void**)&c->norm_first_dev, (nt + 1) * 4));
+        WN_HIP(c, hipMemcpy(c->norm_first_dev, first.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
+        WN_HIP(c, hipMalloc((void**)&c->norm_part_dev, (size_t)c->norm_nspans * 4 + 8));
+    }
     return WN_OK;
 }
 
@@ -232,21 +249,81 @@ __global__ void wn_first_conv_fwd(const void* __restrict__ x, const float* __res
 }
 
 // dW[cin][r] = sum_t x[cin][t] g0[t][r];  db[r] = sum_t g0[t][r]
-__global__ void wn_first_conv_bwd(const void* __restrict__ x, const bf16_t* __restrict__ g0, float* __restrict__ dW,
-                                  float* __restrict__ db, int64_t rows, int R, int is_ids, int rows_per_block) {
+// One-hot input (mu-law-quantize): a row scatter by class id -- float atomics into the [Q][R] kernel gradient (C1-sized models only).
+__global__ void wn_first_conv_bwd_ids(const int32_t* __restrict__ ids, const bf16_t* __restrict__ g0, float* __restrict__ dW,
+                                      int64_t rows, int R, int rows_per_block) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(rows, r0 + rows_per_block);
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
-        float sw = 0.0f, sb = 0.0f;
-        for (int64_t row = r0; row < r1; ++row) {
-            const float g = bf2f(g0[row * R + r]);
-            sb += g;
-            if (is_ids) unsafeAtomicAdd(&dW[(int64_t)((const int32_t*)x)[row] * R + r], g);
-            else sw += ((const float*)x)[row] * g;
+    for (int r = threadIdx.x; r < R; r += blockDim.x)
+        for (int64_t row = r0; row < r1; ++row) unsafeAtomicAdd(&dW[(int64_t)ids[row] * R + r], bf2f(g0[row * R + r]));
+}
+// Column sums of a bf16 [rows][ld] matrix, optionally also weighted by a per-row scalar: sum_t M[t][c] and sum_t x[t] M[t][c].
+// Two stages in a fixed order, no atomics (bit-reproducible): part[blk][0][c], part[blk][1][c], then wn_colsum2_reduce.
+// (Round 2's input-conv gradient walked 128 rows per block one 2-byte load at a time and finished with float atomics: 77 us alone,
+// 0.5 ms beside the weight-gradient kernels.  This one reads 16 B per lane: scalar-input d W / d b and the head-bias column sums.)
+#define WN_CS_MAXBLK 1024
+__global__ __launch_bounds__(256) void wn_colsum2_kernel(const bf16_t* __restrict__ M, int ld, int ncols, const float* __restrict__ xw,
+                                                         int64_t rows, int rows_per_block, float* __restrict__ part) {
+    __shared__ float red[2][2048];                   // [b | w][row lane][ncols]   (row lanes * ncols <= 2048)
+    const int c8n = ncols >> 3, rgn = 256 / c8n;
+    const int tid = threadIdx.x, c8 = tid % c8n, rg = tid / c8n;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float sb[8], sw[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sb[e] = 0.0f; sw[e] = 0.0f; }
+    if (rg < rgn) {
+        for (int64_t row = r0 + rg; row < r1; row += rgn) {
+            const uint4 v = *reinterpret_cast<const uint4*>(M + row * ld + c8 * 8);
+            const float f[8] = {bf2f((bf16_t)(v.x & 0xffff)), bf2f((bf16_t)(v.x >> 16)), bf2f((bf16_t)(v.y & 0xffff)), bf2f((bf16_t)(v.y >> 16)),
+                                bf2f((bf16_t)(v.z & 0xffff)), bf2f((bf16_t)(v.z >> 16)), bf2f((bf16_t)(v.w & 0xffff)), bf2f((bf16_t)(v.w >> 16))};
+            const float x = xw ? xw[row] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sb[e] += f[e]; sw[e] = __builtin_fmaf(x, f[e], sw[e]); }
         }
-        unsafeAtomicAdd(&db[r], sb);
-        if (!is_ids) unsafeAtomicAdd(&dW[r], sw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][rg * ncols + c8 * 8 + e] = sb[e]; red[1][rg * ncols + c8 * 8 + e] = sw[e]; }
     }
+    __syncthreads();
+    for (int i = tid; i < 2 * ncols; i += 256) {
+        const int w = i / ncols, cix = i - w * ncols;
+        if (w == 1 && !xw) continue;
+        float s = 0.0f;
+        for (int g = 0; g < rgn; ++g) s += red[w][g * ncols + cix];
+        part[((int64_t)blockIdx.x * 2 + w) * ncols + cix] = s;
+    }
+}
+// out_b[c] = sum_blk part[blk][0][c] (c < nvalid), out_w[c] = sum_blk part[blk][1][c]; block = 32 columns x 8 block lanes, fixed order
+__global__ __launch_bounds__(256) void wn_colsum2_reduce(const float* __restrict__ part, int nblk, int ncols, int nvalid,
+                                                         float* __restrict__ out_b, float* __restrict__ out_w) {
+    __shared__ float red[8][64];
+    const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const int cix = blockIdx.x * 32 + cl;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (cix < ncols)
+        for (int b = bl; b < nblk; b += 8) {
+            if (out_b) s0 += part[((int64_t)b * 2) * ncols + cix];
+            if (out_w) s1 += part[((int64_t)b * 2 + 1) * ncols + cix];
+        }
+    red[bl][cl] = s0; red[bl][32 + cl] = s1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int w = threadIdx.x >> 5, cc = blockIdx.x * 32 + (threadIdx.x & 31);
+        float s = 0.0f;
+        for (int g = 0; g < 8; ++g) s += red[g][threadIdx.x];
+        if (cc < nvalid) { if (w == 0 && out_b) out_b[cc] = s; if (w == 1 && out_w) out_w[cc] = s; }
+    }
+}
+// column sums (+ x-weighted column sums) of M [rows][ld] into out_b / out_w (either may be null); `slot` picks one of the two
+// ctx-owned partial regions (launches on different streams may overlap)
+int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const float* xw, int64_t rows, float* out_b, float* out_w, int slot, hipStream_t st) {
+    if (ncols % 8 || ncols > 1024 || 256 / (ncols / 8) * ncols > 2048) WN_FAIL(c, WN_E_SHAPE, "wn_colsum2: %d columns", ncols);
+    const int rpb = (int)std::max<int64_t>(64, (rows + WN_CS_MAXBLK - 1) / WN_CS_MAXBLK);
+    const int nblk = cdiv(rows, rpb);
+    float* part = c->cs_part + (size_t)slot * WN_CS_MAXBLK * 2 * 1024;
+    hipLaunchKernelGGL(wn_colsum2_kernel, dim3(nblk), dim3(256), 0, st, M, ld, ncols, out_w ? xw : nullptr, rows, rpb, part);
+    hipLaunchKernelGGL(wn_colsum2_reduce, dim3(cdiv(ncols, 32)), dim3(256), 0, st, part, nblk, ncols, nvalid, out_b, out_w);
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
 }
 
 int wn_first_conv(wn_ctx* c, hipStream_t st) {
@@ -263,11 +340,14 @@ int wn_first_conv(wn_ctx* c, hipStream_t st) {
 int wn_first_conv_grad(wn_ctx* c, const bf16_t* g0, float* grads, hipStream_t st) {
     const int64_t rows = (int64_t)c->fB * c->fT;
     const int is_ids = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE;
-    const int rpb = 128;
-    hipLaunchKernelGGL(wn_first_conv_bwd, dim3(cdiv(rows, rpb)), dim3(256), 0, st, c->fx, g0, grads + c->first.dil_k,
-                       grads + c->first.dil_b, rows, c->R, is_ids, rpb);
-    WN_LAUNCH_CHECK(c);
-    return WN_OK;
+    if (is_ids) {
+        const int rpb = 128;
+        hipLaunchKernelGGL(wn_first_conv_bwd_ids, dim3(cdiv(rows, rpb)), dim3(256), 0, st, (const int32_t*)c->fx, g0, grads + c->first.dil_k, rows, c->R, rpb);
+        WN_LAUNCH_CHECK(c);
+    }
+    // d b = column sums of d h_0; scalar input: d W = the x-weighted column sums, from the same pass
+    return wn_colsum2(c, g0, c->R, c->R, c->R, is_ids ? nullptr : (const float*)c->fx, rows, grads + c->first.dil_b,
+                      is_ids ? nullptr : grads + c->first.dil_k, 0, st);
 }
 
 // =================================================================================== upsample net
@@ -1115,24 +1195,32 @@ __device__ __forceinline__ int find_tensor(const int32_t* __restrict__ offs, int
     return lo;
 }
 #define WN_NORM_SPAN 4096      // floats per wave
-__global__ __launch_bounds__(256) void wn_norm2_kernel(const float* __restrict__ g, const int32_t* __restrict__ offs, int nt, int64_t n, float* __restrict__ norm2) {
-    // every wave walks a contiguous span; the running sum is flushed (wave reduction + ONE atomic) only when the span crosses
-    // into another tensor, so the ~200 norm accumulators see a few thousand atomics instead of one per wave-load
+// Per-variable squared norms WITHOUT atomics: the replicas of a data-parallel job apply clip_by_norm to the SAME all-reduced gradient
+// and must come out bit-identical, which a float-atomic accumulation order does not give (round 2 flushed one atomic per wave and
+// tensor: whenever a norm exceeded the clip threshold the scale differed by ulps between ranks and nothing re-synchronised them).
+// Stage 1: one wave per span of the host-built table (never crosses a tensor), fixed lane-strided order + butterfly -> part[span];
+// stage 2: one wave per tensor sums its spans in a fixed order.
+__global__ __launch_bounds__(256) void wn_norm2_span_kernel(const float* __restrict__ g, const int32_t* __restrict__ spans, int nspans, float* __restrict__ part) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t i0 = wave * WN_NORM_SPAN, i1 = i0 + WN_NORM_SPAN < n ? i0 + WN_NORM_SPAN : n;
-    if (i0 >= n) return;
-    int id = find_tensor(offs, nt, i0);
-    int64_t i = i0;
-    while (i < i1) {
-        const int64_t tend = (id + 1 < nt) ? (int64_t)offs[id + 1] : n;
-        const int64_t e = tend < i1 ? tend : i1;
-        float s = 0.0f;
-        for (int64_t j = i + lane; j < e; j += 64) { const float v = g[j]; s += v * v; }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if (lane == 0) unsafeAtomicAdd(&norm2[id], s);
-        i = e; ++id;
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= nspans) return;
+    const int i0 = spans[2 * w], i1 = spans[2 * w + 1];
+    float s = 0.0f;          // (tensor offsets are multiples of 8 floats: every span starts 16-B aligned)
+    for (int j = i0 + lane * 4; j < i1; j += 256) {
+        if (j + 3 < i1) { const float4 v = *reinterpret_cast<const float4*>(g + j); s += v.x * v.x; s += v.y * v.y; s += v.z * v.z; s += v.w * v.w; }
+        else for (int k = j; k < i1; ++k) s += g[k] * g[k];
     }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) part[w] = s;
+}
+__global__ __launch_bounds__(256) void wn_norm2_tensor_kernel(const float* __restrict__ part, const int32_t* __restrict__ first, int nt, float* __restrict__ norm2) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= nt) return;
+    float s = 0.0f;
+    for (int i = first[t] + lane; i < first[t + 1]; i += 64) s += part[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) norm2[t] = s;
 }
 __global__ void wn_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                float* __restrict__ ema, const int32_t* __restrict__ offs, int nt, int64_t n,
@@ -1175,8 +1263,8 @@ int wn_optim_impl(wn_ctx* c, float* p, const float* g, float* m, float* v, float
     const int nt = (int)c->raw_tensors.size();
     const int64_t n = c->n_raw;
     if (h.clip_gradients) {
-        WN_HIP(c, hipMemsetAsync(c->norm2_dev, 0, nt * 4, st));
-        hipLaunchKernelGGL(wn_norm2_kernel, dim3(cdiv(cdiv(n, WN_NORM_SPAN), 4)), dim3(256), 0, st, g, c->tensor_offsets_dev, nt, n, c->norm2_dev);
+        hipLaunchKernelGGL(wn_norm2_span_kernel, dim3(cdiv(c->norm_nspans, 4)), dim3(256), 0, st, g, c->norm_spans_dev, c->norm_nspans, c->norm_part_dev);
+        hipLaunchKernelGGL(wn_norm2_tensor_kernel, dim3(cdiv(nt, 4)), dim3(256), 0, st, c->norm_part_dev, c->norm_first_dev, nt, c->norm2_dev);
     }
     const double t = (double)(step + 1);
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)h.adam_beta2, t)) / (1.0 - pow((double)h.adam_beta1, t)));

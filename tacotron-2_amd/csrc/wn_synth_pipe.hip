@@ -47,6 +47,7 @@ struct PipeArgs {
     const float* noise; const void* test_inputs; void* out_samples; float* out_raw;
     const float* win_global; const float* bin_global;
     int32_t* abort_flag;
+    const float* gbias;              // global conditioning: [L][B][G] gate bias per stream (b_dil + b_cin + W_g^T g_s + b_g), else null
     unsigned long long* trace; int32_t trace_t0, trace_n;     // optional timestamps (WN_PIPE_TRACE=1): [trace_n][2*(L+2)] of s_memrealtime
     int64_t ring_off[32]; int64_t cin_b_off[32]; int32_t ring_mask[32]; int32_t dil[32];
 };
@@ -192,6 +193,10 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         // z_past for (s, tn): taps x(tn-2d), x(tn-d) from this CU's ring (zero before the utterance), conditioning c(s, tn)
         auto precompute = [&](int s, int tn, bool tap1_is_cur) {
             bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
+            // global conditioning (wavenet.py:766-777, modules.py:503-508): g is constant over time, so W_g^T g + b_g is a per-STREAM gate
+            // bias; it replaces the layer's own bias vector here, off the critical path (the load flies under the matvec below)
+            float gb = 0.0f;
+            if (a.gbias && tid < 64) gb = a.gbias[((int64_t)l * B + s) * a.G + (tid < 32 ? 32 * j + tid : a.GH + 32 * j + (tid - 32))];
             for (int i = tid; i < KP; i += PIPE_THREADS) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 const int k = i * 8;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 zpart[wave * 64 + lane] = mv_rows(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
             }
             lds_barrier();
-            if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zb[tid];
+            if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + (a.gbias ? gb : zb[tid]);
             lds_barrier();
         };
         for (int s = 0; s < B; ++s) precompute(s, 0, false);
@@ -572,7 +577,7 @@ struct Pipe {
     SliceJob* jobs_dev = nullptr; int* job_block0_dev = nullptr; int njobs = 0, nblocks = 0;
     u32x4* XM = nullptr; u32x4* SM = nullptr; u32x4* XML = nullptr; u32x4* SML = nullptr; size_t xm_bytes = 0, sm_bytes = 0;
     bf16_t* ring = nullptr; size_t ring_bytes = 0; int ring_B = 0;
-    int32_t* abort_dev = nullptr;
+    int32_t* abort_dev = nullptr;       // [0] flag of the running launch, [1] sticky OR of every run since the last wn_pipe_check, +256 B: XCC table
     int32_t* abort_host = nullptr;      // pinned: the abort flag of the last run lands here asynchronously (read by wn_pipe_check)
     bool pending = false;               // a run has been enqueued whose flag has not been inspected yet
     int layer_lds = 0, head_lds = 0;
@@ -594,7 +599,6 @@ void wn_pipe_free(wn_ctx* c) {
 // can this model run on the persistent pipeline?  (one CU per 32 gate pairs, all of a CU's weights in 160 KiB of LDS)
 bool wn_pipe_eligible(const wn_ctx* c, int B) {
     const int R = c->R, S = c->S, C = c->C, GH = c->GH, L = c->L;
-    if (c->gin > 0) return false;                       // per-stream gate bias (global conditioning): the graph path handles it
     if (GH % 32 || R % 8 || S % 8 || C % 8 || R > 512) return false;
     const int P = GH / 32;
     if (P > 8 || L > 32 || B > 16 || R > 384 || S > 384 || c->OP > 256) return false;
@@ -674,6 +678,7 @@ static int pipe_build(wn_ctx* c, Pipe* p) {
     WN_HIP(c, hipMalloc((void**)&p->job_block0_dev, b0.size() * sizeof(int)));
     WN_HIP(c, hipMemcpy(p->job_block0_dev, b0.data(), b0.size() * sizeof(int), hipMemcpyHostToDevice));
     WN_HIP(c, hipMalloc((void**)&p->abort_dev, 256 + 4096));       // [0]: abort flag; +256: XCC table (grid <= 1024 entries)
+    WN_HIP(c, hipMemset(p->abort_dev, 0, 256 + 4096));
     WN_HIP(c, hipHostMalloc((void**)&p->abort_host, 64, hipHostMallocDefault));
     *p->abort_host = 0;
     WN_HIP(c, hipStreamCreateWithFlags(&p->priv, hipStreamNonBlocking));
@@ -705,6 +710,10 @@ __global__ void wn_pipe_fixup_kernel(const float* __restrict__ params, char* __r
     }
 }
 
+// the run's flag is folded into the sticky word that travels to the host: back-to-back runs (batches of more than 8 streams go
+// through the pipeline in groups) each clear and overwrite the per-run flag, so a timeout in any group but the last would be lost
+__global__ void wn_pipe_sticky_kernel(int32_t* f) { if (threadIdx.x == 0 && f[0] != 0 && f[1] == 0) f[1] = f[0]; }
+
 // Size mailboxes and ring queues for B streams (they do not depend on T; the conditioning lives in the ctx workspace).  Called from
 // wn_create on inference-only contexts, so that wn_synthesize never allocates there; training contexts get here on first use.
 int wn_pipe_reserve(wn_ctx* c, int B, int T) {
@@ -735,7 +744,11 @@ int wn_pipe_check(wn_ctx* c, bool wait) {
     else if (hipEventQuery(p->ev1) != hipSuccess) return WN_OK;     // still running: nothing to report yet
     p->pending = false;
     const int32_t flag = *p->abort_host;
-    if (flag != 0) WN_FAIL(c, WN_E_HIP, "synthesis pipeline timed out waiting for a hand-off (code %d): are all %d workgroups resident?", flag, p->grid);
+    if (flag != 0) {
+        *p->abort_host = 0;
+        (void)hipMemsetAsync(p->abort_dev + 1, 0, 4, p->priv);      // reported: the next runs start clean (ordered before them on the pipeline's stream)
+        WN_FAIL(c, WN_E_HIP, "synthesis pipeline timed out waiting for a hand-off (code %d): are all %d workgroups resident?", flag, p->grid);
+    }
     return WN_OK;
 }
 
@@ -775,11 +788,13 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     WN_HIP(c, hipMemsetAsync(p->SM, 0, sm, st));
     WN_HIP(c, hipMemsetAsync(p->XML, 0, xm, st));
     WN_HIP(c, hipMemsetAsync(p->SML, 0, sm, st));
-    WN_HIP(c, hipMemsetAsync(p->abort_dev, 0, 256 + 4096, st));
+    WN_HIP(c, hipMemsetAsync(p->abort_dev, 0, 4, st));                     // the per-run flag (the sticky word [1] survives)
+    WN_HIP(c, hipMemsetAsync(p->abort_dev + 64, 0, 4096, st));            // XCC table
     a.XM = p->XM; a.SM = p->SM; a.XML = p->XML; a.SML = p->SML; a.ring = p->ring; a.abort_flag = p->abort_dev; a.xcc_tab = p->abort_dev + 64;
     // ---- conditioning for the whole utterance (wavenet.py:781-803): cbt [B*T][C] bf16
     c->fB = B; c->fT = T; c->fTc = Tc;
     if ((rc = wn_upsample_fwd(c, nullptr, cin, B, Tc, st))) return rc;
+    if (c->gin > 0) { if ((rc = wn_gbias_fwd(c, B, st))) return rc; a.gbias = c->gbias; }      // wavenet.py:766-777
     a.cbt = c->cbt; a.noise = noise; a.test_inputs = test_inputs; a.out_samples = out_samples; a.out_raw = out_raw;
     a.win_global = c->params_dev + c->first.dil_k; a.bin_global = c->params_dev + c->first.dil_b;
     unsigned long long* trace_dev = nullptr; const int trace_n = 32;
@@ -793,7 +808,8 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     hipLaunchKernelGGL(wn_synth_pipe_kernel, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     WN_LAUNCH_CHECK(c);
     // the abort flag travels to pinned host memory behind the kernel; nobody waits for it here (wn_pipe_check / the next call read it)
-    WN_HIP(c, hipMemcpyAsync(p->abort_host, p->abort_dev, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(wn_pipe_sticky_kernel, dim3(1), dim3(64), 0, st, p->abort_dev);
+    WN_HIP(c, hipMemcpyAsync(p->abort_host, p->abort_dev + 1, 4, hipMemcpyDeviceToHost, st));
     p->pending = true; c->synth_path = 2;
     if (trace_dev) {      // per-stage latencies in units of the 100 MHz real-time counter (10 ns)   [diagnostic mode: synchronises]
         WN_HIP(c, hipStreamSynchronize(st));

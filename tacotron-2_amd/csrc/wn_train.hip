@@ -139,6 +139,39 @@ static void wgrad_skipout_args(wn_ctx* c, WgBatchArgs& w, int l0, int ng, int B,
         q.out_off_hi = c->lay[l].out_k; q.bias_off_hi = c->lbias ? c->lay[l].out_b : -1; q.scale_hi = 1.0f;
     }
 }
+// Head weight gradients through the same LDS-DMA kernel (round 2 ran them on the round-1 atomics kernel wn_wgrad_kernel: 2 x 140 us
+// alone, MFMA busy 3.6 %).  d final_convolution_1 [S][S] = R1^T d pre1 (+ bias = column sums of d pre1): both 128-channel halves of a
+// 256-channel block of R1 share the staged d pre1 tile.  d final_convolution_2 [S][O] = H2^T dY has only O (30 / 2 / 256) B columns,
+// so the roles are swapped -- A = dY (one 128-wide tile, ldDY valid columns), B = H2 -- and the reduce writes the transpose; its bias
+// (column sums of dY) comes from wn_colsum2.  Few, long time slabs: these launches run beside the chain, not alone.
+static void wgrad_head1_args(wn_ctx* c, WgBatchArgs& w, int B, int T) {
+    const int S = c->S;
+    wgrad_common(c, w, 1, B, T);
+    w.nseg = 1; w.seg_base[0] = c->R1; w.seg_gstride[0] = 0; w.seg_ld[0] = S; w.seg_nk[0] = S;
+    w.Bm = c->DPRE1; w.b_gstride = 0; w.ldb = S; w.N = S; w.ldw = S;
+    if (wgrad_multi() && S % 256 == 0) {
+        w.na = 2; w.hblocks = S / 256; w.a_colstep = 256;
+        for (int x = 0; x < 2; ++x) { w.a_seg[x] = 0; w.a_col0[x] = 128 * x; w.a_mrow[x] = 128 * x; }
+    }
+    w.spu_cap = 4;
+    WgGroup& q = w.g[0];
+    q.out_off = c->fin1_k; q.bias_off = c->fin1_b; q.bias2_off = 0; q.has_bias2 = 0; q.scale = 1.0f;
+}
+static void wgrad_head2_args(wn_ctx* c, WgBatchArgs& w, int B, int T) {
+    const int S = c->S, O = c->O, ldDY = (O + 15) / 16 * 16;
+    wgrad_common(c, w, 1, B, T);
+    w.nseg = 1; w.seg_base[0] = c->DY; w.seg_gstride[0] = 0; w.seg_ld[0] = ldDY; w.seg_nk[0] = ldDY;
+    w.Bm = c->H2; w.b_gstride = 0; w.ldb = S; w.N = S; w.ldw = O;
+    w.transpose_out = 1; w.m_valid = O; w.spu_cap = 4;
+    WgGroup& q = w.g[0];
+    q.out_off = c->fin2_k; q.bias_off = -1; q.bias2_off = 0; q.has_bias2 = 0; q.scale = 1.0f;      // (the bias row of this launch sums H2: unused)
+}
+static bool wgrad_heads_ok(wn_ctx* c) {
+    static const int v = [] { const char* e = getenv("WN_WGRAD_HEADS"); return e ? atoi(e) : 1; }();      // A/B switch (0: round-1 kernel)
+    if (!v || c->S % 256 != 0 || c->O > 128) return false;
+    WgBatchArgs w; wgrad_head1_args(c, w, 1, c->maxT); if (!wn_wgrad_v2_ok(w)) return false;
+    wgrad_head2_args(c, w, 1, c->maxT); return wn_wgrad_v2_ok(w);
+}
 // bytes of split-K partials the grouped launches can need for any batch <= max_batch at max_time
 size_t wn_wgrad_partial_need(wn_ctx* c) {
     size_t need = 0;
@@ -154,6 +187,12 @@ size_t wn_wgrad_partial_need(wn_ctx* c) {
         wgrad_out_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
         wgrad_skipout_args(c, w, 0, ng, B, c->maxT); if (wn_wgrad_v2_ok(w)) { wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w)); }
     }
+    if (wgrad_heads_ok(c))      // (the head launches share the stream of the stack launches: one buffer serves both)
+        for (int B = 1; B <= c->maxB; ++B) {
+            WgBatchArgs w;
+            wgrad_head1_args(c, w, B, c->maxT); wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w));
+            wgrad_head2_args(c, w, B, c->maxT); wn_wgrad_plan(w); need = std::max(need, wn_wgrad_partial_bytes(w));
+        }
     return need + (1 << 20);
 }
 
@@ -374,10 +413,13 @@ void wn_plan_buckets(wn_ctx* c) {
         c->bucket_off[0] = 0; c->bucket_cnt[0] = c->n_raw; c->nbuckets = 1;          // tensors late: ONE bucket, final when the call ends
         return;
     }
-    const int per = (L + want - 1) / want;
+    // `want` pieces of (almost) equal depth from the top; L >= 2 * want, so per >= 2 and the last (lowest) piece keeps >= per layers.
+    // Pieces deeper than one grouped launch can address (WN_MAX_GROUPS layers) are chunked in stack_wgrads.
+    const int per = L / want;
     int hi = L;
     for (int k = 0; k < want - 1; ++k) {
         const int lo = hi - per;
+        if (lo <= 0) break;
         c->bucket_lo[k] = lo; c->bucket_hi[k] = hi;
         c->bucket_off[k] = c->lay[lo].dil_k;
         c->bucket_cnt[k] = (k == 0 ? tail0 : c->lay[hi].dil_k) - c->lay[lo].dil_k;      // bucket 0 also carries the head (final_convolution_*)
@@ -397,7 +439,9 @@ extern "C" int wn_bwd_bucket_range(const wn_ctx* c, int32_t i, int64_t* offset, 
 extern "C" int wn_bwd_wait_bucket(wn_ctx* c, int32_t i, void* stream) {
     if (!c || i < 0 || i >= c->nbuckets) return WN_E_ARG;
     if (!c->have_bwd) WN_FAIL(c, WN_E_STATE, "wn_bwd_wait_bucket: no wn_train_bwd has been enqueued");
-    WN_HIP(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_bucket[i < c->nbuckets_early ? i : WN_MAX_BUCKETS], 0));
+    // buckets whose weight gradients actually ran early (under the chain) in the LAST backward have their own event; every other
+    // piece -- incl. the early pieces of a model that took the per-layer kernels (narrow channel counts) -- is final with the call
+    WN_HIP(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_bucket[i < c->nearly_live ? i : WN_MAX_BUCKETS], 0));
     return WN_OK;
 }
 
@@ -452,13 +496,19 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
       if (!fused) { wgrad_skip_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w);
                     wgrad_out_args(c, w, 0, 1, c->fB, c->fT); grouped = grouped && wn_wgrad_v2_ok(w); } }
     const int nearly = grouped ? c->nbuckets_early : 0;       // (per-layer v1 kernels: everything after the chain, as one piece)
+    c->nearly_live = nearly;                                  // wn_bwd_wait_bucket: which pieces have their own event in THIS backward
     // ---- weight-gradient stream: head weight gradients first (their operands exist since the forward / loss), then one bucket of
     // stack weight gradients whenever both chain streams have passed its lowest layer
     WN_HIP(c, hipEventRecord(c->ev_w0, st));
     static const bool serial = getenv("WN_SERIAL") != nullptr;      // profiling aid: every kernel on the caller's stream (with WN_BATCH_PARTS=1: exclusive kernel times)
     hipStream_t wst = serial ? st : c->st3;
     WN_HIP(c, hipStreamWaitEvent(wst, c->ev_w0, 0));
-    {   // d final_convolution_2 = H2^T dY: both operands exist since the forward / loss -- starts now, under the chain (low priority)
+    const bool heads_v2 = wgrad_heads_ok(c);
+    if (heads_v2) {   // d final_convolution_2 = H2^T dY: both operands exist since the forward / loss -- starts now, under the chain (low priority)
+        WgBatchArgs w; wgrad_head2_args(c, w, c->fB, c->fT); w.grads = grads;
+        if ((rc = launch_wgrad_batch(c, w, wst))) return rc;
+        if ((rc = wn_colsum2(c, c->DY, ldDY, ldDY, O, nullptr, rows, grads + c->fin2_b, nullptr, 1, wst))) return rc;
+    } else {
         WgArgs w; memset(&w, 0, sizeof w);
         w.nseg = 1; w.seg[0] = seg(c->H2, S, 0, S, 0, 0); w.ones_row = 1;
         w.Bm = c->DY; w.ldb = ldDY; w.colb0 = 0; w.N = O;
@@ -470,7 +520,10 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     // ---- head weight gradients over the whole batch (wavenet.py:136-149): d final_convolution_1 = R1^T dpre1 needs d pre1 of every
     // part, the first thing each chain stream computes (enqueued after the chain in host order, gated only by those events)
     for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_head[pk], 0));
-    {
+    if (heads_v2) {
+        WgBatchArgs w; wgrad_head1_args(c, w, c->fB, c->fT); w.grads = grads;
+        if ((rc = launch_wgrad_batch(c, w, wst))) return rc;
+    } else {
         WgArgs w; memset(&w, 0, sizeof w);
         w.nseg = 1; w.seg[0] = seg(c->R1, S, 0, S, 0, 0); w.ones_row = 1;
         w.Bm = c->DPRE1; w.ldb = S; w.N = S;
@@ -490,7 +543,8 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
         if (k > 0) {
             for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_chain[pk][k], 0));
         }
-        if ((rc = stack_wgrads(c, grads, c->bucket_lo[k], c->bucket_hi[k] - c->bucket_lo[k], fused, wst))) return rc;
+        for (int l0 = c->bucket_lo[k]; l0 < c->bucket_hi[k]; l0 += WN_MAX_GROUPS)
+            if ((rc = stack_wgrads(c, grads, l0, min(WN_MAX_GROUPS, c->bucket_hi[k] - l0), fused, wst))) return rc;
         WN_HIP(c, hipEventRecord(c->ev_bucket[k], wst));
     }
     // ---- after the chain: the lowest layers' weight gradients (weight-gradient stream), and on the second stream everything small

@@ -196,6 +196,10 @@ struct WgBatchArgs {
     // channel halves of u_l) with the SAME staged B tile: B is read na x less often and the DMA issue per MFMA drops accordingly.
     // A tile a of column block h (< hblocks): segment a_seg[a], channels [a_col0[a] + a_colstep h, +128), output rows a_mrow[a] + a_colstep h.
     int32_t na, hblocks, a_colstep, a_seg[3], a_col0[3], a_mrow[3];
+    // head launches (small contractions that run beside the backward chain): spu_cap > 0 bounds the time slabs per utterance (every
+    // slab costs a partial tile); transpose_out: the result is written as out[n][m] (row pitch ldw, only rows m < m_valid) -- the
+    // operand roles are swapped when the natural B operand is narrower than the 256-column tile
+    int32_t spu_cap, transpose_out, m_valid, pad1_;
     float* partial;                     // [unit][mtiles*128 + 8][N] fp32; row mtiles*128 = bias partial
     int32_t B, T, slab, spu, Mrows, mtiles, ntiles, nunits;
     const bf16_t* zero;
@@ -485,6 +489,13 @@ __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(const WgBatchArgs 
     const float sc = hi ? g.scale_hi : g.scale;
     const int col = hi ? c4 * 4 - a.split_n : c4 * 4;
     s.x *= sc; s.y *= sc; s.z *= sc; s.w *= sc;
+    if (a.transpose_out) {
+        if (!is_bias && m < a.m_valid) {
+            float* dst = a.grads + g.out_off + (int64_t)col * a.ldw + m;
+            dst[0] += s.x; dst[a.ldw] += s.y; dst[2 * (int64_t)a.ldw] += s.z; dst[3 * (int64_t)a.ldw] += s.w;
+        }
+        return;
+    }
     auto add4 = [&](float* dst) { float4 o = *reinterpret_cast<float4*>(dst); o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w; *reinterpret_cast<float4*>(dst) = o; };
     if (!is_bias) add4(a.grads + (hi ? g.out_off_hi : g.out_off) + (int64_t)m * (hi ? a.ldw_hi : a.ldw) + col);
     else if (hi) {
@@ -507,6 +518,7 @@ static inline void wn_wgrad_plan(WgBatchArgs& a) {
     int spu = cdiv(a.na > 1 ? 256 : 512, (int64_t)tpu * a.B * a.ngroups);
     const int max_spu = a.T / 256 > 0 ? a.T / 256 : 1;
     if (spu > max_spu) spu = max_spu;
+    if (a.spu_cap > 0 && spu > a.spu_cap) spu = a.spu_cap;
     if (spu < 1) spu = 1;
     a.slab = cdiv(cdiv(a.T, spu), WG2_KT) * WG2_KT;
     a.spu = cdiv(a.T, a.slab);
@@ -514,7 +526,7 @@ static inline void wn_wgrad_plan(WgBatchArgs& a) {
 }
 static inline size_t wn_wgrad_partial_bytes(const WgBatchArgs& a) { return (size_t)a.nunits * (a.mtiles * 128 + 8) * a.N * 4; }
 static inline bool wn_wgrad_v2_ok(const WgBatchArgs& a) {
-    if (a.N % 256 != 0 || a.ldw % 4 != 0 || a.ngroups > WN_MAX_GROUPS) return false;
+    if (a.N % 256 != 0 || (a.ldw % 4 != 0 && !a.transpose_out) || a.ngroups > WN_MAX_GROUPS) return false;
     for (int s = 0; s < a.nseg; ++s) if (a.seg_nk[s] % 8 != 0 || (a.seg_nk[s] % 128 != 0 && s != a.nseg - 1)) return false;
     return true;
 }

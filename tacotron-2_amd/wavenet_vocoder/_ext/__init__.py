@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'csrc', 'libwavenet_mi355.so'))
 
-WN_ABI_VERSION = 3
+WN_ABI_VERSION = 4
 WN_MAX_UPSAMPLE = 8
 INPUT_TYPES = {'raw': 0, 'mulaw': 1, 'mulaw-quantize': 2}
 UPSAMPLE_TYPES = {'NearestNeighbor': 0, '2D': 1, 'SubPixel': 2, '1D': 3, 'Resize': 4}
@@ -93,6 +93,7 @@ def load_library():
         'wn_fill_noise': (ctypes.c_int, [vp, vp, i32, i32, u64, vp]),
         'wn_synth_check': (ctypes.c_int, [vp]),
         'wn_synth_last_path': (ctypes.c_int, [vp]),
+        'wn_synth_pipe_eligible': (ctypes.c_int, [vp, i32]),
         'wn_sample': (ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         'wn_mulaw': (ctypes.c_int, [vp, vp, i64, vp]),
         'wn_inv_mulaw': (ctypes.c_int, [vp, vp, i64, vp]),
@@ -316,6 +317,13 @@ class Engine:
     def synth_check(self):
         """Wait for the last synthesize of this engine and raise if the pipeline gave up on a hand-off."""
         self._ok(self.lib.wn_synth_check(self.h))
+
+    def pipeline_eligible(self, B):
+        """Would synthesize(steps_per_graph <= 0) run B streams on the persistent pipeline?"""
+        rc = int(self.lib.wn_synth_pipe_eligible(self.h, int(B)))
+        if rc < 0:
+            self._ok(rc)
+        return rc == 1
 
     @property
     def synth_path(self):

@@ -91,23 +91,32 @@ class Feeder(object):
         return self._coord is not None and self._coord.should_stop()
 
     def _producer(self, train, q):
-        """Body of a background thread.  Any error (missing .npy, audio / mel length mismatch, '<no_g>' speaker column ...) stops
-        the coordinator and travels through the queue, so that next_*_batch re-raises it in the training loop instead of blocking
-        forever on a dead producer (and, data parallel, leaving the other ranks inside an all-reduce until the RCCL timeout)."""
+        """Body of a background thread.  Any error (missing .npy, audio / mel length mismatch, '<no_g>' speaker column ...) travels
+        through the queue BEHIND the batches that were already produced: next_*_batch re-raises it in the training loop when the
+        loop reaches it.  The producer does not stop the coordinator itself -- the loop tests ``coord.should_stop()`` before every
+        step and would leave silently, with up to 8 good batches still queued, a success message and (data parallel) the other
+        ranks inside an all-reduce; the training loop owns the decision (train.py broadcasts the failure so every rank stops at
+        the same step)."""
         try:
             while not self._should_stop():
                 for batch in self._iter_group(train=train):
-                    if self._put(q, self._prepare_batch(batch)):
+                    if self._put(q, self._pin(self._prepare_batch(batch))):
                         return
         except BaseException as e:          # noqa: BLE001 -- forwarded, not swallowed
             self._error = e
-            if self._coord is not None:
-                self._coord.request_stop(e)
-            for qq in (self._train_q, self._eval_q):
-                try:
-                    qq.put_nowait(_FeederError(e))
-                except queue.Full:
-                    pass                      # the consumer finds self._error after draining what is queued
+            # blocking puts (they give up only when the coordinator stops): the consumer of EITHER queue will reach the error -- the
+            # training loop must hear of a dead eval producer before the eval step blocks on it, and vice versa
+            for qq in (q, self._eval_q if q is self._train_q else self._train_q):
+                if self._put(qq, _FeederError(e)):
+                    return
+
+    @staticmethod
+    def _pin(batch):
+        """numpy batch -> page-locked host tensors (in the producer thread, off the step's critical path): the H2D copies of
+        next_*_batch are then truly asynchronous (``non_blocking`` from pageable memory is a synchronous staged copy)."""
+        if not torch.cuda.is_available():
+            return batch
+        return tuple(None if b is None else torch.from_numpy(b).pin_memory() for b in batch)
 
     def _put(self, q, item):
         """Blocking put that gives up when the coordinator stops (returns True then)."""
@@ -143,9 +152,16 @@ class Feeder(object):
     def next_eval_batch(self):
         return self._to_device(self._get(self._eval_q))
 
+    def failed(self):
+        """The producer thread's exception, if any (the training loop polls it to stop every rank at the same step)."""
+        return self._error
+
     def _to_device(self, batch):
         dev = self._device or torch.device('cuda', torch.cuda.current_device())
-        return tuple(None if b is None else torch.from_numpy(b).to(dev, non_blocking=True) for b in batch)
+        host = tuple(None if b is None else (b if torch.is_tensor(b) else torch.from_numpy(b)) for b in batch)
+        # double buffer: the pinned source of an in-flight copy must outlive it -- keep the last two batches referenced
+        self._inflight = (getattr(self, '_inflight', ()) + (host,))[-2:]
+        return tuple(None if b is None else b.to(dev, non_blocking=True) for b in host)
 
     # ------------------------------------------------------------------ examples
     def _next_group(self, train):

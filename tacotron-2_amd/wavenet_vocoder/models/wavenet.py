@@ -86,12 +86,14 @@ class WaveNet(object):
 
     def _ensure_packed(self):
         if self._dirty:
-            self.engine.pack_weights(self.params)
+            self.engine.pack_weights(self.ema_params if getattr(self, '_pack_ema', False) else self.params)
             self._dirty = False
 
-    def use_ema_weights(self):
-        """Synthesis with the averaged weights (what the reference intended with its shadow saver)."""
-        self.engine.pack_weights(self.ema_params)
+    def use_ema_weights(self, enable=True):
+        """Synthesis / evaluation with the averaged weights (what the reference intended with its shadow saver, train.py:75-83):
+        from now on the engine packs ``ema_params`` instead of ``params`` (training forwards included, so only switch it on for a
+        synthesis-only model or switch it off again)."""
+        self._pack_ema = bool(enable)
         self._dirty = True
 
     # ------------------------------------------------------------------ reference-shaped API
@@ -124,7 +126,7 @@ class WaveNet(object):
             c0 = c[idx:idx + 1, :, :length // hop].contiguous()
             ti = None if hp.wavenet_natural_eval else y0.reshape(1, -1).contiguous()
             g0 = None if g is None else torch.as_tensor(g)[idx:idx + 1]
-            out, raw = self.incremental(None, c=c0, g=g0, time_length=length, test_inputs=ti, return_raw=True)
+            out, raw = self.incremental(None, c=c0, g=g0, time_length=length, test_inputs=ti, return_raw=True, check=True)
             tgt = y0.reshape(1, -1)
             ln = torch.tensor([length], dtype=torch.int32, device=raw.device)
             self.engine.loss(raw, tgt.contiguous(), ln, 0, self._loss_dev)          # no shift: wavenet.py:497-506
@@ -146,7 +148,7 @@ class WaveNet(object):
             raise ValueError('Expected 3 dimension shape [batch_size(1), time_length, {}] for local condition features but found {}'.format(
                 hp.cin_channels, tuple(c.shape)))
         cT = c.transpose(1, 2).contiguous()
-        out = self.incremental(None, c=cT, g=g, time_length=None, test_inputs=test_inputs)
+        out = self.incremental(None, c=cT, g=g, time_length=None, test_inputs=test_inputs, check=True)
         if is_mulaw_quantize(hp.input_type):
             y_hat = util.inv_mulaw_quantize(out)
         elif is_mulaw(hp.input_type):
@@ -239,10 +241,12 @@ class WaveNet(object):
         return torch.softmax(y_hat, dim=1) if softmax else y_hat
 
     def incremental(self, initial_input, c=None, g=None, time_length=100, test_inputs=None, softmax=True, quantize=True,
-                    log_scale_min=-7.0, log_scale_min_gauss=-7.0, noise=None, return_raw=False):
+                    log_scale_min=-7.0, log_scale_min_gauss=-7.0, noise=None, return_raw=False, check=False):
         """Fast-WaveNet generation with ring-buffer queues: c [B,cin,Tc] -> samples [B,T] (wavenet.py:724-911).
         ``initial_input`` is accepted for signature parity; generation always starts from the reference's silence
-        frame (wavenet.py:433-445).  ``noise`` [T,B,noise_per_step] may be supplied for reproducible draws."""
+        frame (wavenet.py:433-445).  ``noise`` [T,B,noise_per_step] may be supplied for reproducible draws.
+        ``check``: wait for the generation and verify it; if the persistent pipeline gave up on a hand-off (a workgroup was not
+        resident -- the reference's loop cannot fail this way) the batch is re-run ONCE on the launch-per-layer graph path."""
         hp = self._hparams
         B, Tc = int(c.shape[0]), int(c.shape[-1])
         hop = audio.get_hop_size(hp)
@@ -265,18 +269,42 @@ class WaveNet(object):
         spg = int(getattr(hp, 'mi355_steps_per_graph', 0))
         cc = c.contiguous().float()
         feats = torch.empty(B, hp.cin_channels, T, device=dev)
-        # The persistent pipeline (real time at 22.05 kHz) pipelines up to 8 streams per run through its layer ring at the wall time
-        # of one; larger batches go through it in groups of 8 (streams are independent: wavenet.py:237-239 splits them over towers).
-        # Global conditioning / very wide models take the launch-per-layer graph path for the whole batch.
-        group = B if (spg > 0 or g is not None or B <= 8) else 8
-        for b0 in range(0, B, group):
-            b1 = min(B, b0 + group)
-            nz = None if noise is None else noise[:, b0:b1].contiguous()
-            if g is not None:
-                self._set_global(g, B)                                                 # wavenet.py:766-777
-            self.engine.synthesize(cc[b0:b1].contiguous(), nz, out[b0:b1], None if raw is None else raw[b0:b1], None if ti is None else ti[b0:b1].contiguous(),
-                                   steps_per_graph=spg, seed=seed * 64 + b0 // group)
-            self.engine.upsampled_features(feats[b0:b1])
+        gt = None
+        if self.global_conditioning_enabled():
+            if g is None:
+                raise ValueError('global conditioning is enabled (gin_channels > 0) but no g was given')
+            gt = torch.as_tensor(g, device=self.device).reshape(B, -1)
+
+        def run(spg_):
+            # The persistent pipeline (real time at 22.05 kHz) pipelines up to 8 streams per run through its layer ring at the wall time
+            # of one; larger batches go through it in groups of 8 (streams are independent: wavenet.py:237-239 splits them over towers).
+            # Models the pipeline does not fit (wn_synth_pipe_eligible) take the launch-per-layer graph path, whose time per step is
+            # nearly independent of the batch: the whole batch in one run.
+            piped = spg_ <= 0 and self.engine.pipeline_eligible(min(B, 8))
+            group = 8 if (piped and B > 8) else B
+            for b0 in range(0, B, group):
+                b1 = min(B, b0 + group)
+                nz = None if noise is None else noise[:, b0:b1].contiguous()
+                if gt is not None:
+                    self._set_global(gt[b0:b1], b1 - b0)                                # wavenet.py:766-777
+                self.engine.synthesize(cc[b0:b1].contiguous(), nz, out[b0:b1], None if raw is None else raw[b0:b1], None if ti is None else ti[b0:b1].contiguous(),
+                                       steps_per_graph=spg_, seed=seed * 64 + b0 // group)
+                self.engine.upsampled_features(feats[b0:b1])
+            return group
+
+        group = run(spg)
+        if check:
+            torch.cuda.synchronize()
+            try:
+                self.engine.synth_check()
+            except _ext.WnError as e:
+                if self.engine.synth_path != 'pipeline':
+                    raise
+                log('WaveNet synthesis: {} -- re-running this batch on the launch-per-layer graph path'.format(e))
+                self.synth_fallbacks = getattr(self, 'synth_fallbacks', 0) + 1
+                group = run(32)
+                torch.cuda.synchronize()
+                self.engine.synth_check()
         if getattr(self, '_logged_synth_path', None) != self.engine.synth_path:
             self._logged_synth_path = self.engine.synth_path
             log('WaveNet synthesis path: {} ({} streams per run)'.format(self.engine.synth_path, group))

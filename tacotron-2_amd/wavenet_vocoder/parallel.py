@@ -86,3 +86,25 @@ def shard_batch(items, rank_=None, world_=None):
         raise ValueError('batch of %d is not divisible by %d ranks (feeder.py:267-268)' % (len(items), w))
     per = len(items) // w
     return items[r * per:(r + 1) * per]
+
+
+def param_checksum(flat):
+    """Exact (bit-pattern) checksum of a flat fp32 tensor: the int64 sum of its words read as int32.  Replicas that applied the same
+    updates to the same all-reduced gradients have EQUAL checksums; any divergence of a single ulp changes it."""
+    return flat.detach().contiguous().view(torch.int32).sum(dtype=torch.int64)
+
+
+def assert_replicas_in_sync(flat, what='parameters'):
+    """Replica-drift guard of data-parallel training: every rank owns a full replica that is never re-broadcast after step 0
+    (clip / Adam / EMA are replicated, deterministic kernels on the all-reduced gradient), so a cheap all-reduce of a checksum at
+    every checkpoint interval proves they are still bit-identical -- and aborts the job on every rank when they are not."""
+    if not is_distributed() or world_size() == 1:
+        return True
+    cs = param_checksum(flat).reshape(1)
+    lo, hi = cs.clone(), cs.clone()
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    if int(lo.item()) != int(hi.item()):
+        raise RuntimeError('data-parallel replicas diverged: %s differ between ranks (checksum %d on rank %d, range [%d, %d])'
+                           % (what, int(cs.item()), rank(), int(lo.item()), int(hi.item())))
+    return True

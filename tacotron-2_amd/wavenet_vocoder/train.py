@@ -62,6 +62,38 @@ class _Coordinator(object):
         self._stop = True
 
 
+class _LateScalars(object):
+    """Device scalars read by the host one (or more) steps late: ``push`` copies a small device vector to a pinned slot behind the
+    work already enqueued and records an event; ``pop_ready(keep)`` waits for -- and returns -- all but the ``keep`` newest."""
+
+    def __init__(self, width, device):
+        self._pending = []
+        self._width = width
+        self._device = device
+        self._pin = torch.cuda.is_available()
+
+    def push(self, tag, vec):
+        host = torch.empty(self._width, dtype=torch.float32, pin_memory=self._pin)
+        host.copy_(vec, non_blocking=True)
+        ev = None
+        if vec.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pending.append((tag, host, ev))
+
+    def pop_ready(self, keep=1):
+        out = []
+        while len(self._pending) > keep:
+            tag, host, ev = self._pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            out.append((tag, tuple(float(v) for v in host)))
+        return out
+
+    def drain(self):
+        return self.pop_ready(0)
+
+
 def time_string():
     from datetime import datetime
     return datetime.now().strftime('%Y-%m-%d %H:%M')
@@ -291,22 +323,52 @@ def train(log_dir, args, hparams, input_path):
             log('Starting new training!', slack=True)
         feeder.start_threads(None)
 
+        # The host reads the loss ONE STEP LATE: step k's loss travels to pinned memory behind step k's kernels and is looked at after
+        # step k+1 has been enqueued, so the device never waits for the host (the reference's session.run returns the loss of the step
+        # it ran: one host round trip per step, which here would expose the ~1 ms of enqueue time every step).  The NaN / > 100
+        # guard (train.py:307-309) therefore trips one step after the fact.  Data parallel: the same late read carries a "some
+        # rank's feeder failed" flag, so that every rank leaves the loop at the SAME step instead of hanging in an all-reduce.
+        late = _LateScalars(2, model.device)
+        last_batch = None
+        flag_const = (torch.zeros(1, device=model.device), torch.ones(1, device=model.device))     # (no H2D copy inside the loop)
         while not coord.should_stop() and step < args.wavenet_train_steps:
             start_time = time.time()
-            batch = feeder.next_train_batch()
+            feeder_error = None
+            try:
+                batch = feeder.next_train_batch()
+                last_batch = batch
+            except RuntimeError as e:
+                if _dist() is None or world == 1 or last_batch is None:
+                    raise
+                feeder_error, batch = e, last_batch       # keep the collectives of this step matched; everyone stops right after
             x, y, lengths, c, g = batch
             model.initialize(y, c, g, lengths, x=x)
             loss_t = model.add_loss()
             step = model.add_optimizer(step)
-            loss = float(loss_t.item())          # one host sync per step, like session.run
+            flag = flag_const[1 if feeder_error is not None else 0]
+            if _dist() and world > 1:
+                flag = flag.clone()
+                _dist().all_reduce(flag, op=_dist().ReduceOp.MAX)
+            late.push(step, torch.cat([loss_t.reshape(1).float(), flag]))
+            if feeder_error is not None:
+                late.drain()
+                raise feeder_error
+            prev = late.pop_ready(keep=1 if step < args.wavenet_train_steps else 0)     # the previous step's (the last step: its own)
             time_window.append(time.time() - start_time)
-            loss_window.append(loss)
-            message = 'Step {:7d} [{:.3f} sec/step, loss={:.5f}, avg_loss={:.5f}]'.format(step, time_window.average, loss, loss_window.average)
-            log(message, end='\r', slack=(step % args.checkpoint_interval == 0))
+            for pstep, (loss, bad) in prev:
+                if bad > 0:
+                    raise RuntimeError('the feeder of another rank failed at step {}: stopping every rank'.format(pstep))
+                loss_window.append(loss)
+                message = 'Step {:7d} [{:.3f} sec/step, loss={:.5f}, avg_loss={:.5f}]'.format(pstep, time_window.average, loss, loss_window.average)
+                log(message, end='\r', slack=(pstep % args.checkpoint_interval == 0))
+                if np.isnan(loss) or loss > 100:
+                    log('Loss exploded to {:.5f} at step {}'.format(loss, pstep))
+                    raise Exception('Loss exploded')
+            loss = loss_window._values[-1] if loss_window.count else float('nan')      # (summaries: the newest loss the host has seen)
 
-            if np.isnan(loss) or loss > 100:
-                log('Loss exploded to {:.5f} at step {}'.format(loss, step))
-                raise Exception('Loss exploded')
+            if _dist() and world > 1 and step % args.checkpoint_interval == 0:
+                from wavenet_vocoder.parallel import assert_replicas_in_sync
+                assert_replicas_in_sync(model.params, what='parameters at step {}'.format(step))
 
             if step % args.summary_interval == 0 and rank == 0:
                 log('\nWriting summary at step {}'.format(step))
@@ -330,8 +392,10 @@ def train(log_dir, args, hparams, input_path):
                 add_embedding_stats(tensorboard_dir, ['WaveNet_model/inference/gc_embedding'], [speaker_embedding_meta], [model.embedding_table], step)
                 log('WaveNet Speaker embeddings have been updated on tensorboard!')
             if _dist() and (step % args.checkpoint_interval == 0 or step % args.eval_interval == 0):
-                _dist().barrier()
+                _dist().barrier()          # rank 0 wrote logs / a checkpoint / ran the eval step: the others wait HERE, not inside the next all-reduce
 
+        if coord.should_stop() and step < args.wavenet_train_steps:
+            raise RuntimeError('training stopped by the coordinator at step {} of {}'.format(step, args.wavenet_train_steps))
         log('Wavenet training complete after {} global steps'.format(args.wavenet_train_steps), slack=True)
         return save_dir
     except Exception as e:

@@ -471,8 +471,10 @@ def test_feeder_ranks_take_disjoint_slices_of_the_same_batches(tmp_path, monkeyp
 
 
 def test_feeder_thread_errors_reach_the_training_loop(tmp_path):
-    """A failure inside a background feeder thread (here: a mel file of the wrong length) stops the coordinator and is re-raised by
-    next_train_batch instead of leaving the training loop blocked on an empty queue."""
+    """A failure inside a background feeder thread (here: a mel file of the wrong length) is re-raised by next_train_batch -- AFTER the
+    batches that were already queued -- instead of leaving the training loop blocked on an empty queue.  The producer must NOT stop the
+    coordinator itself: the loop tests coord.should_stop() before every step and would leave silently with good batches still queued
+    (ADVICE round 2); the loop owns that decision."""
     import hparams as H
     from wavenet_vocoder import feeder as F
     from wavenet_vocoder.train import _Coordinator
@@ -485,10 +487,12 @@ def test_feeder_thread_errors_reach_the_training_loop(tmp_path):
     coord = _Coordinator()
     fd = F.Feeder(coord, meta, str(tmp_path), hp, device=torch.device('cpu'))
     fd.start_threads()
+    got = 0
     with pytest.raises(RuntimeError, match='feeder thread failed'):
         for _ in range(200):
-            fd.next_train_batch()
-    assert coord.should_stop()
+            fd.next_train_batch(); got += 1
+    assert not coord.should_stop() and isinstance(fd.failed(), ValueError)
+    coord.request_stop()
 
 
 def test_dropout_seed_is_per_rank_and_single_gpu_compatible():
