@@ -77,10 +77,21 @@ def alg_bytes_per_sample(hp, e=2):
     return 3 * e * (L * (2 * R + C + 2 * S) + cin + O) + 2 * e * L * (G + G // 2)
 
 
-# measured HBM-side traffic of the gate-GEMM launches at C2 (profiles/r2x_pmc_fetch.md + r2x_pmc_write.md, 48 half-batch launches of 44 000 rows per
-# step): 2 x FETCH_SIZE = 2.26 GB and WRITE_SIZE = 2.16 GB per step => 92.3 MB per launch (algorithmic: 29.6 MB of activations read + 45.1 MB written:
-# sigmoid + gate output); scaled to 8 x 11 000 rows below
-GATE_TRAFFIC_BYTES = 2.0 * (2.27e9 + 2.16e9) / 48.0
+def load_traffic(workload, B, T, path=None):
+    """HBM-side traffic (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC in separate passes, gfx950 FETCH_SIZE calibration) of the training step
+    from the COMMITTED summary tools/pmc_summary.py --traffic wrote (profiles/traffic.json): per step over all kernels, and per launch
+    of the dominant kernel.  None when the summary was measured on another workload / batch geometry (nothing is scaled or guessed)."""
+    path = path or os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get('workload') != workload or (int(t.get('batch', 0)), int(t.get('time', 0))) != (B, T):
+        return None
+    return {'bytes_per_step': t['bytes_per_step'], 'fetch_x2_bytes_per_step': t['fetch_x2_bytes_per_step'], 'write_bytes_per_step': t['write_bytes_per_step'],
+            'gate_bytes_per_launch': t.get('gate_bytes_per_launch'), 'gate_launches_per_step': t.get('gate_launches_per_step'),
+            'source': 'profiles/traffic.json <- %s (%s)' % (' + '.join(t.get('sources', [])), t.get('tag', ''))}
 
 
 def synthetic_batch(hp, B, T, seed, device):
@@ -171,6 +182,26 @@ def cpu_synth_baseline(hp, steps=2200, seconds_budget=15.0):
     return out
 
 
+def cpu_full_batch_reference(workload, B, T):
+    """The oracle on the WHOLE bench batch (not the bounded sample above): the GPU parity test of this geometry runs the oracle's forward +
+    autograd backward on the same 8 x 11 000 batch on the GPU box's host cores and records its wall time; the newest committed record
+    (profiles/*parity_c2_b8.json) is quoted here so that the bounded-sample figure has the full-size one beside it.  Nothing is run."""
+    import glob
+    if workload != 'c2':
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*parity_c2_b8.json')))      # r2e < r2x < r3f < r4a ...: the newest session sorts last
+    for path in reversed(files):
+        try:
+            d = json.load(open(path))
+            if (int(d['B']), int(d['T'])) == (B, T) and d.get('oracle_seconds'):
+                return {'value': B * T / float(d['oracle_seconds']), 'unit': 'audio_samples/s', 'oracle_seconds': float(d['oracle_seconds']),
+                        'what': 'oracle forward + autograd backward (no optimiser) of the full %d x %d batch, utterance by utterance, all host cores of the GPU box' % (B, T),
+                        'source': os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def cpu_baseline_subprocess(workload, hard_timeout=150, fn='cpu_baseline'):
     """Run the CPU leg in a child process so that a pathological host (thread oversubscription) can never
     take the GPU number down with it."""
@@ -228,6 +259,56 @@ def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8)):
     return out
 
 
+def measure_other_workload(key, device, steps=10, warmup=3):
+    """A short run of another BASELINE workload through the same engine (c5_stress = configs[4], default_hparams = the shape that
+    really is HBM-bound), same step function as the headline: ms/step plus its own whole-step HBM / MFMA fractions and the gate
+    GEMM's pure-kernel fraction.  Reported next to the headline, never as `value`."""
+    from wavenet_vocoder import _ext
+    from wavenet_vocoder.models.modules import initialize_parameters
+    hp, B, T = build_hparams(key)
+    hop = int(np.prod(hp.upsample_scales)); T = T // hop * hop
+    eng = _ext.Engine(hp, B, T, grad_buckets=1)
+    flat = initialize_parameters(hp, eng.layout).to(device)
+    grads = torch.zeros_like(flat); m, v, ema = torch.zeros_like(flat), torch.zeros_like(flat), flat.clone()
+    loss = torch.zeros(1, device=device)
+    x, c, y, lengths, _, _ = synthetic_batch(hp, B, T, seed=5339, device=device)
+
+    def step(i):
+        eng.pack_weights(flat)
+        eng.train_fwd(x, c, y, lengths, 1000 + i, loss)
+        eng.train_bwd(grads)
+        lr = _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, i, hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
+        eng.optim_step(flat, grads, m, v, ema, lr, i)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    eng.profile(True)
+    t0 = time.time()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    k_ms, k_n = eng.profile_kernel_result()
+    rows = eng.profile_rows_per_launch() or B * T
+    eng.profile(False)
+    R, G, C = hp.residual_channels, hp.gate_channels, hp.cin_channels
+    value = B * T / dt
+    gate_tf = (2.0 * G * (3 * R + C) * rows / (k_ms / k_n * 1e-3) / 1e12) if k_n else None
+    out = {'workload_key': key, 'steps': steps, 'warmup': warmup, 'batch': B, 'time': T, 'layers': hp.layers, 'stacks': hp.stacks,
+           'R': R, 'G': G, 'S': hp.skip_out_channels, 'out_channels': hp.out_channels, 'params': int(eng.n_params),
+           'ms_per_step': dt * 1e3, 'value': value, 'unit': 'audio_samples/s', 'final_loss': float(loss.item()),
+           'train_tflops_algorithmic': 6.0 * mac_per_sample(hp) * value / 1e12,
+           'mfma_whole_step_frac': 6.0 * mac_per_sample(hp) * value / 1e12 / 2500.0,
+           'hbm_whole_step_frac': alg_bytes_per_sample(hp) * value / 8e12, 'alg_bytes_per_sample': alg_bytes_per_sample(hp),
+           'gate_kernel': {'achieved_TFLOPs': gate_tf, 'frac_of_2500': (gate_tf / 2500.0) if gate_tf else None, 'launches_timed': int(k_n),
+                           'rows_per_launch': rows, 'timing': 'in-kernel stamps (pure kernel time), live in the two-stream step'},
+           'bound': 'hbm' if alg_bytes_per_sample(hp) * 2500e12 > 6.0 * mac_per_sample(hp) * 8e12 else 'mfma'}
+    eng.close()
+    del flat, grads, m, v, ema
+    torch.cuda.empty_cache()
+    return out
+
+
 class SmiSampler:
     """rocm-smi power / clock samples while a block runs (one subprocess call per ~second, in a thread).  Best effort: any failure
     just leaves the lists empty."""
@@ -272,12 +353,6 @@ class SmiSampler:
         return out
 
 
-# HBM-side traffic of one C2 training step, ALL kernels: sum over the kernels of (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3
-# PMC passes of this round (separate passes; FETCH_SIZE doubled as the gfx950 calibration in DESIGN 4 prescribes), per step.
-STEP_TRAFFIC_BYTES = {'c2': 35.28e9}          # 26.23 GB fetched + 9.05 GB written (round 1: 36.99 + 10.18 = 47.17 GB)
-STEP_TRAFFIC_SOURCE = 'profiles/r2x_pmc_fetch.md + profiles/r2x_pmc_write.md'
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -286,6 +361,7 @@ def main():
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-synth', action='store_true')
+    ap.add_argument('--no-other-workloads', action='store_true', help='skip the 10-step runs of c5_stress / default_hparams appended under other_workloads')
     ap.add_argument('--no-exclusive', action='store_true', help='skip the untimed single-stream pass (keeps a rocprofv3 trace to the timed configuration)')
     ap.add_argument('--sustained', type=int, default=100, help='steps per block of the untimed-by-contract sustained measurement (3 blocks after the timed region; 0 = off)')
     ap.add_argument('--emulate-allreduce-gbps', type=float, default=0.0,
@@ -390,6 +466,7 @@ def main():
     dt = time.time() - t0
     _log('timed region done: %.1f ms/step' % (dt / args.steps * 1e3))
     prof_ms, prof_n = eng.profile_result()
+    kern_ms, kern_n = eng.profile_kernel_result()
     rows_launch = eng.profile_rows_per_launch()
     eng.profile(False)
     # ---- sustained view (>= 20 warm-up, >= 100 timed steps, median of 3): the contract's timed region above may be a
@@ -428,7 +505,7 @@ def main():
                         'host_ms': float(np.median(hs)), 'step_ms': float(np.median(ds))}
         _log('host enqueue %.2f ms of a %.2f ms step' % (host_enqueue['host_ms'], host_enqueue['step_ms']))
     # untimed extra: the same kernel with the GPU to itself (whole batch on one stream), for the kernel-quality view
-    excl_ms, excl_n, excl_rows = 0.0, 0, 0
+    excl_ms, excl_n, excl_rows, exk_ms, exk_n = 0.0, 0, 0, 0.0, 0
     if not args.no_exclusive:
         eng.set_batch_parts(1)
         one_step(args.warmup + args.steps)
@@ -436,6 +513,7 @@ def main():
         for i in range(2):
             one_step(args.warmup + args.steps + 1 + i)
         excl_ms, excl_n = eng.profile_result()
+        exk_ms, exk_n = eng.profile_kernel_result()
         excl_rows = eng.profile_rows_per_launch()
         eng.profile(False)
         eng.set_batch_parts(0)
@@ -453,9 +531,17 @@ def main():
         R, G, C = hp.residual_channels, hp.gate_channels, hp.cin_channels
         rows_launch = rows_launch or B * T       # the layer chain runs per half-batch on two streams
         flops_launch = 2.0 * G * (3 * R + C) * rows_launch
-        avg_s = (prof_ms / max(prof_n, 1)) * 1e-3
-        achieved = flops_launch / avg_s / 1e12 if prof_n else None
+        # two clocks on the same launches: the kernel's OWN duration from in-kernel stamps (first workgroup start .. last workgroup end;
+        # what rocprofv3's kernel trace reports, profiles/*kernel_stats.csv) and the HIP-event bracket on the launch stream, which also
+        # counts the wait for CU slots behind the other half-batch's kernels.  `achieved` / `frac` use the kernel's own duration.
+        avg_ev_s = (prof_ms / max(prof_n, 1)) * 1e-3
+        avg_s = (kern_ms / max(kern_n, 1)) * 1e-3 if kern_n else avg_ev_s
+        achieved = flops_launch / avg_s / 1e12 if (kern_n or prof_n) else None
+        achieved_ev = flops_launch / avg_ev_s / 1e12 if prof_n else None
         peak = 2500.0
+        traffic = load_traffic(args.workload, B, T)
+        unprof = sustained['ms_per_step'] if sustained else None
+        ex_avg = (exk_ms / max(exk_n, 1)) if exk_n else (excl_ms / max(excl_n, 1))
         res = {
             'metric': 'wavenet_train_audio_samples_per_sec', 'value': value, 'unit': 'audio_samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -467,24 +553,33 @@ def main():
             'samples_per_sec_per_gpu': value / world,
             'train_tflops_algorithmic': 6.0 * mac * value / 1e12,
             'final_loss': final_loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1> (dilated conv + cond GEMM + gate, fwd)',
+            'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1,3> (dilated conv + cond GEMM + gate, fwd)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
-                         'traffic': GATE_TRAFFIC_BYTES * rows_launch / (8 * 11000.0) if args.workload == 'c2' and T == 11000 else None,
-                         'traffic_source': 'profiles/r2x_pmc_fetch.md + r2x_pmc_write.md: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC in separate passes, gfx950 correction), scaled by rows per launch',
-                         'launches_timed': int(prof_n), 'avg_launch_ms': avg_s * 1e3 if prof_n else None,
+                         'frac_incl_queue_wait': (achieved_ev / peak) if achieved_ev else None,
+                         'timing': 'achieved / frac: in-kernel start..end stamps of every timed launch (the kernel duration rocprofv3 reports); '
+                                   'frac_incl_queue_wait: HIP events around the same launches on their stream (adds the wait behind the other stream)',
+                         'traffic': (traffic['gate_bytes_per_launch'] * rows_launch / (B * T / 2.0)) if (traffic and traffic.get('gate_bytes_per_launch')) else None,
+                         'traffic_source': (traffic['source'] + ': 2 x FETCH_SIZE + WRITE_SIZE per gate launch of a half batch') if traffic else None,
+                         'launches_timed': int(kern_n or prof_n), 'avg_launch_ms': avg_s * 1e3 if (kern_n or prof_n) else None,
+                         'avg_launch_ms_event_bracket': avg_ev_s * 1e3 if prof_n else None,
                          'alg_flops_per_launch': flops_launch, 'alg_bytes_per_launch': float(rows_launch) * (2 * R + 2 * C + 2 * G),
                          'rows_per_launch': rows_launch,
-                         'note': 'each launch covers one half-batch; its duration includes time shared with the HBM-bound out-conv launches of the other half-batch running concurrently on a second stream'},
-            'roofline_exclusive': {'what': 'same kernel, whole batch on one stream (no concurrent kernels), 2 untimed steps after the timed region',
-                                   'avg_launch_ms': excl_ms / max(excl_n, 1), 'rows_per_launch': excl_rows,
-                                   'achieved': (2.0 * G * (3 * R + C) * excl_rows / (excl_ms / max(excl_n, 1) * 1e-3) / 1e12) if excl_n else None,
-                                   'frac': (2.0 * G * (3 * R + C) * excl_rows / (excl_ms / max(excl_n, 1) * 1e-3) / 1e12 / peak) if excl_n else None},
+                         'profiling_cost': {'what': 'the timed region records 2 events per gate launch and the kernel stamps its start / end; the sustained blocks '
+                                                    'below run the same steps without either', 'ms_per_step_profiled': dt / args.steps * 1e3, 'ms_per_step_unprofiled': unprof},
+                         'note': 'each launch covers one half-batch and shares the GPU with the HBM-bound out-conv launches of the other half-batch on a second stream'},
+            'roofline_exclusive': {'what': 'same kernel, whole batch on one stream (no concurrent kernels), 2 untimed steps after the timed region; in-kernel stamps',
+                                   'avg_launch_ms': ex_avg, 'avg_launch_ms_event_bracket': excl_ms / max(excl_n, 1), 'rows_per_launch': excl_rows,
+                                   'achieved': (2.0 * G * (3 * R + C) * excl_rows / (ex_avg * 1e-3) / 1e12) if excl_n else None,
+                                   'frac': (2.0 * G * (3 * R + C) * excl_rows / (ex_avg * 1e-3) / 1e12 / peak) if excl_n else None},
             # whole-step view asked for by the north star: SURVEY 8d algorithmic HBM bytes per audio sample (bf16) x samples/s vs 8 TB/s
             'hbm_roofline_whole_step': {'alg_bytes_per_sample': alg_bytes_per_sample(hp), 'achieved_GBps': alg_bytes_per_sample(hp) * value / world / 1e9,
                                         'peak_GBps': 8000.0, 'frac': alg_bytes_per_sample(hp) * value / world / 8e12,
                                         'alg_bytes_per_step': alg_bytes_per_sample(hp) * B * T,
-                                        'traffic_per_step': STEP_TRAFFIC_BYTES.get(args.workload) if (B, T) == (8, 11000) else None,
-                                        'traffic_source': STEP_TRAFFIC_SOURCE + ': sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE per step'},
+                                        'traffic_per_step': traffic['bytes_per_step'] if traffic else None,
+                                        'traffic_fetch_x2_per_step': traffic['fetch_x2_bytes_per_step'] if traffic else None,
+                                        'traffic_write_per_step': traffic['write_bytes_per_step'] if traffic else None,
+                                        'traffic_source': (traffic['source'] + ': sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE per step') if traffic else None},
+            'mfma_whole_step_frac': 6.0 * mac * value / world / 1e12 / peak,
             'sustained': sustained, 'host_enqueue': host_enqueue,
             'grad_buckets': [list(b) for b in eng.grad_buckets()], 'force_dist': bool(args.force_dist),
             'emulated_allreduce': ({'gbps': args.emulate_allreduce_gbps, 'bytes': int(eng.n_params) * 4,
@@ -498,9 +593,18 @@ def main():
                 res['synthesis'] = measure_synthesis(hp, flat, device)
             except Exception as e:          # never lose the training number to a synthesis problem
                 res['synthesis'] = {'error': str(e)[:300]}
+        if world == 1 and not args.no_other_workloads and args.workload == 'c2':
+            res['other_workloads'] = {}
+            for key in ('default_hparams', 'c5_stress'):
+                _log('other workload %s ...' % key)
+                try:
+                    res['other_workloads'][key] = measure_other_workload(key, device)
+                except Exception as e:          # never lose the headline to an extra
+                    res['other_workloads'][key] = {'error': str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             _log('cpu baseline (oracle) ...')
             res['cpu_baseline'] = cpu_baseline_subprocess(args.workload)
+            res['cpu_baseline']['full_batch'] = cpu_full_batch_reference(args.workload, B, T)
             if not args.no_synth:
                 _log('cpu baseline, synthesis (oracle incremental loop) ...')
                 try:

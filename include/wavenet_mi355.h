@@ -231,6 +231,9 @@ int wn_debug_copy(wn_ctx* ctx, const char* name, int32_t layer, float* out, int6
  * stream between wn_profile(ctx,1) and wn_profile_result -- which SYNCHRONISES on the recorded events (bench only). */
 int wn_profile(wn_ctx* ctx, int32_t enable);
 int wn_profile_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
+/* the same launches by IN-KERNEL stamps (first workgroup's start .. last workgroup's end on the 100 MHz wall clock): the kernel's own
+ * duration, as rocprofv3's kernel trace reports it -- without the wait behind the other stream's kernels the event bracket includes */
+int wn_profile_kernel_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
 /* time rows (utterances x samples) one timed launch processed: the layer chain runs per half-batch on two streams */
 int64_t wn_profile_rows_per_launch(const wn_ctx* ctx);
 /* A/B switch of the stream structure.  0: default (2 when the batch has >= 2 utterances), 1: whole batch on the caller's stream,

@@ -57,6 +57,11 @@ CONFIGS = {
     'mol_1d': dict(upsample_type='1D', upsample_scales=[2, 2], NN_init=False),
     'mol_nearest': dict(upsample_type='NearestNeighbor', upsample_scales=[4]),
     'softmax': dict(input_type='mulaw-quantize', out_channels=32, quantize_channels=32, layers=6, stacks=3),
+    # dropout ON (the benchmarked configuration trains with wavenet_dropout = 0.05): the stand-in records the keep masks it drew, so
+    # the placement of the op (conv input only, modules.py:484) and the 1 / (1 - p) scaling are pinned by reference execution
+    'mol_2d_dropout': dict(wavenet_dropout=0.05),
+    'gauss_subpixel_legacy_dropout': dict(out_channels=2, upsample_type='SubPixel', upsample_scales=[3, 2], legacy=True, residual_legacy=True,
+                                          wavenet_dropout=0.3),
     'mol_gin_embed': dict(gin_channels=4, use_speaker_embedding=True),
     'mol_gin_raw_nobias': dict(gin_channels=4, use_speaker_embedding=False, use_bias=False),
     # weight normalisation (modules.py:44-177): gains perturbed away from ||v|| so that the normalisation is visible
@@ -151,7 +156,10 @@ def run_config(wn, name, over):
                 for o in (vv if isinstance(vv, (list, tuple)) else [vv]):
                     _wn_layers(o, seen)
         _wn_layers(model, set())
+    shim._STATE.dropout_masks.clear()
     y_hat = model.step(x, c=c, g=g, softmax=False)
+    drop_masks = [m.clone() for m in shim._STATE.dropout_masks]       # one [B, R, T] keep mask per residual layer, in layer order
+    assert len(drop_masks) == (hp.layers if hp.wavenet_dropout > 0 else 0)
     c_up = model.upsampled_local_features
     assert y_hat.shape == (B, hp.out_channels, T) and not torch.equal(y0, y_hat)
 
@@ -202,6 +210,8 @@ def run_config(wn, name, over):
         out['ids'] = ids
     if g is not None:
         out['g'] = g
+    if drop_masks:
+        out['dropout_masks'] = torch.stack(drop_masks)                # [L, B, R, T]
     out.update(res)
     arrays = {k: v.detach().numpy() for k, v in out.items()}
     for k, v in shim.variables().items():

@@ -22,12 +22,12 @@ import torch
 import torch.nn.functional as F
 
 _STATE = types.SimpleNamespace(variables={}, gen=torch.Generator().manual_seed(20240917), uniform_draws=[], normal_draws=[],
-                               scope=[])
+                               scope=[], dropout_masks=[])
 
 
 def reset(seed=20240917):
     _STATE.variables.clear(); _STATE.gen = torch.Generator().manual_seed(seed)
-    _STATE.uniform_draws.clear(); _STATE.normal_draws.clear(); _STATE.scope.clear()
+    _STATE.uniform_draws.clear(); _STATE.normal_draws.clear(); _STATE.scope.clear(); _STATE.dropout_masks.clear()
 
 
 def variables():
@@ -422,9 +422,16 @@ def resize_images(images, size, method=1):
 
 
 def dropout(x, rate=0.5, training=False):
+    """tf.layers.dropout -> tf.nn.dropout(x, keep_prob = 1 - rate): binary = floor(keep_prob + U[0,1)), out = x / keep_prob * binary.
+    TensorFlow's RNG stream cannot be reproduced, so the keep masks are drawn from the stand-in's generator and RECORDED in call
+    order (_STATE.dropout_masks): the golden files carry them and the oracle is handed the same masks -- what the reference's code
+    decides (WHERE the op sits, on which tensor, and that the kept values are scaled by 1 / (1 - rate)) is executed, not restated."""
     if not training or rate == 0:
         return x
-    raise NotImplementedError('the golden configurations run with wavenet_dropout = 0 (TF RNG streams cannot be reproduced)')
+    keep = 1.0 - float(rate)
+    binary = torch.floor(keep + torch.rand(x.shape, generator=_STATE.gen))
+    _STATE.dropout_masks.append(binary.clone())
+    return x / keep * binary
 
 
 def random_uniform(s, minval=0.0, maxval=1.0, dtype=None):

@@ -18,6 +18,9 @@ LIB = os.path.join(HERE, 'libwavenet_mi355.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-inline-asm']
 
 
+LAST_BUILD = {}      # translation unit -> 'compiled' | 'reused' (object newer than its source, every header and this script); 'link' likewise
+
+
 def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
@@ -26,7 +29,9 @@ def _compile(src):
     obj = os.path.join(HERE, src.replace('.hip', '.o'))
     newest = max([_mtime(os.path.join(HERE, src))] + [_mtime(os.path.join(HERE, h)) for h in HEADERS] + [_mtime(__file__)])
     if _mtime(obj) > newest:
+        LAST_BUILD[src] = 'reused'
         return obj, ''
+    LAST_BUILD[src] = 'compiled'
     cmd = ['hipcc'] + FLAGS + ['-c', os.path.join(HERE, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -46,7 +51,9 @@ def build(force=False, verbose=True):
     warn = ''.join(w for _, w in res)
     if verbose and warn.strip():
         print(warn, file=sys.stderr)
+    LAST_BUILD['link'] = 'reused'
     if _mtime(LIB) < max(_mtime(o) for o in objs):
+        LAST_BUILD['link'] = 'linked'
         cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -56,3 +63,4 @@ def build(force=False, verbose=True):
 
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    print('build mode: ' + ', '.join('%s %s' % kv for kv in sorted(LAST_BUILD.items())))

@@ -154,6 +154,8 @@ struct wn_ctx {
     const void* fx = nullptr; const void* fy = nullptr; const int32_t* flen = nullptr; const float* fc = nullptr;
     // live profiling of the dominant kernel (bench.py roofline): event pairs around every gate-GEMM launch
     bool prof = false; std::vector<hipEvent_t> pev; size_t pev_used = 0;
+    unsigned long long* kprof_dev = nullptr;      // [WN_KPROF_MAX][2] in-kernel {first start, last end} stamps of the timed gate launches
+#define WN_KPROF_MAX 8192
     // batch parts: the serial layer chain of the two half-batches runs on two streams so that the MFMA/power-bound GEMMs of
     // one half overlap the HBM-bound kernels of the other (fwd: gate | out conv, bwd: dx | dgate); joined before the loss / wgrads
 #define WN_MAX_PARTS 4

@@ -580,6 +580,7 @@ struct Pipe {
     int32_t* abort_dev = nullptr;       // [0] flag of the running launch, [1] sticky OR of every run since the last wn_pipe_check, +256 B: XCC table
     int32_t* abort_host = nullptr;      // pinned: the abort flag of the last run lands here asynchronously (read by wn_pipe_check)
     bool pending = false;               // a run has been enqueued whose flag has not been inspected yet
+    int test_aborts = 0;
     int layer_lds = 0, head_lds = 0;
     PipeArgs proto;
     hipStream_t priv = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -808,6 +809,9 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     hipLaunchKernelGGL(wn_synth_pipe_kernel, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     WN_LAUNCH_CHECK(c);
     // the abort flag travels to pinned host memory behind the kernel; nobody waits for it here (wn_pipe_check / the next call read it)
+    if (const char* e = getenv("WN_PIPE_TEST_ABORT")) {      // test hook: raise the flag of the first `n` runs as a timed-out hand-off would
+        if (p->test_aborts++ < atoi(e)) WN_HIP(c, hipMemsetD32Async((hipDeviceptr_t)p->abort_dev, 999, 1, st));
+    } else p->test_aborts = 0;
     hipLaunchKernelGGL(wn_pipe_sticky_kernel, dim3(1), dim3(64), 0, st, p->abort_dev);
     WN_HIP(c, hipMemcpyAsync(p->abort_host, p->abort_dev + 1, 4, hipMemcpyDeviceToHost, st));
     p->pending = true; c->synth_path = 2;

@@ -52,6 +52,7 @@ struct GemmArgs {
     uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;   // dropout mask spec (row pitch of the dropped tensor)
     const bf16_t* zero;         // >= 16 B of zeros in device memory (source of out-of-range rows for the LDS-DMA kernel)
     unsigned long long* trace;  // harness-only (WN_EPI_ABLATE builds): per-workgroup s_memtime stamps of the main loop
+    unsigned long long* kprof;  // wn_profile: {min over workgroups of the start, max of the end} of THIS launch in 100 MHz wall-clock ticks (null: off)
     int32_t stagger;            // shader cycles the second-resident workgroups of the first round wait before starting (0: off)
     int32_t xcd_span;           // LDS-DMA kernels: > 0 = XCD x owns the contiguous tiles [x * xcd_span, (x + 1) * xcd_span); 0 = tiles interleaved over XCDs
     int32_t taps;               // 3: seg[0..2] are the dilated taps of ONE tensor (same base / ld / nk), staged interleaved in BK-channel blocks
@@ -433,6 +434,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     const int mblk = q % a.mblocks;
     const int tile = a.xcd_span > 0 ? xcd * a.xcd_span + q / a.mblocks : (q / a.mblocks) * 8 + xcd;
     if (tile >= a.ntiles) return;
+    if (a.kprof && tid == 0) atomicMin(a.kprof, (unsigned long long)wall_clock64());
     if (a.stagger > 0 && id < 512) {
         // All tiles cost the same, so co-resident (and neighbouring) workgroups would reach their MFMA-idle, store-heavy
         // epilogues at the same moment.  First-round workgroups therefore start with a placement-dependent delay; later
@@ -1089,6 +1091,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
             }
         }
     }
+    if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
 }
 
 // Tile order of the LDS-DMA kernels (A/B switch WN_TILE_ORDER: 1 = contiguous run of tiles per XCD, 0 = interleaved).

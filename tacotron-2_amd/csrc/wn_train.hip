@@ -32,7 +32,34 @@ static void prof_mark(wn_ctx* c, hipStream_t st) {
     if (c->pev_used == c->pev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->pev.push_back(e); }
     (void)hipEventRecord(c->pev[c->pev_used++], st);
 }
-extern "C" int wn_profile(wn_ctx* c, int32_t enable) { if (!c) return WN_E_ARG; c->prof = enable != 0; c->pev_used = 0; return WN_OK; }
+__global__ void wn_kprof_init_kernel(unsigned long long* k, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { k[2 * i] = ~0ull; k[2 * i + 1] = 0ull; }
+}
+extern "C" int wn_profile(wn_ctx* c, int32_t enable) {
+    if (!c) return WN_E_ARG;
+    c->prof = enable != 0; c->pev_used = 0;
+    if (c->prof) {
+        if (!c->kprof_dev) WN_HIP(c, hipMalloc((void**)&c->kprof_dev, (size_t)WN_KPROF_MAX * 16));
+        hipLaunchKernelGGL(wn_kprof_init_kernel, dim3(cdiv(WN_KPROF_MAX, 256)), dim3(256), 0, 0, c->kprof_dev, WN_KPROF_MAX);
+        WN_HIP(c, hipDeviceSynchronize());
+    }
+    return WN_OK;
+}
+// the same launches by their IN-KERNEL stamps (first workgroup's start .. last workgroup's end, 100 MHz wall clock): pure kernel time,
+// without the queue / CU-slot wait behind the other stream's kernels that the event bracket of wn_profile_result includes
+extern "C" int wn_profile_kernel_result(wn_ctx* c, double* total_ms, int64_t* launches) {
+    if (!c || !total_ms || !launches) return WN_E_ARG;
+    *total_ms = 0.0; *launches = 0;
+    const size_t n = std::min<size_t>(c->pev_used / 2, WN_KPROF_MAX);
+    if (!c->kprof_dev || n == 0) return WN_OK;
+    for (size_t i = 0; i + 1 < c->pev_used; i += 2) WN_HIP(c, hipEventSynchronize(c->pev[i + 1]));
+    std::vector<unsigned long long> h(2 * n);
+    WN_HIP(c, hipMemcpy(h.data(), c->kprof_dev, 16 * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i)
+        if (h[2 * i] != ~0ull && h[2 * i + 1] >= h[2 * i]) { *total_ms += (double)(h[2 * i + 1] - h[2 * i]) * 1e-5; ++*launches; }
+    return WN_OK;
+}
 // total milliseconds and number of launches of the dominant kernel (gate GEMM) since wn_profile(ctx, 1); synchronises.
 // rows (b*T) one timed gate-GEMM launch processed in the last forward (half the batch when the two-stream split is on)
 extern "C" int64_t wn_profile_rows_per_launch(const wn_ctx* c) { return c ? c->prof_rows : 0; }
@@ -240,7 +267,7 @@ static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
         else a.e.bias = c->b1sum + (size_t)l * G;
         a.e.out0 = c->TS + (size_t)l * NT * GH; a.e.ld_out0 = GH;      // sigmoid half only (tanh = u / sigmoid in the backward)
         a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
-        if (prof) prof_mark(c, st);
+        if (prof) { a.kprof = (c->kprof_dev && c->pev_used / 2 < WN_KPROF_MAX) ? c->kprof_dev + 2 * (c->pev_used / 2) : nullptr; prof_mark(c, st); }
         if ((rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st))) return rc;
         if (prof) prof_mark(c, st);
         if (l + 1 < L) {      // the residual output of the last layer is never consumed (wavenet.py:716)

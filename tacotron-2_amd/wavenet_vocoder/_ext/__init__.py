@@ -103,6 +103,7 @@ def load_library():
         'wn_loss': (ctypes.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         'wn_profile': (ctypes.c_int, [vp, i32]),
         'wn_profile_result': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]),
+        'wn_profile_kernel_result': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]),
         'wn_profile_rows_per_launch': (i64, [vp]),
         'wn_set_batch_parts': (ctypes.c_int, [vp, i32]),
         'wn_debug_copy': (ctypes.c_int, [vp, ctypes.c_char_p, i32, vp, i64, vp]),
@@ -339,6 +340,12 @@ class Engine:
     def profile_result(self):
         ms, n = ctypes.c_double(), ctypes.c_int64()
         self._ok(self.lib.wn_profile_result(self.h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def profile_kernel_result(self):
+        """(total ms, launches) of the timed gate launches by their in-kernel start / end stamps (pure kernel time)."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        self._ok(self.lib.wn_profile_kernel_result(self.h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
     def set_batch_parts(self, parts):

@@ -292,19 +292,26 @@ class WaveNet(object):
                 self.engine.upsampled_features(feats[b0:b1])
             return group
 
-        group = run(spg)
-        if check:
-            torch.cuda.synchronize()
-            try:
-                self.engine.synth_check()
-            except _ext.WnError as e:
-                if self.engine.synth_path != 'pipeline':
-                    raise
-                log('WaveNet synthesis: {} -- re-running this batch on the launch-per-layer graph path'.format(e))
-                self.synth_fallbacks = getattr(self, 'synth_fallbacks', 0) + 1
-                group = run(32)
+        def attempt(spg_):
+            grp = run(spg_)
+            if check:
                 torch.cuda.synchronize()
                 self.engine.synth_check()
+            return grp
+
+        try:
+            group = attempt(spg)
+        except _ext.WnError as e:
+            if not check or self.engine.synth_path != 'pipeline' or 'timed out' not in str(e):
+                raise
+            log('WaveNet synthesis: {} -- re-running this batch on the launch-per-layer graph path'.format(e))
+            self.synth_fallbacks = getattr(self, 'synth_fallbacks', 0) + 1
+            torch.cuda.synchronize()
+            try:
+                self.engine.synth_check()          # (a flag of a later group of the same batch may still be pending)
+            except _ext.WnError:
+                pass
+            group = attempt(32)
         if getattr(self, '_logged_synth_path', None) != self.engine.synth_path:
             self._logged_synth_path = self.engine.synth_path
             log('WaveNet synthesis path: {} ({} streams per run)'.format(self.engine.synth_path, group))

@@ -56,7 +56,12 @@ TOL_YHAT = 3e-2         # end-to-end y_hat vs the emulating oracle              
 TOL_YHAT_FP32 = 3e-2    # y_hat vs the fp32 oracle (the stated price of bf16 operands)
 TOL_GRAD_GLOBAL = 5e-3      # all gradients as one vector                               (measured <= 1.7e-3)
 TOL_GRAD_TENSOR = 1.4e-2    # residual stack + head + input conv tensors                (measured <= 4.7e-3)
+TOL_GRAD_FP32_GLOBAL = 3e-2   # all gradients as one vector vs the FP32 oracle (no rounding emulation): set from the first measurement, see profiles/r4*_pytest
+TOL_GRAD_FP32_TENSOR = 6e-2   # worst residual-stack / head tensor vs the FP32 oracle
 TOL_GRAD_UPSAMPLE = 1.2e-1  # the 6 upsample-net tensors (<= 55 elements each; every element sums bf16 d z over all layers and rows: measured <= 3.9e-2)
+
+
+_LAST_GRADS = {}
 
 
 def _case(over, B, T, lengths, check_layers, chunk=1, seed=1234, report=None, batch_parts=0, grad_buckets=None):
@@ -84,6 +89,7 @@ def _case(over, B, T, lengths, check_layers, chunk=1, seed=1234, report=None, ba
     torch.cuda.synchronize()
     yhat = yhat_dev.cpu()
     g_dev = download_grads(eng, grads_dev)
+    _LAST_GRADS['flat'] = grads_dev.cpu()
     R, GH = cfg.residual_channels, cfg.gate_channels // 2
     dev_act = {}
     for l in check_layers:
@@ -184,6 +190,25 @@ def test_c2_bench_geometry_b2_two_streams():
     e = rel_err(r['yhat'][:1], y_fp)
     print('   y_hat vs fp32 oracle (utterance 0): %.3e' % e)
     assert e < TOL_YHAT_FP32
+    # gradients against the FP32 oracle too (the reference arithmetic, no rounding emulation): the distance bf16 operands put
+    # between this engine's gradients and the reference's, on the whole batch with the same masks and the same ragged lengths
+    cfg, params, wav, c = r['cfg'], r['params'], r['wav'], r['c']
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    lengths = [11000, 9377]
+    counts = [n - 1 for n in lengths]; total = float(sum(counts))
+    for b in range(2):
+        masks = [torch.from_numpy(dropout_mask_rows(1234, l, b * 11000, 11000, 256, 0.05)).view(1, 11000, 256).permute(0, 2, 1).contiguous() for l in range(24)]
+        yb = O.step(leaf, cfg, wav[b:b + 1].view(1, 1, -1), c[b:b + 1], dropout_masks=masks)
+        (O.training_loss(cfg, yb, wav[b:b + 1].view(1, -1, 1), lengths[b:b + 1]) * (counts[b] / total)).backward()
+        del yb, masks
+    g_dev = download_grads(r['eng'], _LAST_GRADS['flat'])
+    g_fp = {k: (leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k])) for k in leaf}
+    gtot = rel_err(torch.cat([g_dev[k].flatten() for k in g_fp]), torch.cat([g_fp[k].flatten() for k in g_fp]))
+    worst = sorted(((rel_err(g_dev[k], g_fp[k]), k) for k in g_fp if float(g_fp[k].norm()) > 1e-6), reverse=True)
+    stack = [w for w in worst if not w[1].startswith('local_conditioning_upsampling')]
+    print('   gradients vs FP32 oracle: global rel-L2 %.3e; worst stack/head tensor %s %.3e; worst upsample-net tensor %s %.3e'
+          % (gtot, stack[0][1], stack[0][0], [w for w in worst if w not in stack][0][1], [w for w in worst if w not in stack][0][0]))
+    assert gtot < TOL_GRAD_FP32_GLOBAL and stack[0][0] < TOL_GRAD_FP32_TENSOR
 
 
 def test_c2_bench_geometry_b8():

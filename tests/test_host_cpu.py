@@ -235,6 +235,90 @@ def test_bucketed_gradient_allreduce_gloo(tmp_path):
         assert p.returncode == 0 and 'rank ok' in o, o[-2000:]
 
 
+_PRODUCT_DP_WORKER = r'''
+import sys, types, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/tacotron-2_amd')
+import torch.distributed as dist
+import hparams as H
+from wavenet_vocoder.models.wavenet import WaveNet
+from wavenet_vocoder.parallel import assert_replicas_in_sync, param_checksum
+rank = int(sys.argv[1])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=2)
+N = 4096
+class FakeEngine:
+    """The engine calls WaveNet.add_optimizer makes, on CPU tensors: a rank-dependent "backward", the bucket table, and clip -> Adam
+    -> EMA written with deterministic torch ops (what wn_optim_step does on the device, atomic-free since round 3)."""
+    n_params = N
+    def __init__(self): self.step_seen = 0
+    def train_bwd(self, grads):
+        g = torch.Generator().manual_seed(1000 * self.step_seen + rank)
+        grads.copy_(torch.randn(N, generator=g) * (10.0 if self.step_seen == 1 else 0.1))      # step 1: norms above the clip threshold
+        self.step_seen += 1
+    def grad_buckets(self): return [(2048, 2048), (1024, 1024), (0, 1024)]
+    def wait_bucket(self, i, stream): pass
+    def optim_step(self, p, g, m, v, ema, lr, step):
+        for lo in range(0, N, 512):                       # "variables" of 512 floats: per-variable clip_by_norm, clip_by_value
+            gs = g[lo:lo + 512]
+            gs = gs * 1.0 / torch.clamp(gs.norm(), min=1.0)
+            gs = gs.clamp(-0.5, 0.5)
+            m[lo:lo + 512].mul_(0.9).add_(gs, alpha=0.1); v[lo:lo + 512].mul_(0.999).addcmul_(gs, gs, value=0.001)
+            p[lo:lo + 512].sub_(lr * m[lo:lo + 512] / (v[lo:lo + 512].sqrt() + 1e-8))
+        ema.sub_((1 - 0.9999) * (ema - p))
+hp = H._build()
+model = WaveNet(hp)
+model.engine = FakeEngine()
+g0 = torch.Generator().manual_seed(7 + rank)              # replicas START different: build() broadcasts rank 0's parameters
+model.params = torch.randn(N, generator=g0)
+dist.broadcast(model.params, 0)
+model.grads = torch.zeros(N); model.adam_m = torch.zeros(N); model.adam_v = torch.zeros(N); model.ema_params = model.params.clone()
+model._dist = dist; model._world = 2; model._have_fwd = True
+for step in range(3):
+    model._have_fwd = True
+    assert model.add_optimizer(step) == step + 1
+    assert_replicas_in_sync(model.params, 'parameters'); assert_replicas_in_sync(model.adam_v, 'adam v'); assert_replicas_in_sync(model.ema_params, 'ema')
+other = [torch.zeros(N), torch.zeros(N)]
+dist.all_gather(other, model.params)
+assert torch.equal(other[0], other[1])                    # bit-identical replicas after three steps
+# the guard notices a single-ulp drift on one rank -- on BOTH ranks
+if rank == 1:
+    model.params.view(torch.int32)[17] += 1
+try:
+    assert_replicas_in_sync(model.params, 'parameters'); raise SystemExit('drift went unnoticed on rank %%d' %% rank)
+except RuntimeError as e:
+    assert 'diverged' in str(e)
+dist.barrier(); dist.destroy_process_group()
+print('rank ok')
+'''
+
+
+def test_product_add_optimizer_keeps_replicas_bit_identical_gloo(tmp_path):
+    """wavenet.py:553-613 as this tree runs it data parallel: the PRODUCT's WaveNet.add_optimizer (backward -> bucketed tower mean ->
+    clip / Adam / EMA) on two gloo ranks with a stand-in engine, three steps (one with norms above the clip threshold): parameters,
+    Adam slots and EMA stay bit-identical across ranks, and the checksum guard (parallel.assert_replicas_in_sync, called by the
+    training loop at every checkpoint interval) raises on every rank when one replica drifts by a single ulp."""
+    port = 33500 + (os.getpid() % 2000)
+    script = tmp_path / 'product_dp_worker.py'
+    script.write_text(_PRODUCT_DP_WORKER % {'root': ROOT, 'port': port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and 'rank ok' in o, o[-3000:]
+
+
+def test_late_scalars_are_read_one_step_behind():
+    """The training loop's host-side reads (train._LateScalars): the loss of step k is looked at after step k + 1 was enqueued."""
+    from wavenet_vocoder.train import _LateScalars
+    late = _LateScalars(2, torch.device('cpu'))
+    seen = []
+    for k in range(1, 5):
+        late.push(k, torch.tensor([float(k) * 0.5, 0.0]))
+        seen += late.pop_ready(keep=1 if k < 4 else 0)
+    assert [s for s, _ in seen] == [1, 2, 3, 4] and [v[0] for _, v in seen] == [0.5, 1.0, 1.5, 2.0]
+    late.push(9, torch.tensor([float('nan'), 1.0]))
+    (tag, (loss, bad)), = late.drain()
+    assert tag == 9 and np.isnan(loss) and bad == 1.0
+
+
 def test_host_formats_match_reference_execution(golden_dir, tmp_path):
     """Batch assembly, learning-rate schedules, wav writer and hop size against golden vectors produced by executing the
     reference's own feeder.py / wavenet.py / datasets/audio.py (oracle/gen_golden_host.py)."""
@@ -623,3 +707,25 @@ def test_bench_algorithmic_work_matches_the_scope_table():
         assert bench.alg_bytes_per_sample(hp) == nbytes, (w, bench.alg_bytes_per_sample(hp))
     hp, B, T = bench.build_hparams('c2')
     assert (B, T) == (8, 11000) and abs(6.0 * bench.mac_per_sample(hp) / 1e6 - 81.84) < 0.01
+
+
+def test_bench_traffic_constants_come_from_the_committed_pmc_summary():
+    """bench.py's `traffic` / `traffic_per_step` are not hand-copied constants any more -- they are loaded from
+    profiles/traffic.json, which tools/pmc_summary.py --traffic writes from the FETCH_SIZE / WRITE_SIZE passes.  Recompute the summary from
+    the committed per-kernel tables it names and require the same numbers; another batch geometry gets None, not a scaled guess."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench
+    import pmc_summary
+    t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    src = [os.path.join(ROOT, p) for p in t['sources']]
+    assert all(os.path.exists(p) for p in src), src
+    again = pmc_summary.traffic_summary(src[0], src[1])
+    got = bench.load_traffic('c2', 8, 11000)
+    assert got is not None
+    for k in ('bytes_per_step', 'fetch_x2_bytes_per_step', 'write_bytes_per_step', 'gate_bytes_per_launch'):
+        assert abs(again[k] - t[k]) <= 2e-3 * t[k], (k, again[k], t[k])            # (the .md tables keep 4 significant digits)
+        assert got[k] == t[k]
+    assert abs(sum(v['bytes_per_step'] for v in t['kernels'].values()) - t['bytes_per_step']) < 1.0
+    assert 20e9 < t['bytes_per_step'] < 60e9 and t['gate_launches_per_step'] == 48
+    assert bench.load_traffic('c2', 4, 11000) is None and bench.load_traffic('c5_stress', 8, 12000) is None

@@ -83,7 +83,7 @@ def _load_stack(path):
 
 
 def test_reference_executed_goldens_exist():
-    assert len(_STACK_FILES) >= 18, 'run oracle/gen_golden_stack.py in the container that has /root/reference'
+    assert len(_STACK_FILES) >= 20 and any('dropout' in p for p in _STACK_FILES), 'run oracle/gen_golden_stack.py in the container that has /root/reference'
 
 
 @pytest.mark.parametrize('path', _STACK_FILES, ids=[os.path.basename(p)[6:-4] for p in _STACK_FILES])
@@ -101,7 +101,15 @@ def test_stack_matches_reference_execution(path):
         gg = gg.reshape(-1) if cfg.use_speaker_embedding else gg.reshape(gg.shape[0], -1)
     c_up = O.upsample(params, cfg, c)
     np.testing.assert_allclose(c_up.numpy(), g['c_up'], rtol=1e-5, atol=1e-6)                 # wavenet.py:680-702
-    y = O.step(params, cfg, x, c, g=gg)
+    masks = None
+    if 'dropout_masks' in g.files:      # the keep masks the reference run drew (tf.layers.dropout executed on the stand-in, modules.py:484)
+        assert cfg.wavenet_dropout > 0
+        dm = torch.from_numpy(g['dropout_masks'])
+        masks = [dm[l] for l in range(dm.shape[0])]
+        assert len(masks) == cfg.layers and 0.0 < float(1.0 - dm.mean()) < 2.5 * cfg.wavenet_dropout + 0.05
+        y_off = O.step(params, cfg, x, c, g=gg)
+        assert not np.allclose(y_off.numpy(), g['y_hat'], rtol=1e-3, atol=1e-3)               # the masks matter
+    y = O.step(params, cfg, x, c, g=gg, dropout_masks=masks)
     np.testing.assert_allclose(y.numpy(), g['y_hat'], rtol=2e-5, atol=2e-6)                   # wavenet.py:650-721
     # masked training loss as WaveNet.add_loss wires it (wavenet.py:476-495, 632-638; modules.py:781-836), ragged lengths
     y_t = torch.from_numpy(g['ids']).long() if 'ids' in g.files else torch.from_numpy(g['wav']).unsqueeze(-1)

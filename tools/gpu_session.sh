@@ -1,0 +1,72 @@
+#!/bin/bash
+# One GPU-box session, parameterised (replaces the one-off gpu_r2*.sh scripts of round 2).
+#   bash tools/gpu_session.sh <tag> <stage> [<stage> ...]
+# stages:
+#   tests        full `pytest -m gpu` suite, verbose (-s keeps the measured distances), junit-free log
+#   tests:<expr> only the tests matching -k <expr>
+#   smoke        __graft_entry__.smoke()
+#   bench        default-flag bench line (what the driver runs) -> bench.json
+#   benchq       short bench (no synth / cpu baseline / other workloads) -> benchq.json
+#   ab:<name>=<ENV=V>[,<ENV=V>]   one A/B arm of the short bench (appends to ab.txt); `ab:base=` for the baseline
+#   kt           rocprofv3 kernel trace + stats of the bench step (live, two streams) -> kernel_stats.csv, timeline.txt
+#   serial       the same with every kernel alone on one stream (exclusive kernel times) -> serial_kernel_stats.csv
+#   pmc          FETCH_SIZE and WRITE_SIZE passes -> pmc_fetch.md, pmc_write.md, traffic.json (bench.py loads the committed copy)
+#   sq           SQ counter passes of the bench step -> pmc_sq.md
+#   harness      tools/gemm_harness + ablation + wgrad harness tables
+#   pipetrace    WN_PIPE_TRACE stage trace of the synthesis pipeline (B = 1, 8) -> pipe_trace_b*.txt
+#   other        10-step runs of the other workloads only
+TAG=${1:-s}; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+export WN_PARITY_REPORT_DIR=$OUT
+BQ="--no-cpu-baseline --no-synth --no-exclusive --no-other-workloads --sustained 0"
+for st in "$@"; do
+  cd $R
+  case $st in
+    tests) ( timeout 1500 python -m pytest tests -m gpu -q -s --maxfail=8 2>&1; echo "rc=$?" ) > $OUT/pytest_gpu_verbose.log; grep -E "passed|failed|error|rc=" $OUT/pytest_gpu_verbose.log | tail -5 ;;
+    tests:*) ( timeout 1200 python -m pytest tests -m gpu -q -s --maxfail=8 -k "${st#tests:}" 2>&1; echo "rc=$?" ) > $OUT/pytest_gpu_k.log; grep -E "passed|failed|error|rc=" $OUT/pytest_gpu_k.log | tail -5 ;;
+    smoke) ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) > $OUT/smoke.log; cat $OUT/smoke.log ;;
+    bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "rc=$?" >> $OUT/bench.err; cut -c1-400 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+    benchq) timeout 300 python bench.py --steps 40 --warmup 8 $BQ > $OUT/benchq.json 2> $OUT/benchq.err; cut -c1-300 $OUT/benchq.json ;;
+    ab:*) spec=${st#ab:}; name=${spec%%=*}; envs=$(echo "${spec#*=}" | tr ',' ' ')
+      ( env $envs timeout 240 python bench.py --steps 40 --warmup 8 $BQ 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', '%.3f ms/step' % d['ms_per_step'], 'gate frac %.3f (incl. wait %.3f)' % (d['roofline']['frac'], d['roofline']['frac_incl_queue_wait']))" ) >> $OUT/ab.txt 2>&1; tail -1 $OUT/ab.txt ;;
+    kt) cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o c2 -- python $R/bench.py --steps 5 --warmup 2 $BQ > $OUT/kt.log 2>&1; cd $R
+      f=$(find $OUT/kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv
+      f=$(find $OUT/kt -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python tools/timeline.py $f > $OUT/timeline.txt 2>&1
+      rm -rf $OUT/kt; head -14 $OUT/timeline.txt ;;
+    serial) cd /tmp; WN_SERIAL=1 WN_BATCH_PARTS=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -o c2 -- python $R/bench.py --steps 5 --warmup 2 $BQ > $OUT/serial.log 2>&1; cd $R
+      f=$(find $OUT/serial -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/serial_kernel_stats.csv
+      rm -rf $OUT/serial; head -12 $OUT/serial_kernel_stats.csv | cut -c1-150 ;;
+    pmc) cd /tmp
+      for c in FETCH_SIZE WRITE_SIZE; do
+        n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+        timeout 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -o c2 -- python $R/bench.py --steps 2 --warmup 1 $BQ > $OUT/pmc_$n.log 2>&1
+        f=$(find $OUT/pmc_$n -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f $OUT/pmc_$n.csv && python $R/tools/pmc_summary.py $f --md > $OUT/pmc_$n.md
+        rm -rf $OUT/pmc_$n
+      done
+      cd $R; python tools/pmc_summary.py --traffic $OUT/pmc_fetch.csv $OUT/pmc_write.csv --tag $TAG --fetch-name profiles/${TAG}_pmc_fetch.md --write-name profiles/${TAG}_pmc_write.md --out $OUT/traffic.json
+      rm -f $OUT/pmc_fetch.csv $OUT/pmc_write.csv ;;
+    sq) cd /tmp; i=0
+      for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES"; do
+        i=$((i+1)); timeout 400 rocprofv3 --pmc $set --output-format csv -d $OUT/sq$i -o c2 -- python $R/bench.py --steps 2 --warmup 1 $BQ > $OUT/sq$i.log 2>&1
+        f=$(find $OUT/sq$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $f --md > $OUT/pmc_sq$i.md
+        rm -rf $OUT/sq$i
+      done; cd $R ;;
+    harness) cd /tmp
+      for h in gemm_harness gemm_harness_ablate wgrad_harness; do [ -x $R/tools/$h ] && timeout 180 $R/tools/$h > $OUT/$h.txt 2>&1; done
+      cd $R; tail -40 $OUT/gemm_harness.txt ;;
+    pipetrace) for b in 1 8; do WN_PIPE_TRACE=1 timeout 200 python tools/pipe_trace.py $b > $OUT/pipe_trace_b$b.txt 2>&1; tail -4 $OUT/pipe_trace_b$b.txt; done ;;
+    other) timeout 400 python - > $OUT/other_workloads.json 2> $OUT/other.err <<'PY'
+import json, sys, os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+import bench, torch
+print(json.dumps({k: bench.measure_other_workload(k, torch.device('cuda', 0)) for k in ('default_hparams', 'c2_4stack', 'c5_stress')}, indent=1))
+PY
+      cut -c1-600 $OUT/other_workloads.json ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done
+find $OUT -name '*.csv' -size +8M -delete
+ls $OUT
