@@ -261,7 +261,7 @@ __global__ void wn_first_conv_bwd_ids(const int32_t* __restrict__ ids, const bf1
 // Two stages in a fixed order, no atomics (bit-reproducible): part[blk][0][c], part[blk][1][c], then wn_colsum2_reduce.
 // (Round 2's input-conv gradient walked 128 rows per block one 2-byte load at a time and finished with float atomics: 77 us alone,
 // 0.5 ms beside the weight-gradient kernels.  This one reads 16 B per lane: scalar-input d W / d b and the head-bias column sums.)
-#define WN_CS_MAXBLK 1024
+#define WN_CS_MAXBLK 512
 __global__ __launch_bounds__(256) void wn_colsum2_kernel(const bf16_t* __restrict__ M, int ld, int ncols, const float* __restrict__ xw,
                                                          int64_t rows, int rows_per_block, float* __restrict__ part) {
     __shared__ float red[2][2048];                   // [b | w][row lane][ncols]   (row lanes * ncols <= 2048)
@@ -292,25 +292,29 @@ __global__ __launch_bounds__(256) void wn_colsum2_kernel(const bf16_t* __restric
         part[((int64_t)blockIdx.x * 2 + w) * ncols + cix] = s;
     }
 }
-// out_b[c] = sum_blk part[blk][0][c] (c < nvalid), out_w[c] = sum_blk part[blk][1][c]; block = 32 columns x 8 block lanes, fixed order
-__global__ __launch_bounds__(256) void wn_colsum2_reduce(const float* __restrict__ part, int nblk, int ncols, int nvalid,
-                                                         float* __restrict__ out_b, float* __restrict__ out_w) {
-    __shared__ float red[8][64];
-    const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
-    const int cix = blockIdx.x * 32 + cl;
-    float s0 = 0.0f, s1 = 0.0f;
-    if (cix < ncols)
-        for (int b = bl; b < nblk; b += 8) {
-            if (out_b) s0 += part[((int64_t)b * 2) * ncols + cix];
-            if (out_w) s1 += part[((int64_t)b * 2 + 1) * ncols + cix];
+// out_b[c] = sum_blk part[blk][0][c] (c < nvalid), out_w[c] = sum_blk part[blk][1][c]; block = 16 columns x 2 sums x 32 block lanes
+// (1024 threads, 4 loads in flight each), combined in a fixed order
+__global__ __launch_bounds__(1024) void wn_colsum2_reduce(const float* __restrict__ part, int nblk, int ncols, int nvalid,
+                                                          float* __restrict__ out_b, float* __restrict__ out_w) {
+    __shared__ float red[32][33];
+    const int cw = threadIdx.x & 31, bl = threadIdx.x >> 5;          // cw: (column, which sum); bl: block lane
+    const int w = cw >> 4, cix = blockIdx.x * 16 + (cw & 15);
+    const bool on = cix < ncols && (w == 0 ? out_b != nullptr : out_w != nullptr);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (on) {
+        const float* p = part + (int64_t)w * ncols + cix;
+        int b = bl;
+        for (; b + 96 < nblk; b += 128) {
+            s0 += p[(int64_t)b * 2 * ncols]; s1 += p[(int64_t)(b + 32) * 2 * ncols]; s2 += p[(int64_t)(b + 64) * 2 * ncols]; s3 += p[(int64_t)(b + 96) * 2 * ncols];
         }
-    red[bl][cl] = s0; red[bl][32 + cl] = s1;
+        for (; b < nblk; b += 32) s0 += p[(int64_t)b * 2 * ncols];
+    }
+    red[bl][cw] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int w = threadIdx.x >> 5, cc = blockIdx.x * 32 + (threadIdx.x & 31);
+    if (threadIdx.x < 32) {
         float s = 0.0f;
-        for (int g = 0; g < 8; ++g) s += red[g][threadIdx.x];
-        if (cc < nvalid) { if (w == 0 && out_b) out_b[cc] = s; if (w == 1 && out_w) out_w[cc] = s; }
+        for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];
+        if (on && cix < nvalid) (w == 0 ? out_b : out_w)[cix] = s;
     }
 }
 // column sums (+ x-weighted column sums) of M [rows][ld] into out_b / out_w (either may be null); `slot` picks one of the two
@@ -321,7 +325,7 @@ int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const 
     const int nblk = cdiv(rows, rpb);
     float* part = c->cs_part + (size_t)slot * WN_CS_MAXBLK * 2 * 1024;
     hipLaunchKernelGGL(wn_colsum2_kernel, dim3(nblk), dim3(256), 0, st, M, ld, ncols, out_w ? xw : nullptr, rows, rpb, part);
-    hipLaunchKernelGGL(wn_colsum2_reduce, dim3(cdiv(ncols, 32)), dim3(256), 0, st, part, nblk, ncols, nvalid, out_b, out_w);
+    hipLaunchKernelGGL(wn_colsum2_reduce, dim3(cdiv(ncols, 16)), dim3(1024), 0, st, part, nblk, ncols, nvalid, out_b, out_w);
     WN_LAUNCH_CHECK(c);
     return WN_OK;
 }

@@ -809,9 +809,9 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     hipLaunchKernelGGL(wn_synth_pipe_kernel, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     WN_LAUNCH_CHECK(c);
     // the abort flag travels to pinned host memory behind the kernel; nobody waits for it here (wn_pipe_check / the next call read it)
-    if (const char* e = getenv("WN_PIPE_TEST_ABORT")) {      // test hook: raise the flag of the first `n` runs as a timed-out hand-off would
-        if (p->test_aborts++ < atoi(e)) WN_HIP(c, hipMemsetD32Async((hipDeviceptr_t)p->abort_dev, 999, 1, st));
-    } else p->test_aborts = 0;
+    if (const char* e = getenv("WN_PIPE_TEST_ABORT")) {      // test hook: raise the flag as a timed-out hand-off would, until `n` runs of this context were flagged in total
+        if (p->test_aborts < atoi(e)) { ++p->test_aborts; WN_HIP(c, hipMemsetD32Async((hipDeviceptr_t)p->abort_dev, 999, 1, st)); }
+    }
     hipLaunchKernelGGL(wn_pipe_sticky_kernel, dim3(1), dim3(64), 0, st, p->abort_dev);
     WN_HIP(c, hipMemcpyAsync(p->abort_host, p->abort_dev + 1, 4, hipMemcpyDeviceToHost, st));
     p->pending = true; c->synth_path = 2;

@@ -978,27 +978,44 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         constexpr int PROWS = Cfg::EPI_ROWS;                 // rows per pass (one 32-row tile of every wave column)
         const EpiArgs& e = a.e;
         const int h = lane >> 5;
+        // The barriers of the epilogue order LDS traffic only (no LDS-DMA is in flight any more: the last ring step drained vmcnt), so
+        // they must not drain the vector-memory counter: the global loads of a pass are issued BEFORE its two barriers and the stores
+        // of the previous pass stay in flight across them.
+        auto epi_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        // Item geometry.  A pass holds PROWS rows x MTILE channels; thread -> (row, 8 channels) items it = tid + k * NTH.  NTH is a multiple
+        // of the items per row, so a thread keeps ITS channel group and walks rows rl0 + k * RSTEP: every address is
+        // (wave-uniform base) + (32-bit lane offset), no 64-bit multiplies per item.
+        constexpr int NTH = Cfg::NW * 64;
+        auto unpack8 = [](const uint4 x, float* f) {
+            f[0] = bf2f((bf16_t)(x.x & 0xffff)); f[1] = bf2f((bf16_t)(x.x >> 16)); f[2] = bf2f((bf16_t)(x.y & 0xffff)); f[3] = bf2f((bf16_t)(x.y >> 16));
+            f[4] = bf2f((bf16_t)(x.z & 0xffff)); f[5] = bf2f((bf16_t)(x.z >> 16)); f[6] = bf2f((bf16_t)(x.w & 0xffff)); f[7] = bf2f((bf16_t)(x.w >> 16));
+        };
+        auto pack8 = [](const float* f) { return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7])); };
+        const int64_t tile_row0 = rowbase + t0;            // first row of this workgroup's time tile (wave-uniform)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int rl = wn * 32 + (lane & 31), ml = (wm * MT + i) * 32 + qd * 8 + h * 4;
-                    *reinterpret_cast<float4*>(lds + rl * PITCH + ml * 4) =
-                        make_float4(acc[i][j][qd * 4], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]);
-                }
-            __syncthreads();
             if constexpr (EPI == EPI_GATE) {
+                epi_barrier();
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int rl = wn * 32 + (lane & 31), ml = (wm * MT + i) * 32 + qd * 8 + h * 4;
+                        *reinterpret_cast<float4*>(lds + rl * PITCH + ml * 4) =
+                            make_float4(acc[i][j][qd * 4], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]);
+                    }
+                epi_barrier();
                 constexpr int GT = Cfg::MTILE / 2, C8 = GT / 8, ITEMS = PROWS * C8;
-                bf16_t* TS = (bf16_t*)e.out0; bf16_t* U = (bf16_t*)e.out1;      // (the bias is already in the accumulators)
-                for (int it = tid; it < ITEMS; it += Cfg::NW * 64) {
-                    const int rl = it / C8, c8 = it % C8;
-                    const int t = t0 + ((rl >> 5) * NT + j) * 32 + (rl & 31);
-                    if (t >= T) continue;
-                    const int gl = c8 * 8, ml = (gl >> 5) * 64 + (gl & 31);
-                    const int g = mblk * GT + gl;
+                static_assert(ITEMS % NTH == 0 && NTH % C8 == 0, "gate epilogue items");
+                constexpr int NIT = ITEMS / NTH, RSTEP = NTH / C8;
+                const int c8 = tid % C8, rl0 = tid / C8;
+                const int gl = c8 * 8, ml = (gl >> 5) * 64 + (gl & 31);
+                bf16_t* const TSb = (bf16_t*)e.out0 + tile_row0 * e.ld_out0 + mblk * GT + gl;      // (the bias is already in the accumulators)
+                bf16_t* const Ub = (bf16_t*)e.out1 + tile_row0 * e.ld_out1 + mblk * GT + gl;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int rl = rl0 + k * RSTEP;
+                    const int tr = ((rl >> 5) * NT + j) * 32 + (rl & 31);             // row inside the time tile
                     const float4 a0 = *reinterpret_cast<const float4*>(lds + rl * PITCH + ml * 4), a1 = *reinterpret_cast<const float4*>(lds + rl * PITCH + ml * 4 + 16);
                     const float4 b0 = *reinterpret_cast<const float4*>(lds + rl * PITCH + (ml + 32) * 4), b1 = *reinterpret_cast<const float4*>(lds + rl * PITCH + (ml + 32) * 4 + 16);
                     const float za[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, zb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
@@ -1009,39 +1026,68 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                         const float s0_ = fast_sigmoid(zb[2 * p]), s1_ = fast_sigmoid(zb[2 * p + 1]);
                         ps[p] = pack_bf2(s0_, s1_); pu[p] = pack_bf2(t0_ * s0_, t1_ * s1_);
                     }
-                    const int64_t row = rowbase + t;
-                    // saved for backward: sigmoid + u (tanh is recovered as u / sigmoid, gate_tanh_from)
-                    *reinterpret_cast<uint4*>(TS + row * e.ld_out0 + g) = make_uint4(ps[0], ps[1], ps[2], ps[3]);
-                    *reinterpret_cast<uint4*>(U + row * e.ld_out1 + g) = make_uint4(pu[0], pu[1], pu[2], pu[3]);
+                    if (t0 + tr < T) {
+                        // saved for backward: sigmoid + u (tanh is recovered as u / sigmoid, gate_tanh_from)
+                        *reinterpret_cast<uint4*>(TSb + (uint32_t)(tr * e.ld_out0)) = make_uint4(ps[0], ps[1], ps[2], ps[3]);
+                        *reinterpret_cast<uint4*>(Ub + (uint32_t)(tr * e.ld_out1)) = make_uint4(pu[0], pu[1], pu[2], pu[3]);
+                    }
                 }
             } else {
                 constexpr int C8 = Cfg::MTILE / 8, ITEMS = PROWS * C8;
-                for (int it = tid; it < ITEMS; it += Cfg::NW * 64) {
-                    const int rl = it / C8, c8 = it % C8;
-                    const int t = t0 + ((rl >> 5) * NT + j) * 32 + (rl & 31);
-                    if (t >= T) continue;
-                    const int m = mblk * Cfg::MTILE + c8 * 8;
-                    const int64_t row = rowbase + t;
+                static_assert(ITEMS % NTH == 0 && NTH % C8 == 0, "epilogue items");
+                constexpr int NIT = ITEMS / NTH, RSTEP = NTH / C8;
+                const int c8 = tid % C8, rl0 = tid / C8;
+                const int mo = mblk * Cfg::MTILE + c8 * 8;
+                // ---- every global load of the pass first (round 2 walked the items in a loop of load -> wait -> load -> wait -> compute ->
+                // store: 8 dependent HBM round trips per workgroup, which is what bounded the HBM-bound launches at ~4 TB/s with 16 waves
+                // per CU each holding 32 B in flight).  Rows past the end of the utterance read the last valid row (never stored).
+                uint4 l0[NIT], l1[NIT];
+                int trs[NIT];
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int rl = rl0 + k * RSTEP;
+                    trs[k] = ((rl >> 5) * NT + j) * 32 + (rl & 31);
+                    const int trc = min(trs[k], T - 1 - t0);
+                    l0[k] = make_uint4(0, 0, 0, 0); l1[k] = make_uint4(0, 0, 0, 0);
+                    if constexpr (EPI == EPI_DGATE) {
+                        l0[k] = *reinterpret_cast<const uint4*>((const bf16_t*)e.in1 + tile_row0 * e.ld_in0 + mo + (uint32_t)(trc * e.ld_in0));      // u = tanh * sigmoid
+                        l1[k] = *reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + tile_row0 * e.ld_in0 + mo + (uint32_t)(trc * e.ld_in0));      // sigmoid
+                    } else if constexpr (EPI == EPI_MASK_STORE) {
+                        l0[k] = *reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + tile_row0 * e.ld_in0 + mo + (uint32_t)(trc * e.ld_in0));
+                    } else {      // EPI_STORE_BF16 / EPI_DX: the residual operand, when there is one
+                        if (e.in0) l0[k] = *reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + tile_row0 * e.ld_in0 + mo + (uint32_t)(trc * e.ld_in0));
+                    }
+                }
+                epi_barrier();
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int rl = wn * 32 + (lane & 31), ml = (wm * MT + i) * 32 + qd * 8 + h * 4;
+                        *reinterpret_cast<float4*>(lds + rl * PITCH + ml * 4) =
+                            make_float4(acc[i][j][qd * 4], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]);
+                    }
+                epi_barrier();
+                bf16_t* const o0 = (bf16_t*)e.out0 + tile_row0 * e.ld_out0 + mo;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int rl = rl0 + k * RSTEP, tr = trs[k];
+                    const bool valid = t0 + tr < T;
                     const float4 a0 = *reinterpret_cast<const float4*>(lds + rl * PITCH + c8 * 32), a1 = *reinterpret_cast<const float4*>(lds + rl * PITCH + c8 * 32 + 16);
                     float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    auto unpack8 = [](const uint4 x, float* f) {
-                        f[0] = bf2f((bf16_t)(x.x & 0xffff)); f[1] = bf2f((bf16_t)(x.x >> 16)); f[2] = bf2f((bf16_t)(x.y & 0xffff)); f[3] = bf2f((bf16_t)(x.y >> 16));
-                        f[4] = bf2f((bf16_t)(x.z & 0xffff)); f[5] = bf2f((bf16_t)(x.z >> 16)); f[6] = bf2f((bf16_t)(x.w & 0xffff)); f[7] = bf2f((bf16_t)(x.w >> 16));
-                    };
-                    auto pack8 = [](const float* f) { return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7])); };
                     if constexpr (EPI == EPI_STORE_BF16) {        // (bias: already in the accumulators)
                         if (e.in0) {
-                            float x[8]; unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), x);
+                            float x[8]; unpack8(l0[k], x);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] += x[r];
                         }
 #pragma unroll
                         for (int r = 0; r < 8; ++r) { v[r] *= e.scale; if (e.relu) v[r] = fmaxf(v[r], 0.0f); }
                         const uint4 pk = pack8(v);
-                        *reinterpret_cast<uint4*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pk;
+                        if (valid) *reinterpret_cast<uint4*>(o0 + (uint32_t)(tr * e.ld_out0)) = pk;
                         if (e.out1) {     // dropout of the next layer's conv input (tf.layers.dropout, modules.py:484), from the ROUNDED value
                             float x[8], dd[8]; unpack8(pk, x);
-                            const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);      // % 8 == 0 (m % 8 == 0, drop_ld = R % 8 == 0): two whole quads
+                            const uint32_t e0 = (uint32_t)((tile_row0 + tr) * a.drop_ld + mo);      // % 8 == 0 (mo % 8 == 0, drop_ld = R % 8 == 0): two whole quads
                             uint32_t wq[4];
                             wn_drop_quad(a.key_lo, a.key_hi, e0 >> 2, wq[0], wq[1]); wn_drop_quad(a.key_lo, a.key_hi, (e0 >> 2) + 1, wq[2], wq[3]);
 #pragma unroll
@@ -1050,25 +1096,25 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                                 dd[2 * p] = ((w & 0xffffu) >= a.thresh16) ? x[2 * p] * a.keep_scale : 0.0f;
                                 dd[2 * p + 1] = ((w >> 16) >= a.thresh16) ? x[2 * p + 1] * a.keep_scale : 0.0f;
                             }
-                            *reinterpret_cast<uint4*>((bf16_t*)e.out1 + row * e.ld_out1 + m) = pack8(dd);
+                            if (valid) *reinterpret_cast<uint4*>((bf16_t*)e.out1 + tile_row0 * e.ld_out1 + mo + (uint32_t)(tr * e.ld_out1)) = pack8(dd);
                         }
                     } else if constexpr (EPI == EPI_DGATE) {
                         float uu[8], sg[8], da[8], db[8];
-                        unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in1 + row * e.ld_in0 + m), uu);      // u = tanh * sigmoid
-                        unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), sg);      // sigmoid
+                        unpack8(l0[k], uu); unpack8(l1[k], sg);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) gate_backward(v[r], uu[r], sg[r], da[r], db[r]);
-                        bf16_t* DZ = (bf16_t*)e.out0;
-                        *reinterpret_cast<uint4*>(DZ + row * e.ld_out0 + m) = pack8(da);
-                        *reinterpret_cast<uint4*>(DZ + row * e.ld_out0 + e.GH + m) = pack8(db);
+                        if (valid) {
+                            *reinterpret_cast<uint4*>(o0 + (uint32_t)(tr * e.ld_out0)) = pack8(da);
+                            *reinterpret_cast<uint4*>(o0 + e.GH + (uint32_t)(tr * e.ld_out0)) = pack8(db);
+                        }
                     } else if constexpr (EPI == EPI_MASK_STORE) {
-                        float ref[8]; unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), ref);
+                        float ref[8]; unpack8(l0[k], ref);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = (ref[r] > 0.0f) ? v[r] * e.scale : 0.0f;
-                        *reinterpret_cast<uint4*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pack8(v);
+                        if (valid) *reinterpret_cast<uint4*>(o0 + (uint32_t)(tr * e.ld_out0)) = pack8(v);
                     } else if constexpr (EPI == EPI_DX) {
                         if (a.thresh16 != 0) {
-                            const uint32_t e0 = (uint32_t)(row * a.drop_ld + m);
+                            const uint32_t e0 = (uint32_t)((tile_row0 + tr) * a.drop_ld + mo);
                             uint32_t wq[4];
                             wn_drop_quad(a.key_lo, a.key_hi, e0 >> 2, wq[0], wq[1]); wn_drop_quad(a.key_lo, a.key_hi, (e0 >> 2) + 1, wq[2], wq[3]);
 #pragma unroll
@@ -1079,13 +1125,13 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
                             }
                         }
                         if (e.in0) {
-                            float x[8]; unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)e.in0 + row * e.ld_in0 + m), x);
+                            float x[8]; unpack8(l0[k], x);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] += x[r];
                         }
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= e.scale;
-                        *reinterpret_cast<uint4*>((bf16_t*)e.out0 + row * e.ld_out0 + m) = pack8(v);
+                        if (valid) *reinterpret_cast<uint4*>(o0 + (uint32_t)(tr * e.ld_out0)) = pack8(v);
                     }
                 }
             }

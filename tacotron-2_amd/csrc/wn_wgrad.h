@@ -518,8 +518,18 @@ static inline void wn_wgrad_plan(WgBatchArgs& a) {
     int spu = cdiv(a.na > 1 ? 256 : 512, (int64_t)tpu * a.B * a.ngroups);
     const int max_spu = a.T / 256 > 0 ? a.T / 256 : 1;
     if (spu > max_spu) spu = max_spu;
-    if (a.spu_cap > 0 && spu > a.spu_cap) spu = a.spu_cap;
     if (spu < 1) spu = 1;
+    if (a.na > 1 && a.spu_cap == 0) {
+        // multi-A workgroups own their CU: a launch of W workgroups takes ceil(W / 256) rounds, and a last round that is mostly empty is
+        // paid in full (d [W_skip | W_out] at C2: 2 x 24 x 8 = 384 workgroups = 1.5 rounds, 25 % of the launch idle).  One or two more slabs
+        // per utterance (each costs a partial tile) when that brings the idle share of the rounds under 10 %.
+        auto idle = [&](int sp) { const int64_t w = (int64_t)tpu * a.B * a.ngroups * sp; const int64_t r = (w + 255) / 256; return (double)(r * 256 - w) / (double)(r * 256); };
+        int best = spu;
+        for (int sp = spu; sp <= spu + 2 && sp <= max_spu; ++sp)
+            if (idle(sp) < idle(best) - 0.05) best = sp;
+        if (idle(spu) > 0.10) spu = best;
+    }
+    if (a.spu_cap > 0 && spu > a.spu_cap) spu = a.spu_cap;
     a.slab = cdiv(cdiv(a.T, spu), WG2_KT) * WG2_KT;
     a.spu = cdiv(a.T, a.slab);
     a.nunits = a.ngroups * a.B * a.spu;
