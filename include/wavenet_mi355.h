@@ -50,6 +50,12 @@ enum wn_upsample_type {                                                         
 };
 enum wn_activation { WN_ACT_NONE = 0, WN_ACT_RELU = 1, WN_ACT_LEAKY_RELU = 2 };             /* hparams.py:220 */
 enum wn_lr_schedule { WN_LR_EXPONENTIAL = 0, WN_LR_NOAM = 1 };                              /* hparams.py:309 */
+/* Arithmetic of the teacher-forced forward (WaveNet.step, the training-mode loss value, evaluation):
+ *   WN_COMPUTE_BF16     bf16 MFMA operands, fp32 accumulation (BASELINE configs[1]'s training dtype; the only mode with a backward);
+ *   WN_COMPUTE_F32_FWD  the reference's own arithmetic -- fp32 activations, fp32 weights, fp32 accumulation (modules.py:306-320,
+ *                       wavenet.py:650-721) -- for wn_train_fwd's y_hat / loss.  wn_train_bwd returns WN_E_UNSUPPORTED after such a
+ *                       forward (gradients need the bf16 engine's saved activations); synthesis is unaffected. */
+enum wn_compute_dtype { WN_COMPUTE_BF16 = 0, WN_COMPUTE_F32_FWD = 1 };
 
 #define WN_MAX_UPSAMPLE 8
 
@@ -98,6 +104,7 @@ typedef struct wn_config {
      * the caller can all-reduce one piece while the next is computed.  <= 1 (single GPU): everything is final when the call ends and
      * the weight gradients run after the backward chain (measured 1.5 % faster than overlapping them when there is nothing to hide). */
     int32_t grad_buckets;
+    int32_t compute_dtype;          /* wn_compute_dtype (hparams mi355_compute_dtype: 'bf16' | 'fp32') */
 } wn_config;
 
 typedef struct wn_ctx wn_ctx;

@@ -175,6 +175,8 @@ struct wn_ctx {
     // synthesis state (lazy)
     struct Synth* synth = nullptr;
     void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)
+    void* f32 = nullptr;                  // fp32-forward state (wn_f32.hip), allocated on the first forward of a cfg.compute_dtype = WN_COMPUTE_F32_FWD context
+    bool fwd_was_f32 = false;
 };
 
 extern std::string g_create_err;
@@ -214,4 +216,7 @@ int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st);           // d W_g, d
 int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const float* xw, int64_t rows, float* out_b, float* out_w, int slot, hipStream_t st);
 size_t wn_wgrad_partial_need(wn_ctx* ctx);
 void wn_plan_buckets(wn_ctx* ctx);
+int wn_f32_forward(wn_ctx* ctx, hipStream_t st);                  // fp32-accurate forward into YHAT (wn_f32.hip)
+void wn_f32_free(wn_ctx* ctx);
+const float* wn_f32_debug(const wn_ctx* ctx, const char* name, int layer);
 int wn_sample_impl(wn_ctx* ctx, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st);

@@ -332,6 +332,14 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
     if ((rc = wn_upsample_fwd(c, nullptr, c->fc, c->fB, c->fTc, st))) return rc;     // wavenet.py:680-702
     if ((rc = wn_first_conv(c, st))) return rc;                                      // wavenet.py:705
     if ((rc = wn_gbias_fwd(c, c->fB, st))) return rc;                                // wavenet.py:669-678
+    c->fwd_was_f32 = (c->cfg.compute_dtype == WN_COMPUTE_F32_FWD);
+    if (c->fwd_was_f32) {      // the reference's fp32 arithmetic for y_hat / the loss value (wn_f32.hip); no saved activations for a backward
+        if ((rc = wn_f32_forward(c, st))) return rc;
+        if (y_hat_out) WN_HIP(c, hipMemcpyAsync(y_hat_out, c->YHAT, (size_t)c->fB * c->O * c->fT * 4, hipMemcpyDeviceToDevice, st));
+        if (loss_out) { if ((rc = wn_loss_fwd_bwd(c, loss_out, st))) return rc; }
+        c->have_loss = false;
+        return WN_OK;
+    }
     rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first, int) {
         if (first) c->prof_rows = nb * c->fT;      // rows of one timed gate-GEMM launch (wn_profile_result)
         return fwd_part(c, b0, nb, s, c->prof && first);

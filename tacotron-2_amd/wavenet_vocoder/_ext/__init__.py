@@ -19,6 +19,7 @@ INPUT_TYPES = {'raw': 0, 'mulaw': 1, 'mulaw-quantize': 2}
 UPSAMPLE_TYPES = {'NearestNeighbor': 0, '2D': 1, 'SubPixel': 2, '1D': 3, 'Resize': 4}
 ACTIVATIONS = {None: 0, 'None': 0, 'Relu': 1, 'LeakyRelu': 2}
 LR_SCHEDULES = {'exponential': 0, 'noam': 1}
+COMPUTE_DTYPES = {'bf16': 0, 'fp32': 1, 'float32': 1}      # wn_compute_dtype: 'fp32' = the reference's arithmetic for the FORWARD (step / eval / loss value)
 STATUS = {0: 'WN_OK', -1: 'WN_E_ARG', -2: 'WN_E_SHAPE', -3: 'WN_E_HIP', -4: 'WN_E_UNSUPPORTED', -5: 'WN_E_STATE'}
 
 
@@ -45,6 +46,7 @@ class WnConfig(ctypes.Structure):
         ('weight_normalization', ctypes.c_int32),
         ('inference_only', ctypes.c_int32),
         ('grad_buckets', ctypes.c_int32),
+        ('compute_dtype', ctypes.c_int32),
     ]
 
 
@@ -173,6 +175,10 @@ def config_from_hparams(hp, max_batch, max_time, inference_only=False, grad_buck
         dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         grad_buckets = int(getattr(hp, 'mi355_grad_buckets', 3)) if dp else 1
     cfg.grad_buckets = int(grad_buckets)
+    dt = str(getattr(hp, 'mi355_compute_dtype', 'bf16'))
+    if dt not in COMPUTE_DTYPES:
+        raise ValueError("mi355_compute_dtype must be 'bf16' or 'fp32' (got %r)" % (dt,))
+    cfg.compute_dtype = COMPUTE_DTYPES[dt]
     return cfg
 
 

@@ -272,3 +272,74 @@ def test_ema_weights_flag_changes_what_synthesis_uses():
     model.use_ema_weights(False)
     a2 = model.incremental(None, c=c.cuda(), noise=nz_dev.cuda(), test_inputs=wav.cuda(), return_raw=True, check=True)[1].clone()
     assert torch.equal(a, a2) and rel_err(b, a) > 1e-2
+
+
+@pytest.mark.parametrize('name', ['c1_exact', 'paper_width_6_layers', 'gin_legacy_gauss'])
+def test_fp32_forward_mode_matches_the_fp32_oracle_per_layer(name):
+    """mi355_compute_dtype = 'fp32' (wn_config.compute_dtype = WN_COMPUTE_F32_FWD, csrc/wn_f32.hip): the reference's own arithmetic --
+    fp32 activations, weights and accumulation (modules.py:306-320, 471-521; wavenet.py:650-721) -- for the teacher-forced forward.
+    Every layer's input X_l and gate output U_l, y_hat and the masked loss against the FP32 oracle (no rounding emulation) with the
+    device's dropout masks: 1e-4 relative per layer is the stated tolerance (measured ~1e-6: summation order only).  The backward is
+    refused after such a forward."""
+    from wavenet_vocoder import _ext
+    from hip_util import oracle_masks
+    over, B, T = {
+        'c1_exact': (C1, 1, 2048),
+        'paper_width_6_layers': (dict(PAPER, layers=6, stacks=2), 2, 2200),
+        'gin_legacy_gauss': (dict(SMALL, layers=6, stacks=3, out_channels=2, legacy=True, residual_legacy=True, upsample_type='SubPixel', wavenet_dropout=0.1,
+                                  gin_channels=16, use_speaker_embedding=True, n_speakers=4, log_scale_min_gauss=float(np.log(1e-7))), 3, 320),
+    }[name]
+    hp = make_hp(**dict(over, mi355_compute_dtype='fp32'))
+    cfg = oracle_cfg(hp)
+    assert T % cfg.hop == 0
+    eng = _ext.Engine(hp, B, T)
+    params = O.init_params(cfg, seed=5339, bias_scale=0.05)
+    eng.pack_weights(upload_params(eng, params))
+    wav, c = synth_batch(cfg, B, T, seed=3)
+    lengths = [T] + [T - 37 * (i + 1) for i in range(B - 1)]
+    ln = torch.tensor(lengths, dtype=torch.int32).cuda()
+    g = None
+    if cfg.gin_channels > 0:
+        g = torch.tensor([1, 3, 0][:B], dtype=torch.int32)
+        eng.set_global_condition(g.cuda())
+    if cfg.input_type == 'mulaw-quantize':
+        ids = torch.from_numpy(M.mulaw_quantize(wav.numpy())).int()
+        x_dev, y_dev = ids.cuda(), ids.cuda()
+        x_or = torch.nn.functional.one_hot(ids.long(), cfg.quantize_channels).float().permute(0, 2, 1).contiguous(); y_or = ids.long()
+    else:
+        x_dev, y_dev = wav.view(B, 1, T).contiguous().cuda(), wav.view(B, T, 1).contiguous().cuda()
+        x_or, y_or = wav.view(B, 1, T), wav.view(B, T, 1)
+    loss = torch.zeros(1, device='cuda'); yhat = torch.empty(B, cfg.out_channels, T, device='cuda')
+    seed = 777
+    eng.train_fwd(x_dev, c.cuda(), y_dev, ln, seed, loss, yhat)
+    torch.cuda.synchronize()
+    masks = oracle_masks(seed, cfg, B, T) if cfg.wavenet_dropout > 0 else None
+    with torch.no_grad():
+        y, aux = O.step(params, cfg, x_or, c, dropout_masks=masks, emulate_bf16=False, return_aux=True, g=g)
+        lo = float(O.training_loss(cfg, y, y_or, lengths))
+    R, GH = cfg.residual_channels, cfg.gate_channels // 2
+    worst = 0.0
+    for l in range(cfg.layers):
+        xd = eng.debug_copy('X', l, B * T, R).cpu().view(B, T, R); ud = eng.debug_copy('U', l, B * T, GH).cpu().view(B, T, GH)
+        ex = rel_err(xd, aux['layer_in'][l].permute(0, 2, 1)); eu = rel_err(ud, aux['u'][l].permute(0, 2, 1))
+        mx = float((xd - aux['layer_in'][l].permute(0, 2, 1)).abs().max() / aux['layer_in'][l].abs().max())
+        worst = max(worst, ex, eu, mx)
+        assert ex < 1e-4 and eu < 1e-4 and mx < 1e-4, (l, ex, eu, mx)
+    ey = rel_err(yhat.cpu(), y)
+    print('\nfp32 forward mode [%s]: worst per-layer distance %.2e, y_hat rel-L2 %.2e, loss dev %.7f oracle %.7f' % (name, worst, ey, float(loss.item()), lo))
+    assert ey < 1e-4 and abs(float(loss.item()) - lo) <= 1e-4 * max(1.0, abs(lo))
+    grads = torch.empty(eng.n_params, device='cuda')
+    with pytest.raises(_ext.WnError, match='fp32 forward'):
+        eng.train_bwd(grads)
+    # the same engine configuration in bf16 is ~1e-3 .. 1e-2 away from this arithmetic: the mode is not a no-op
+    hp16 = make_hp(**over)
+    eng16 = _ext.Engine(hp16, B, T)
+    eng16.pack_weights(upload_params(eng16, params))
+    if g is not None:
+        eng16.set_global_condition(g.cuda())
+    y16 = torch.empty_like(yhat)
+    eng16.train_fwd(x_dev, c.cuda(), y_dev, ln, seed, loss, y16)
+    torch.cuda.synchronize()
+    e16 = rel_err(y16.cpu(), y)
+    print('   bf16 engine vs the same fp32 oracle: y_hat rel-L2 %.2e' % e16)
+    assert e16 > 20 * ey
