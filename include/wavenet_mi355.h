@@ -104,7 +104,7 @@ typedef struct wn_config {
      * the caller can all-reduce one piece while the next is computed.  <= 1 (single GPU): everything is final when the call ends and
      * the weight gradients run after the backward chain (measured 1.5 % faster than overlapping them when there is nothing to hide). */
     int32_t grad_buckets;
-    int32_t compute_dtype;          /* wn_compute_dtype (hparams mi355_compute_dtype: 'bf16' | 'fp32') */
+    int32_t compute_dtype;          /* enum wn_compute_dtype; hparams key mi355_compute_dtype: 'bf16' | 'fp32' */
 } wn_config;
 
 typedef struct wn_ctx wn_ctx;
