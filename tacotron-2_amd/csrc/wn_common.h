@@ -166,6 +166,7 @@ struct wn_ctx {
     // the serial backward chain; ev_bucket[k] = bucket k of the flat gradient is final (index WN_MAX_BUCKETS: the whole buffer)
 #define WN_MAX_BUCKETS 8
     hipStream_t st3 = nullptr; hipEvent_t ev_chain[WN_MAX_PARTS][WN_MAX_BUCKETS] = {}; hipEvent_t ev_bucket[WN_MAX_BUCKETS + 2] = {}; hipEvent_t ev_w0 = nullptr;
+    std::vector<hipEvent_t> ev_ls[2];      // lockstep schedule: the MFMA-bound launch of (part, layer) is done
     hipEvent_t ev_head[WN_MAX_PARTS] = {};   // d pre1 of a batch part exists (the head weight gradients may start under the chain)
     int nbuckets = 0, nbuckets_early = 0, nearly_live = 0; int bucket_lo[WN_MAX_BUCKETS + 2] = {}, bucket_hi[WN_MAX_BUCKETS + 2] = {};
     int64_t bucket_off[WN_MAX_BUCKETS + 2] = {}, bucket_cnt[WN_MAX_BUCKETS + 2] = {}; bool have_bwd = false;

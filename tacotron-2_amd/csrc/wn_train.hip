@@ -246,44 +246,51 @@ static int n_parts(wn_ctx* c) {
 }
 extern "C" int wn_set_batch_parts(wn_ctx* c, int32_t parts) { if (!c || parts < 0 || parts > WN_MAX_PARTS) return WN_E_ARG; c->parts_req = parts; return WN_OK; }
 
-// layers + skip sum + head of the utterances [b0, b0 + nb) on stream st (wavenet.py:706-721)
-static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
-    const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C;
+// one residual layer of the utterances [b0, b0 + nb), in two launches (wavenet.py:706-715 / modules.py:471-521):
+//   fwd_gate: dropout -> dilated taps -> conditioning 1x1 -> tanh * sigmoid   (MFMA-bound),
+//   fwd_out : out 1x1 + residual (+ the dropout-applied copy the next gate stages)   (HBM-bound)
+static int fwd_gate(wn_ctx* c, int l, int b0, int nb, hipStream_t st, bool prof) {
+    const int R = c->R, G = c->G, GH = c->GH, C = c->C;
+    const int64_t NT = c->NT;
+    const int d = c->dil[l];
+    const bf16_t* XDl = c->XD + (size_t)l * NT * R;      // dropout already applied by the producer
+    GemmArgs a; base_args(c, a, c->packs[l].w1, b0, nb);
+    a.nseg = 4;
+    a.seg[0] = seg(XDl, R, 0, R, -2 * d, 0);
+    a.seg[1] = seg(XDl, R, 0, R, -d, 0);
+    a.seg[2] = seg(XDl, R, 0, R, 0, 0);
+    a.seg[3] = seg(c->cbt, C, 0, C, 0, 0);
+    a.taps = c->packs[l].w1.kil ? 3 : 0;
+    if (c->gin > 0) { a.e.bias = c->gbias + (size_t)l * c->fB * G; a.e.bias_bstride = G; }      // + W_g^T g + b_g per utterance
+    else a.e.bias = c->b1sum + (size_t)l * G;
+    a.e.out0 = c->TS + (size_t)l * NT * GH; a.e.ld_out0 = GH;      // sigmoid half only (tanh = u / sigmoid in the backward)
+    a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
+    if (prof) { a.kprof = (c->kprof_dev && c->pev_used / 2 < WN_KPROF_MAX) ? c->kprof_dev + 2 * (c->pev_used / 2) : nullptr; prof_mark(c, st); }
+    int rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st);
+    if (prof) prof_mark(c, st);
+    return rc;
+}
+static int fwd_out(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
+    if (l + 1 >= c->L) return WN_OK;      // the residual output of the last layer is never consumed (wavenet.py:716)
+    const int R = c->R, GH = c->GH;
+    const int64_t NT = c->NT;
+    GemmArgs o; base_args(c, o, c->packs[l].wo, b0, nb);
+    o.nseg = 1; o.seg[0] = seg(c->U + (size_t)l * NT * GH, GH, 0, GH, 0, 0);
+    o.e.bias = c->params_dev + c->lay[l].out_b;
+    o.e.in0 = c->X + (size_t)l * NT * R; o.e.ld_in0 = R;
+    o.e.scale = c->res_scale;
+    o.e.out0 = c->X + (size_t)(l + 1) * NT * R; o.e.ld_out0 = R;
+    if (c->cfg.dropout > 0.0f) {
+        o.e.out1 = c->XD + (size_t)(l + 1) * NT * R; o.e.ld_out1 = R;
+        set_dropout(c, l + 1, o.key_lo, o.key_hi, o.thresh16, o.keep_scale, o.drop_ld);
+    }
+    return wn_launch_gemm<EPI_STORE_BF16>(c, o, c->packs[l].wo.M, st);
+}
+// skip sum + head of the utterances [b0, b0 + nb) (wavenet.py:716-721)
+static int fwd_tail(wn_ctx* c, int b0, int nb, hipStream_t st) {
+    const int L = c->L, GH = c->GH, S = c->S;
     const int64_t NT = c->NT;
     int rc;
-    const int drop = c->cfg.dropout > 0.0f ? 1 : 0;
-    for (int l = 0; l < L; ++l) {                                                    // wavenet.py:706-715 / modules.py:471-521
-        const int d = c->dil[l];
-        const bf16_t* Xl = c->X + (size_t)l * NT * R;
-        const bf16_t* XDl = c->XD + (size_t)l * NT * R;      // dropout already applied by the producer
-        GemmArgs a; base_args(c, a, c->packs[l].w1, b0, nb);
-        a.nseg = 4;
-        a.seg[0] = seg(XDl, R, 0, R, -2 * d, 0);
-        a.seg[1] = seg(XDl, R, 0, R, -d, 0);
-        a.seg[2] = seg(XDl, R, 0, R, 0, 0);
-        a.seg[3] = seg(c->cbt, C, 0, C, 0, 0);
-        a.taps = c->packs[l].w1.kil ? 3 : 0;
-        if (c->gin > 0) { a.e.bias = c->gbias + (size_t)l * c->fB * G; a.e.bias_bstride = G; }      // + W_g^T g + b_g per utterance
-        else a.e.bias = c->b1sum + (size_t)l * G;
-        a.e.out0 = c->TS + (size_t)l * NT * GH; a.e.ld_out0 = GH;      // sigmoid half only (tanh = u / sigmoid in the backward)
-        a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
-        if (prof) { a.kprof = (c->kprof_dev && c->pev_used / 2 < WN_KPROF_MAX) ? c->kprof_dev + 2 * (c->pev_used / 2) : nullptr; prof_mark(c, st); }
-        if ((rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st))) return rc;
-        if (prof) prof_mark(c, st);
-        if (l + 1 < L) {      // the residual output of the last layer is never consumed (wavenet.py:716)
-            GemmArgs o; base_args(c, o, c->packs[l].wo, b0, nb);
-            o.nseg = 1; o.seg[0] = seg(c->U + (size_t)l * NT * GH, GH, 0, GH, 0, 0);
-            o.e.bias = c->params_dev + c->lay[l].out_b;
-            o.e.in0 = Xl; o.e.ld_in0 = R;
-            o.e.scale = c->res_scale;
-            o.e.out0 = c->X + (size_t)(l + 1) * NT * R; o.e.ld_out0 = R;
-            if (drop) {
-                o.e.out1 = c->XD + (size_t)(l + 1) * NT * R; o.e.ld_out1 = R;
-                set_dropout(c, l + 1, o.key_lo, o.key_hi, o.thresh16, o.keep_scale, o.drop_ld);
-            }
-            if ((rc = wn_launch_gemm<EPI_STORE_BF16>(c, o, c->packs[l].wo.M, st))) return rc;
-        }
-    }
     {   // skip sum over all layers as one contraction, + ReLU (wavenet.py:716-719 first activation)
         GemmArgs a; base_args(c, a, c->wskip, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->U, GH, 0, GH, 0, 0); a.nrep = L; a.rep_stride = NT * GH;
@@ -302,6 +309,58 @@ static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
         a.e.bias = c->params_dev + c->fin2_b; a.e.out0 = c->YHAT; a.e.M_valid = c->O;
         if ((rc = wn_launch_gemm<EPI_STORE_F32_BOT>(c, a, c->wh2.M, st))) return rc;
     }
+    return WN_OK;
+}
+// layers + skip sum + head of the utterances [b0, b0 + nb) on stream st (wavenet.py:706-721)
+static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
+    int rc;
+    for (int l = 0; l < c->L; ++l) {
+        if ((rc = fwd_gate(c, l, b0, nb, st, prof))) return rc;
+        if ((rc = fwd_out(c, l, b0, nb, st))) return rc;
+    }
+    return fwd_tail(c, b0, nb, st);
+}
+
+// ---- lockstep schedule of the two half-batches (WN_LOCKSTEP, default on for 2 parts) ---------------------------------------------
+// Two independent streams drift into phase: both run their MFMA-bound launch (gate / d x) at the same time and then both their
+// HBM-bound one (out conv / d z), so that for half of the step ONE kernel has the GPU (rocprofv3: 5.7 of 10.9 ms with a single kernel in
+// flight) and neither resource is covered while the other is the limit.  Here the MFMA-bound launches of the two halves form ONE
+// alternating chain -- gate_A(l) -> gate_B(l) -> gate_A(l + 1) ... each waiting for the previous one's event -- and every HBM-bound launch
+// sits between two of its own stream's chain links, i.e. beside the OTHER half's MFMA-bound launch: out_A(l) || gate_B(l),
+// out_B(l) || gate_A(l + 1).  Same kernels, same arguments, same results; only cross-stream events are added.
+static bool lockstep_on() {
+    static const int v = [] { const char* e = getenv("WN_LOCKSTEP"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+static int lockstep_events(wn_ctx* c) {
+    while ((int)c->ev_ls[0].size() < c->L)
+        for (int k = 0; k < 2; ++k) { hipEvent_t e; WN_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_ls[k].push_back(e); }
+    return WN_OK;
+}
+static int fwd_lockstep(wn_ctx* c, hipStream_t st) {
+    int rc;
+    if ((rc = parts_setup(c, 2))) return rc;
+    if ((rc = lockstep_events(c))) return rc;
+    c->parts = 2;
+    hipStream_t sA = st, sB = c->st2;
+    const int bA = c->fB / 2, nA = bA, nB = c->fB - bA;      // part 0: [0, bA) on the caller's stream, part 1: [bA, fB) on the ctx-owned one
+    c->prof_rows = nA * c->fT;
+    WN_HIP(c, hipEventRecord(c->ev_fork, st));
+    WN_HIP(c, hipStreamWaitEvent(sB, c->ev_fork, 0));
+    for (int l = 0; l < c->L; ++l) {
+        if (l > 0) WN_HIP(c, hipStreamWaitEvent(sA, c->ev_ls[1][l - 1], 0));
+        if ((rc = fwd_gate(c, l, 0, nA, sA, c->prof))) return rc;
+        WN_HIP(c, hipEventRecord(c->ev_ls[0][l], sA));
+        if ((rc = fwd_out(c, l, 0, nA, sA))) return rc;
+        WN_HIP(c, hipStreamWaitEvent(sB, c->ev_ls[0][l], 0));
+        if ((rc = fwd_gate(c, l, bA, nB, sB, false))) return rc;
+        WN_HIP(c, hipEventRecord(c->ev_ls[1][l], sB));
+        if ((rc = fwd_out(c, l, bA, nB, sB))) return rc;
+    }
+    if ((rc = fwd_tail(c, 0, nA, sA))) return rc;
+    if ((rc = fwd_tail(c, bA, nB, sB))) return rc;
+    WN_HIP(c, hipEventRecord(c->ev_pjoin[1], sB));
+    WN_HIP(c, hipStreamWaitEvent(st, c->ev_pjoin[1], 0));
     return WN_OK;
 }
 
@@ -340,7 +399,8 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
         c->have_loss = false;
         return WN_OK;
     }
-    rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first, int) {
+    if (n_parts(c) == 2 && lockstep_on()) rc = fwd_lockstep(c, st);
+    else rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first, int) {
         if (first) c->prof_rows = nb * c->fT;      // rows of one timed gate-GEMM launch (wn_profile_result)
         return fwd_part(c, b0, nb, s, c->prof && first);
     });
@@ -354,9 +414,8 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
 // backward serial chain of the utterances [b0, b0 + nb): head dgrads, then d z / d h of every layer, top to bottom.
 // GXall[l] = rho * dL/dh_l is kept for every layer (rho = sqrt(.5) if residual_legacy), so that all weight gradients can be
 // contracted afterwards over the whole batch.
-static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
-    const int L = c->L, R = c->R, G = c->G, S = c->S, O = c->O;
-    const int64_t NT = c->NT;
+static int bwd_head(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
+    const int S = c->S, O = c->O;
     const int ldDY = (O + 15) / 16 * 16;
     int rc;
     {   // d pre1 = (W2 dY) * (H2 > 0)
@@ -372,39 +431,78 @@ static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
         a.e.in0 = c->R1; a.e.ld_in0 = S; a.e.out0 = c->DSKIP; a.e.ld_out0 = S;
         if ((rc = wn_launch_gemm<EPI_MASK_STORE>(c, a, c->wh1T.M, st))) return rc;
     }
-    const int drop = c->cfg.dropout > 0.0f ? 1 : 0;
-    for (int l = L - 1; l >= 0; --l) {
-        const int d = c->dil[l];
-        bf16_t* DZl = c->DZ + (size_t)l * NT * G;
-        const bf16_t* gx_up = c->GXall + (size_t)(l + 1) * NT * R;
-        bf16_t* gx_dn = c->GXall + (size_t)l * NT * R;
-        const bool top = (l == L - 1);
-        {   // d z: through the 1x1 convs and the gate (modules.py:510-515)
-            GemmArgs a; base_args(c, a, c->packs[l].w2T, b0, nb);
-            a.nseg = 2;
-            a.seg[0] = seg(gx_up, R, 0, R, 0, 0);
-            a.seg[1] = seg(c->DSKIP, S, 0, S, 0, 0);
-            a.e.in0 = c->TS + (size_t)l * NT * (G / 2); a.e.in1 = c->U + (size_t)l * NT * (G / 2); a.e.ld_in0 = G / 2; a.e.out0 = DZl; a.e.ld_out0 = G;
-            if ((rc = wn_launch_gemm<EPI_DGATE>(c, a, c->packs[l].w2T.M, st))) return rc;
-        }
-        {   // d h_l = dropout-mask * conv^T(dz) + residual path   (modules.py:484, 517-520)
-            GemmArgs a; base_args(c, a, c->packs[l].w1T, b0, nb);
-            a.nseg = 3;
-            a.seg[0] = seg(DZl, G, 0, G, 2 * d, 0);
-            a.seg[1] = seg(DZl, G, 0, G, d, 0);
-            a.seg[2] = seg(DZl, G, 0, G, 0, 0);
-            a.taps = c->packs[l].w1T.kil ? 3 : 0;
-            set_dropout(c, l, a.key_lo, a.key_hi, a.thresh16, a.keep_scale, a.drop_ld);
-            if (!drop) a.thresh16 = 0;
-            a.e.in0 = top ? nullptr : gx_up; a.e.ld_in0 = R;
-            a.e.scale = (l > 0) ? c->res_scale : 1.0f;
-            a.e.out0 = gx_dn; a.e.ld_out0 = R;
-            if ((rc = wn_launch_gemm<EPI_DX>(c, a, c->packs[l].w1T.M, st))) return rc;
-        }
-        // d z / d h of the layers [l, L) exist for this batch part: the weight gradients of a bucket whose lowest layer is l may start
-        for (int k = 0; k < c->nbuckets_early; ++k)
-            if (c->bucket_lo[k] == l) WN_HIP(c, hipEventRecord(c->ev_chain[part][k], st));
+    return WN_OK;
+}
+// d z of layer l: through the 1x1 convs and the gate (modules.py:510-515)   (HBM-bound)
+static int bwd_dgate(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
+    const int R = c->R, G = c->G, S = c->S;
+    const int64_t NT = c->NT;
+    GemmArgs a; base_args(c, a, c->packs[l].w2T, b0, nb);
+    a.nseg = 2;
+    a.seg[0] = seg(c->GXall + (size_t)(l + 1) * NT * R, R, 0, R, 0, 0);
+    a.seg[1] = seg(c->DSKIP, S, 0, S, 0, 0);
+    a.e.in0 = c->TS + (size_t)l * NT * (G / 2); a.e.in1 = c->U + (size_t)l * NT * (G / 2); a.e.ld_in0 = G / 2; a.e.out0 = c->DZ + (size_t)l * NT * G; a.e.ld_out0 = G;
+    return wn_launch_gemm<EPI_DGATE>(c, a, c->packs[l].w2T.M, st);
+}
+// d h_l = dropout-mask * conv^T(dz) + residual path   (modules.py:484, 517-520)   (MFMA-bound); then the bucket events of this part
+static int bwd_dx(wn_ctx* c, int l, int b0, int nb, hipStream_t st, int part) {
+    const int R = c->R, G = c->G;
+    const int64_t NT = c->NT;
+    const int d = c->dil[l];
+    bf16_t* DZl = c->DZ + (size_t)l * NT * G;
+    const bool top = (l == c->L - 1);
+    GemmArgs a; base_args(c, a, c->packs[l].w1T, b0, nb);
+    a.nseg = 3;
+    a.seg[0] = seg(DZl, G, 0, G, 2 * d, 0);
+    a.seg[1] = seg(DZl, G, 0, G, d, 0);
+    a.seg[2] = seg(DZl, G, 0, G, 0, 0);
+    a.taps = c->packs[l].w1T.kil ? 3 : 0;
+    set_dropout(c, l, a.key_lo, a.key_hi, a.thresh16, a.keep_scale, a.drop_ld);
+    if (!(c->cfg.dropout > 0.0f)) a.thresh16 = 0;
+    a.e.in0 = top ? nullptr : c->GXall + (size_t)(l + 1) * NT * R; a.e.ld_in0 = R;
+    a.e.scale = (l > 0) ? c->res_scale : 1.0f;
+    a.e.out0 = c->GXall + (size_t)l * NT * R; a.e.ld_out0 = R;
+    int rc = wn_launch_gemm<EPI_DX>(c, a, c->packs[l].w1T.M, st);
+    if (rc) return rc;
+    // d z / d h of the layers [l, L) exist for this batch part: the weight gradients of a bucket whose lowest layer is l may start
+    for (int k = 0; k < c->nbuckets_early; ++k)
+        if (c->bucket_lo[k] == l) WN_HIP(c, hipEventRecord(c->ev_chain[part][k], st));
+    return WN_OK;
+}
+static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
+    int rc;
+    if ((rc = bwd_head(c, b0, nb, st, part))) return rc;
+    for (int l = c->L - 1; l >= 0; --l) {
+        if ((rc = bwd_dgate(c, l, b0, nb, st))) return rc;
+        if ((rc = bwd_dx(c, l, b0, nb, st, part))) return rc;
     }
+    return WN_OK;
+}
+// lockstep backward (see fwd_lockstep): the d x launches of the two halves form one alternating chain, top layer first --
+// dx_A(l) -> dx_B(l) -> dx_A(l - 1) ... -- and each d z launch runs beside the other half's d x: dz_B(l) || dx_A(l), dz_A(l - 1) || dx_B(l)
+static int bwd_lockstep(wn_ctx* c, hipStream_t st) {
+    int rc;
+    if ((rc = parts_setup(c, 2))) return rc;
+    if ((rc = lockstep_events(c))) return rc;
+    c->parts = 2;
+    hipStream_t sA = st, sB = c->st2;
+    const int bA = c->fB / 2, nA = bA, nB = c->fB - bA;
+    WN_HIP(c, hipEventRecord(c->ev_fork, st));
+    WN_HIP(c, hipStreamWaitEvent(sB, c->ev_fork, 0));
+    if ((rc = bwd_head(c, 0, nA, sA, 0))) return rc;
+    if ((rc = bwd_head(c, bA, nB, sB, 1))) return rc;
+    for (int l = c->L - 1; l >= 0; --l) {
+        if ((rc = bwd_dgate(c, l, 0, nA, sA))) return rc;
+        if (l < c->L - 1) WN_HIP(c, hipStreamWaitEvent(sA, c->ev_ls[1][l + 1], 0));
+        if ((rc = bwd_dx(c, l, 0, nA, sA, 0))) return rc;
+        WN_HIP(c, hipEventRecord(c->ev_ls[0][l], sA));
+        if ((rc = bwd_dgate(c, l, bA, nB, sB))) return rc;
+        WN_HIP(c, hipStreamWaitEvent(sB, c->ev_ls[0][l], 0));
+        if ((rc = bwd_dx(c, l, bA, nB, sB, 1))) return rc;
+        WN_HIP(c, hipEventRecord(c->ev_ls[1][l], sB));
+    }
+    WN_HIP(c, hipEventRecord(c->ev_pjoin[1], sB));
+    WN_HIP(c, hipStreamWaitEvent(st, c->ev_pjoin[1], 0));
     return WN_OK;
 }
 
@@ -551,7 +649,8 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
         if ((rc = launch_wgrad(c, w, wst))) return rc;
     }
     // ---- the serial chain, per batch part (two streams)
-    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;
+    if (n_parts(c) == 2 && lockstep_on() && !serial) { if ((rc = bwd_lockstep(c, st))) return rc; }
+    else if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;
     // ---- head weight gradients over the whole batch (wavenet.py:136-149): d final_convolution_1 = R1^T dpre1 needs d pre1 of every
     // part, the first thing each chain stream computes (enqueued after the chain in host order, gated only by those events)
     for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_head[pk], 0));

@@ -15,6 +15,7 @@
 #   harness      tools/gemm_harness + ablation + wgrad harness tables
 #   pipetrace    WN_PIPE_TRACE stage trace of the synthesis pipeline (B = 1, 8) -> pipe_trace_b*.txt
 #   other        10-step runs of the other workloads only
+#   benchw:<w>   short bench of workload <w> (c2_4stack, default_hparams, c5_stress); ktw:<w> its rocprofv3 kernel statistics
 TAG=${1:-s}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -34,8 +35,12 @@ for st in "$@"; do
       ( env $envs timeout 240 python bench.py --steps 40 --warmup 8 $BQ 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', '%.3f ms/step' % d['ms_per_step'], 'gate frac %.3f (incl. wait %.3f)' % (d['roofline']['frac'], d['roofline']['frac_incl_queue_wait']))" ) >> $OUT/ab.txt 2>&1; tail -1 $OUT/ab.txt ;;
     kt) cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o c2 -- python $R/bench.py --steps 5 --warmup 2 $BQ > $OUT/kt.log 2>&1; cd $R
       f=$(find $OUT/kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv
-      f=$(find $OUT/kt -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python tools/timeline.py $f > $OUT/timeline.txt 2>&1
+      f=$(find $OUT/kt -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python tools/timeline.py $f 1 --detail > $OUT/timeline.txt 2>&1
       rm -rf $OUT/kt; head -14 $OUT/timeline.txt ;;
+    ktw:*) w=${st#ktw:}; cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktw -o w -- python $R/bench.py --workload $w --steps 10 --warmup 5 $BQ > $OUT/ktw_$w.log 2>&1; cd $R
+      f=$(find $OUT/ktw -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_$w.csv
+      rm -rf $OUT/ktw; tail -2 $OUT/ktw_$w.log | cut -c1-200; head -16 $OUT/kernel_stats_$w.csv | cut -c1-160 ;;
+    benchw:*) w=${st#benchw:}; timeout 300 python bench.py --workload $w --steps 20 --warmup 5 $BQ > $OUT/bench_$w.json 2> $OUT/bench_$w.err; cut -c1-200 $OUT/bench_$w.json ;;
     serial) cd /tmp; WN_SERIAL=1 WN_BATCH_PARTS=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -o c2 -- python $R/bench.py --steps 5 --warmup 2 $BQ > $OUT/serial.log 2>&1; cd $R
       f=$(find $OUT/serial -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/serial_kernel_stats.csv
       rm -rf $OUT/serial; head -12 $OUT/serial_kernel_stats.csv | cut -c1-150 ;;

@@ -71,6 +71,13 @@ def main():
     for t, d in pts:
         hist[depth] += t - lastt; lastt = t; depth += d
     print('kernels in flight: ' + '  '.join('%d: %.0f us' % (d, v / 1e3) for d, v in sorted(hist.items())))
+    # excerpt: every kernel of a window of the forward chain and of the backward chain (start, end, queue): how the two part streams interleave
+    if '--detail' in sys.argv:
+        for label, w0 in (('forward', marks[1][1] + 800000), ('backward', marks[2][1] + 800000)):
+            print('--- %s chain, 600 us window from %.1f us: start end dur queue kernel' % (label, (w0 - t0) / 1e3))
+            for s, e, n, qi in step:
+                if e > w0 and s < w0 + 600000:
+                    print('   %9.1f %9.1f %7.1f  q%s  %s' % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, qi, short(n)))
     # per kernel kind
     agg = defaultdict(lambda: [0, 0])
     for s, e, n, _ in step:
