@@ -594,6 +594,9 @@ def main():
             except Exception as e:          # never lose the training number to a synthesis problem
                 res['synthesis'] = {'error': str(e)[:300]}
         if world == 1 and not args.no_other_workloads and args.workload == 'c2':
+            # the headline engine's side streams must not exist while another engine is timed: streams are multiplexed onto a few
+            # hardware queues and merely existing ones serialise against the streams that carry the step
+            eng.close()
             res['other_workloads'] = {}
             for key in ('default_hparams', 'c5_stress'):
                 _log('other workload %s ...' % key)

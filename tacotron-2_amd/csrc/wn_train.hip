@@ -321,15 +321,19 @@ static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
     return fwd_tail(c, b0, nb, st);
 }
 
-// ---- lockstep schedule of the two half-batches (WN_LOCKSTEP, default on for 2 parts) ---------------------------------------------
+// ---- lockstep schedule of the two half-batches (A/B switch WN_LOCKSTEP=1; OFF by default: measured slower) ----------------------------
 // Two independent streams drift into phase: both run their MFMA-bound launch (gate / d x) at the same time and then both their
 // HBM-bound one (out conv / d z), so that for half of the step ONE kernel has the GPU (rocprofv3: 5.7 of 10.9 ms with a single kernel in
 // flight) and neither resource is covered while the other is the limit.  Here the MFMA-bound launches of the two halves form ONE
 // alternating chain -- gate_A(l) -> gate_B(l) -> gate_A(l + 1) ... each waiting for the previous one's event -- and every HBM-bound launch
 // sits between two of its own stream's chain links, i.e. beside the OTHER half's MFMA-bound launch: out_A(l) || gate_B(l),
 // out_B(l) || gate_A(l + 1).  Same kernels, same arguments, same results; only cross-stream events are added.
+// MEASURED (profiles/r4d_ab_lockstep.txt, r4d_timeline_lockstep.txt): 11.6 vs 10.06 ms/step.  The pairing works -- a half-batch gate
+// launch runs 58-65 us beside the other half's out conv, 28 % of MFMA peak instead of 23 % -- but every cross-stream event costs
+// ~15-24 us between the signalling kernel's end and the waiting kernel's start (96 of them per pass: 98 idle gaps, 0.93 ms, GPU busy
+// 92 % instead of 98.7 %).  Kept as a switch; the same pairing without the event latency needs both launches in ONE grid.
 static bool lockstep_on() {
-    static const int v = [] { const char* e = getenv("WN_LOCKSTEP"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("WN_LOCKSTEP"); return e ? atoi(e) : 0; }();
     return v != 0;
 }
 static int lockstep_events(wn_ctx* c) {
