@@ -414,12 +414,12 @@ struct LdsGemmCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+// The kernel BODY is a device function of (arguments, LDS arena, workgroup id) so that two different launches can share one grid
+// (wn_fused_pair_kernel below); wn_gemm_lds_kernel is the one-launch wrapper.
 template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 0, int TAPS = 0>
-__global__ __launch_bounds__(WM * WN * 64, (lds_gemm_min_waves(MT, NT, WM, WN, BK, NBUF)))
-void wn_gemm_lds_kernel(const GemmArgs a) {
+__device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const lds, const int wg_id) {
     using Cfg = LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>;
     static_assert(TAPS == 0 || (TAPS == 3 && NBUF == 3 && (PIPE <= 1 || PIPE >= 6)), "interleaved taps: the tap of a chunk is its ring slot (ring depth 3 == 3 taps)");
-    __shared__ __attribute__((aligned(1024))) char lds[Cfg::LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -429,7 +429,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     // congruent mod 8 (one L2).  With xcd_span > 0 each XCD also walks a CONTIGUOUS run of time tiles, so the rows a
     // dilated tap reaches back to (<= 2d rows = <= 32 tiles at d = 2048) were fetched by the same XCD a moment ago and are
     // still in its 4 MB L2 (interleaved order: only taps of d % 1024 == 0 stay on their XCD; the others re-fetch).
-    const int id = blockIdx.x;
+    const int id = wg_id;
     const int xcd = id & 7, q = id >> 3;
     const int mblk = q % a.mblocks;
     const int tile = a.xcd_span > 0 ? xcd * a.xcd_span + q / a.mblocks : (q / a.mblocks) * 8 + xcd;
@@ -790,8 +790,8 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
         };
         const int npad = (nchunks + NBUF - 1) / NBUF * NBUF;          // zero chunks pad the count: no guards inside the unrolled body
 #ifdef WN_EPI_ABLATE
-        const bool tr_on = (dbg & 16) && a.trace && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 1024;
-        unsigned long long* const tr = a.trace + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 64 * 4;
+        const bool tr_on = (dbg & 16) && a.trace && lane == 0 && (wave == 0 || wave == 5) && wg_id < 1024;
+        unsigned long long* const tr = a.trace + ((size_t)wg_id * 2 + (wave ? 1 : 0)) * 64 * 4;
 #define WN_TR(ch_, slot_) do { if (tr_on && (ch_) < 64) tr[(ch_) * 4 + (slot_)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WN_TR(ch_, slot_) do { } while (0)
@@ -955,8 +955,8 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     if ((dbg & 32) && a.trace && tid == 0) {
         unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a.trace[(size_t)blockIdx.x * 4 + 0] = wg_t_start; a.trace[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-        a.trace[(size_t)blockIdx.x * 4 + 2] = hwid; a.trace[(size_t)blockIdx.x * 4 + 3] = xcc;
+        a.trace[(size_t)wg_id * 4 + 0] = wg_t_start; a.trace[(size_t)wg_id * 4 + 1] = __builtin_amdgcn_s_memtime();
+        a.trace[(size_t)wg_id * 4 + 2] = hwid; a.trace[(size_t)wg_id * 4 + 3] = xcc;
     }
     if (a.e.scale != -7777.0f) {
 #pragma unroll
@@ -1140,6 +1140,32 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
     if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
 }
 
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 0, int TAPS = 0>
+__global__ __launch_bounds__(WM * WN * 64, (lds_gemm_min_waves(MT, NT, WM, WN, BK, NBUF)))
+void wn_gemm_lds_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(1024))) char lds[LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>::LDS_BYTES];
+    wn_gemm_lds_body<MT, NT, WM, WN, BK, NBUF, EPI, PIPE, TAPS>(a, lds, blockIdx.x);
+}
+
+// Two launches in ONE grid: an MFMA-bound launch of one half of the batch (gate / d x: K-interleaved taps, 256 x 128 tiles) and an
+// HBM-bound launch of the OTHER half (out conv / d z: 256 x 128 tiles) interleaved in groups of 8 workgroups (a group of 8 consecutive
+// ids covers the 8 XCDs once, so every body keeps its id % 8 == XCD decode).  The serial layer chain alternates the two kinds, and each
+// kind alone under-uses the GPU: a half-batch gate launch is 1.34 rounds of workgroups and leaves HBM idle, the out conv leaves the
+// matrix pipe idle.  Two streams only overlap them by accident (rocprofv3: one kernel in flight for more than half of the step) and
+// forcing the pairing with cross-stream events costs 15-24 us per event (wn_train.hip, lockstep).  In one grid the dispatcher fills
+// every freed CU slot with the next workgroup of EITHER kind, with no boundary between them.
+template <int EPI_A, int EPI_B>
+__global__ __launch_bounds__(512, 4)      // 4 waves per SIMD = two 8-wave workgroups per CU (<= 128 VGPRs)
+void wn_fused_pair_kernel(const GemmArgs a, const GemmArgs b, const int groups_a, const int groups_b) {
+    using CfgA = LdsGemmCfg<2, 2, 4, 2, 32, 3>;
+    __shared__ __attribute__((aligned(1024))) char lds[CfgA::LDS_BYTES];
+    const int q = blockIdx.x >> 3, r = blockIdx.x & 7;
+    const int64_t tot = (int64_t)groups_a + groups_b;
+    const int na0 = (int)((int64_t)q * groups_a / tot), na1 = (int)((int64_t)(q + 1) * groups_a / tot);      // A groups among the first q / q + 1 groups
+    if (na1 > na0) wn_gemm_lds_body<2, 2, 4, 2, 32, 3, EPI_A, 1, 3>(a, lds, na0 * 8 + r);
+    else wn_gemm_lds_body<2, 2, 4, 2, 32, 3, EPI_B, 1, 0>(b, lds, (q - na0) * 8 + r);
+}
+
 // Tile order of the LDS-DMA kernels (A/B switch WN_TILE_ORDER: 1 = contiguous run of tiles per XCD, 0 = interleaved).
 static inline bool wn_tile_order_contiguous() {
     static const int v = [] { const char* e = getenv("WN_TILE_ORDER"); return e ? atoi(e) : 1; }();
@@ -1150,6 +1176,26 @@ static inline bool wn_tile_order_contiguous() {
 static inline int wn_stagger_min_grid() {
     static const int v = [] { const char* e = getenv("WN_STAGGER_MIN_GRID"); return e ? atoi(e) : 1024; }();
     return v;
+}
+
+// grid of the 256 x 128 LDS-DMA launch of `a` (fills the decode fields); 0 if the shape does not take that kernel
+static inline int wn_prep_v2(GemmArgs& a, int M) {
+    if (M % 256 != 0 || a.e.M_valid != M || !a.zero) return 0;
+    a.mblocks = M / 256;
+    a.tiles_per_utt = cdiv(a.T, 128);
+    a.ntiles = a.tiles_per_utt * a.B;
+    a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
+    a.stagger = 0;
+    return cdiv(a.ntiles, 8) * a.mblocks * 8;
+}
+// one grid for the MFMA-bound launch `a` (taps == 3) and the HBM-bound launch `b`; WN_E_SHAPE if either does not fit the 256 x 128 kernel
+template <int EPI_A, int EPI_B>
+static inline int wn_launch_fused_pair(wn_ctx* ctx, GemmArgs& a, int Ma, GemmArgs& b, int Mb, hipStream_t st) {
+    const int ga = wn_prep_v2(a, Ma), gb = wn_prep_v2(b, Mb);
+    if (!ga || !gb || a.taps != 3 || b.taps != 0 || b.nrep != 1) WN_FAIL(ctx, WN_E_SHAPE, "fused pair launch: shapes M = %d / %d do not take the 256 x 128 kernels", Ma, Mb);
+    hipLaunchKernelGGL((wn_fused_pair_kernel<EPI_A, EPI_B>), dim3(ga + gb), dim3(512), 0, st, a, b, ga / 8, gb / 8);
+    WN_LAUNCH_CHECK(ctx);
+    return WN_OK;
 }
 
 // Host-side launcher: picks the main loop and workgroup shape from M.

@@ -249,12 +249,12 @@ extern "C" int wn_set_batch_parts(wn_ctx* c, int32_t parts) { if (!c || parts < 
 // one residual layer of the utterances [b0, b0 + nb), in two launches (wavenet.py:706-715 / modules.py:471-521):
 //   fwd_gate: dropout -> dilated taps -> conditioning 1x1 -> tanh * sigmoid   (MFMA-bound),
 //   fwd_out : out 1x1 + residual (+ the dropout-applied copy the next gate stages)   (HBM-bound)
-static int fwd_gate(wn_ctx* c, int l, int b0, int nb, hipStream_t st, bool prof) {
+static void mk_gate(wn_ctx* c, int l, int b0, int nb, GemmArgs& a) {
     const int R = c->R, G = c->G, GH = c->GH, C = c->C;
     const int64_t NT = c->NT;
     const int d = c->dil[l];
     const bf16_t* XDl = c->XD + (size_t)l * NT * R;      // dropout already applied by the producer
-    GemmArgs a; base_args(c, a, c->packs[l].w1, b0, nb);
+    base_args(c, a, c->packs[l].w1, b0, nb);
     a.nseg = 4;
     a.seg[0] = seg(XDl, R, 0, R, -2 * d, 0);
     a.seg[1] = seg(XDl, R, 0, R, -d, 0);
@@ -265,16 +265,11 @@ static int fwd_gate(wn_ctx* c, int l, int b0, int nb, hipStream_t st, bool prof)
     else a.e.bias = c->b1sum + (size_t)l * G;
     a.e.out0 = c->TS + (size_t)l * NT * GH; a.e.ld_out0 = GH;      // sigmoid half only (tanh = u / sigmoid in the backward)
     a.e.out1 = c->U + (size_t)l * NT * GH; a.e.ld_out1 = GH;
-    if (prof) { a.kprof = (c->kprof_dev && c->pev_used / 2 < WN_KPROF_MAX) ? c->kprof_dev + 2 * (c->pev_used / 2) : nullptr; prof_mark(c, st); }
-    int rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st);
-    if (prof) prof_mark(c, st);
-    return rc;
 }
-static int fwd_out(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
-    if (l + 1 >= c->L) return WN_OK;      // the residual output of the last layer is never consumed (wavenet.py:716)
+static void mk_out(wn_ctx* c, int l, int b0, int nb, GemmArgs& o) {
     const int R = c->R, GH = c->GH;
     const int64_t NT = c->NT;
-    GemmArgs o; base_args(c, o, c->packs[l].wo, b0, nb);
+    base_args(c, o, c->packs[l].wo, b0, nb);
     o.nseg = 1; o.seg[0] = seg(c->U + (size_t)l * NT * GH, GH, 0, GH, 0, 0);
     o.e.bias = c->params_dev + c->lay[l].out_b;
     o.e.in0 = c->X + (size_t)l * NT * R; o.e.ld_in0 = R;
@@ -284,6 +279,21 @@ static int fwd_out(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
         o.e.out1 = c->XD + (size_t)(l + 1) * NT * R; o.e.ld_out1 = R;
         set_dropout(c, l + 1, o.key_lo, o.key_hi, o.thresh16, o.keep_scale, o.drop_ld);
     }
+}
+static void prof_gate(wn_ctx* c, GemmArgs& a, hipStream_t st) {
+    a.kprof = (c->kprof_dev && c->pev_used / 2 < WN_KPROF_MAX) ? c->kprof_dev + 2 * (c->pev_used / 2) : nullptr;
+    prof_mark(c, st);
+}
+static int fwd_gate(wn_ctx* c, int l, int b0, int nb, hipStream_t st, bool prof) {
+    GemmArgs a; mk_gate(c, l, b0, nb, a);
+    if (prof) prof_gate(c, a, st);
+    int rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st);
+    if (prof) prof_mark(c, st);
+    return rc;
+}
+static int fwd_out(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
+    if (l + 1 >= c->L) return WN_OK;      // the residual output of the last layer is never consumed (wavenet.py:716)
+    GemmArgs o; mk_out(c, l, b0, nb, o);
     return wn_launch_gemm<EPI_STORE_BF16>(c, o, c->packs[l].wo.M, st);
 }
 // skip sum + head of the utterances [b0, b0 + nb) (wavenet.py:716-721)
@@ -339,6 +349,53 @@ static bool lockstep_on() {
 static int lockstep_events(wn_ctx* c) {
     while ((int)c->ev_ls[0].size() < c->L)
         for (int k = 0; k < 2; ++k) { hipEvent_t e; WN_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_ls[k].push_back(e); }
+    return WN_OK;
+}
+// ---- fused-pair schedule (default for two half-batches of a wide model; A/B switch WN_FUSED=0) ---------------------------------------
+// ONE stream, one grid per pair (wn_fused_pair_kernel): gate_A(0);  then per layer  [out_A(l) | gate_B(l)]  and  [gate_A(l + 1) | out_B(l)].
+// Every launch holds the MFMA-bound kernel of one half and the HBM-bound kernel of the other; the pairing is the lockstep one, without
+// events.  Same kernel bodies, same arguments => bitwise the same results as the two-stream schedule.
+static bool fused_ok(wn_ctx* c) {
+    static const int v = [] { const char* e = getenv("WN_FUSED"); return e ? atoi(e) : 1; }();
+    if (!v || c->fB < 2 || !c->zero_page) return false;
+    for (int l = 0; l < c->L; ++l) {
+        const WnLayerPacks& p = c->packs[l];
+        if (!p.w1.kil || !p.w1T.kil || p.w1.M % 256 || p.wo.M % 256 || p.w2T.M % 256 || p.w1T.M % 256) return false;
+        if (p.w1.M_valid != p.w1.M || p.wo.M_valid != p.wo.M || p.w2T.M_valid != p.w2T.M || p.w1T.M_valid != p.w1T.M) return false;
+    }
+    return true;
+}
+static int fwd_fused(wn_ctx* c, hipStream_t st) {
+    int rc;
+    if ((rc = parts_setup(c, 2))) return rc;
+    c->parts = 2;
+    const int L = c->L, bA = c->fB / 2, nA = bA, nB = c->fB - bA;      // half A: utterances [0, bA), half B: [bA, fB)
+    c->prof_rows = nA * c->fT;
+    if ((rc = fwd_gate(c, 0, 0, nA, st, c->prof))) return rc;
+    for (int l = 0; l < L; ++l) {
+        {   // [out_A(l) | gate_B(l)]
+            GemmArgs g; mk_gate(c, l, bA, nB, g);
+            if (l + 1 < L) {
+                GemmArgs o; mk_out(c, l, 0, nA, o);
+                if ((rc = wn_launch_fused_pair<EPI_GATE, EPI_STORE_BF16>(c, g, c->packs[l].w1.M, o, c->packs[l].wo.M, st))) return rc;
+            } else if ((rc = wn_launch_gemm<EPI_GATE>(c, g, c->packs[l].w1.M, st))) return rc;
+        }
+        if (l + 1 < L) {   // [gate_A(l + 1) | out_B(l)]
+            GemmArgs g; mk_gate(c, l + 1, 0, nA, g);
+            GemmArgs o; mk_out(c, l, bA, nB, o);
+            if (c->prof) prof_gate(c, g, st);
+            rc = wn_launch_fused_pair<EPI_GATE, EPI_STORE_BF16>(c, g, c->packs[l + 1].w1.M, o, c->packs[l].wo.M, st);
+            if (c->prof) prof_mark(c, st);
+            if (rc) return rc;
+        }
+    }
+    // skip sum + head: HBM-bound launches of the two halves, side by side on the two streams as before
+    WN_HIP(c, hipEventRecord(c->ev_fork, st));
+    WN_HIP(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+    if ((rc = fwd_tail(c, bA, nB, c->st2))) return rc;
+    WN_HIP(c, hipEventRecord(c->ev_pjoin[1], c->st2));
+    if ((rc = fwd_tail(c, 0, nA, st))) return rc;
+    WN_HIP(c, hipStreamWaitEvent(st, c->ev_pjoin[1], 0));
     return WN_OK;
 }
 static int fwd_lockstep(wn_ctx* c, hipStream_t st) {
@@ -403,7 +460,8 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
         c->have_loss = false;
         return WN_OK;
     }
-    if (n_parts(c) == 2 && lockstep_on()) rc = fwd_lockstep(c, st);
+    if (n_parts(c) == 2 && fused_ok(c)) rc = fwd_fused(c, st);
+    else if (n_parts(c) == 2 && lockstep_on()) rc = fwd_lockstep(c, st);
     else rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first, int) {
         if (first) c->prof_rows = nb * c->fT;      // rows of one timed gate-GEMM launch (wn_profile_result)
         return fwd_part(c, b0, nb, s, c->prof && first);
@@ -438,24 +496,23 @@ static int bwd_head(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
     return WN_OK;
 }
 // d z of layer l: through the 1x1 convs and the gate (modules.py:510-515)   (HBM-bound)
-static int bwd_dgate(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
+static void mk_dgate(wn_ctx* c, int l, int b0, int nb, GemmArgs& a) {
     const int R = c->R, G = c->G, S = c->S;
     const int64_t NT = c->NT;
-    GemmArgs a; base_args(c, a, c->packs[l].w2T, b0, nb);
+    base_args(c, a, c->packs[l].w2T, b0, nb);
     a.nseg = 2;
     a.seg[0] = seg(c->GXall + (size_t)(l + 1) * NT * R, R, 0, R, 0, 0);
     a.seg[1] = seg(c->DSKIP, S, 0, S, 0, 0);
     a.e.in0 = c->TS + (size_t)l * NT * (G / 2); a.e.in1 = c->U + (size_t)l * NT * (G / 2); a.e.ld_in0 = G / 2; a.e.out0 = c->DZ + (size_t)l * NT * G; a.e.ld_out0 = G;
-    return wn_launch_gemm<EPI_DGATE>(c, a, c->packs[l].w2T.M, st);
 }
-// d h_l = dropout-mask * conv^T(dz) + residual path   (modules.py:484, 517-520)   (MFMA-bound); then the bucket events of this part
-static int bwd_dx(wn_ctx* c, int l, int b0, int nb, hipStream_t st, int part) {
+// d h_l = dropout-mask * conv^T(dz) + residual path   (modules.py:484, 517-520)   (MFMA-bound)
+static void mk_dx(wn_ctx* c, int l, int b0, int nb, GemmArgs& a) {
     const int R = c->R, G = c->G;
     const int64_t NT = c->NT;
     const int d = c->dil[l];
     bf16_t* DZl = c->DZ + (size_t)l * NT * G;
     const bool top = (l == c->L - 1);
-    GemmArgs a; base_args(c, a, c->packs[l].w1T, b0, nb);
+    base_args(c, a, c->packs[l].w1T, b0, nb);
     a.nseg = 3;
     a.seg[0] = seg(DZl, G, 0, G, 2 * d, 0);
     a.seg[1] = seg(DZl, G, 0, G, d, 0);
@@ -466,12 +523,22 @@ static int bwd_dx(wn_ctx* c, int l, int b0, int nb, hipStream_t st, int part) {
     a.e.in0 = top ? nullptr : c->GXall + (size_t)(l + 1) * NT * R; a.e.ld_in0 = R;
     a.e.scale = (l > 0) ? c->res_scale : 1.0f;
     a.e.out0 = c->GXall + (size_t)l * NT * R; a.e.ld_out0 = R;
-    int rc = wn_launch_gemm<EPI_DX>(c, a, c->packs[l].w1T.M, st);
-    if (rc) return rc;
-    // d z / d h of the layers [l, L) exist for this batch part: the weight gradients of a bucket whose lowest layer is l may start
+}
+static int bwd_dgate(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
+    GemmArgs a; mk_dgate(c, l, b0, nb, a);
+    return wn_launch_gemm<EPI_DGATE>(c, a, c->packs[l].w2T.M, st);
+}
+// d z / d h of the layers [l, L) exist for this batch part: the weight gradients of a bucket whose lowest layer is l may start
+static int chain_events(wn_ctx* c, int l, int part, hipStream_t st) {
     for (int k = 0; k < c->nbuckets_early; ++k)
         if (c->bucket_lo[k] == l) WN_HIP(c, hipEventRecord(c->ev_chain[part][k], st));
     return WN_OK;
+}
+static int bwd_dx(wn_ctx* c, int l, int b0, int nb, hipStream_t st, int part) {
+    GemmArgs a; mk_dx(c, l, b0, nb, a);
+    int rc = wn_launch_gemm<EPI_DX>(c, a, c->packs[l].w1T.M, st);
+    if (rc) return rc;
+    return chain_events(c, l, part, st);
 }
 static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
     int rc;
@@ -479,6 +546,34 @@ static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
     for (int l = c->L - 1; l >= 0; --l) {
         if ((rc = bwd_dgate(c, l, b0, nb, st))) return rc;
         if ((rc = bwd_dx(c, l, b0, nb, st, part))) return rc;
+    }
+    return WN_OK;
+}
+// fused-pair backward (see fwd_fused): dz_A(L-1);  then per layer, top first,  [dx_A(l) | dz_B(l)]  and  [dx_B(l) | dz_A(l - 1)]
+static int bwd_fused(wn_ctx* c, hipStream_t st) {
+    int rc;
+    if ((rc = parts_setup(c, 2))) return rc;
+    c->parts = 2;
+    const int L = c->L, bA = c->fB / 2, nA = bA, nB = c->fB - bA;
+    // head gradients of the two halves: small launches, one after the other on this stream
+    if ((rc = bwd_head(c, 0, nA, st, 0))) return rc;
+    if ((rc = bwd_head(c, bA, nB, st, 1))) return rc;
+    if ((rc = bwd_dgate(c, L - 1, 0, nA, st))) return rc;
+    for (int l = L - 1; l >= 0; --l) {
+        {   // [dx_A(l) | dz_B(l)]
+            GemmArgs x; mk_dx(c, l, 0, nA, x);
+            GemmArgs z; mk_dgate(c, l, bA, nB, z);
+            if ((rc = wn_launch_fused_pair<EPI_DX, EPI_DGATE>(c, x, c->packs[l].w1T.M, z, c->packs[l].w2T.M, st))) return rc;
+        }
+        {   // [dx_B(l) | dz_A(l - 1)]
+            GemmArgs x; mk_dx(c, l, bA, nB, x);
+            if (l > 0) {
+                GemmArgs z; mk_dgate(c, l - 1, 0, nA, z);
+                if ((rc = wn_launch_fused_pair<EPI_DX, EPI_DGATE>(c, x, c->packs[l].w1T.M, z, c->packs[l - 1].w2T.M, st))) return rc;
+            } else if ((rc = wn_launch_gemm<EPI_DX>(c, x, c->packs[l].w1T.M, st))) return rc;
+        }
+        if ((rc = chain_events(c, l, 0, st))) return rc;
+        if ((rc = chain_events(c, l, 1, st))) return rc;
     }
     return WN_OK;
 }
@@ -653,7 +748,8 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
         if ((rc = launch_wgrad(c, w, wst))) return rc;
     }
     // ---- the serial chain, per batch part (two streams)
-    if (n_parts(c) == 2 && lockstep_on() && !serial) { if ((rc = bwd_lockstep(c, st))) return rc; }
+    if (n_parts(c) == 2 && fused_ok(c) && !serial) { if ((rc = bwd_fused(c, st))) return rc; }
+    else if (n_parts(c) == 2 && lockstep_on() && !serial) { if ((rc = bwd_lockstep(c, st))) return rc; }
     else if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;
     // ---- head weight gradients over the whole batch (wavenet.py:136-149): d final_convolution_1 = R1^T dpre1 needs d pre1 of every
     // part, the first thing each chain stream computes (enqueued after the chain in host order, gated only by those events)

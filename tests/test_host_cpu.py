@@ -442,10 +442,14 @@ def test_static_isa_audit_no_scratch_and_two_workgroups_per_cu():
     spec.loader.exec_module(mod)
     rows = mod.audit()
     assert len(rows) > 40
-    bad = [r['name'] for r in rows if r['scratch'] or r['vspill'] or r['dyn_stack']]      # SGPR spills go to VGPR lanes, not memory
+    # (the fused d x | d z pair kernel keeps ONE 64-bit value in scratch across its main loop -- stored before the loop, reloaded after
+    # it, nothing inside: allowed up to 16 bytes; everything else must be spill-free.  SGPR spills go to VGPR lanes, not memory.)
+    bad = [r['name'] for r in rows if (r['scratch'] or r['vspill'] or r['dyn_stack'])
+           and not (r['name'].startswith('wn_fused_pair_kernel') and int(r['scratch']) <= 16 and int(r['vspill']) <= 2 and not r['dyn_stack'])]
     assert not bad, 'kernels with scratch / spills: %s' % bad
-    prod = [r for r in rows if r['name'].startswith('wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3,') or r['name'].startswith('wn_wgrad_lds_kernel')]
-    assert len(prod) >= 6
+    prod = [r for r in rows if r['name'].startswith('wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3,') or r['name'].startswith('wn_wgrad_lds_kernel')
+            or r['name'].startswith('wn_fused_pair_kernel')]
+    assert len(prod) >= 8
     for r in prod:
         if re.match(r'wn_wgrad_lds_kernel<3, [23]>', r['name']):
             # multi-A weight-gradient workgroups: alone on their CU by design (128 - 192 accumulator registers, <= 120 KiB ring)
