@@ -351,12 +351,16 @@ static int lockstep_events(wn_ctx* c) {
         for (int k = 0; k < 2; ++k) { hipEvent_t e; WN_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_ls[k].push_back(e); }
     return WN_OK;
 }
-// ---- fused-pair schedule (default for two half-batches of a wide model; A/B switch WN_FUSED=0) ---------------------------------------
+// ---- fused-pair schedule (A/B switch WN_FUSED=1; OFF by default: measured slower) ----------------------------------------------------
 // ONE stream, one grid per pair (wn_fused_pair_kernel): gate_A(0);  then per layer  [out_A(l) | gate_B(l)]  and  [gate_A(l + 1) | out_B(l)].
 // Every launch holds the MFMA-bound kernel of one half and the HBM-bound kernel of the other; the pairing is the lockstep one, without
-// events.  Same kernel bodies, same arguments => bitwise the same results as the two-stream schedule.
+// events.  Same kernel bodies, same arguments => the same results as the two-stream schedule (57 parity tests green with it on).
+// MEASURED (profiles/r4e_ab_fused.txt, r4e_timeline_fused.txt): 11.2 vs 9.9 ms/step.  A fused [gate | out conv] grid takes 65-69 us and a
+// [d x | d z] grid 71-79 us -- less than the two kernels one after the other (94 / 98 us) but every grid drains completely before the next
+// one starts, so the serial chain pays 94 launch tails per pass; two free-running streams hide each kernel's tail under the other
+// stream's next launch and come out ahead (157 us per layer and direction for both halves).  C5 width: 44.2 vs 41.9 ms.
 static bool fused_ok(wn_ctx* c) {
-    static const int v = [] { const char* e = getenv("WN_FUSED"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("WN_FUSED"); return e ? atoi(e) : 0; }();
     if (!v || c->fB < 2 || !c->zero_page) return false;
     for (int l = 0; l < c->L; ++l) {
         const WnLayerPacks& p = c->packs[l];
