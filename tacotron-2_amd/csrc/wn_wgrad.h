@@ -480,8 +480,18 @@ __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(const WgBatchArgs 
     const int upg = a.B * a.spu;
     const float* p = a.partial + ((int64_t)grp * upg * rows_p + prow) * a.N + c4 * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < upg; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)k * rows_p * a.N);
+    const int64_t ustride = (int64_t)rows_p * a.N;
+    int k = 0;
+    for (; k + 4 <= upg; k += 4) {      // four partial tiles in flight per thread (the sum stays in unit order)
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)k * ustride), v1 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 1) * ustride);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 2) * ustride), v3 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 3) * ustride);
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+        s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+        s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; k < upg; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)k * ustride);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     const WgGroup& g = a.g[grp];

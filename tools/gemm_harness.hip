@@ -185,6 +185,20 @@ int main(int argc, char** argv) {
             a2.trace = nullptr; a2.stagger = 0;
         }
         for (int dbgf : {0, 1, 2, 3, 7}) { a2.stagger = dbgf ? -dbgf : 0; printf("  probe flags %d (1 noDMA 2 noLDSread 4 nobarrier 8 hotDMA): ", dbgf); TRY_GATE3(2, 2, 4, 2, 32, 3, 2) }
+        {   // SURVEY K3 probe (round 3): the MAIN LOOP of a 512-row tile -- what a fused gate + out-conv workgroup (all 512 gate channels of its
+            // time rows, u kept on chip) would run -- against the production 256 x 128 tile, same contraction (M = 512, K = 848, sequential
+            // segments, epilogue ablated).  No 512-row shape lets two workgroups share a CU: 512 x 64 needs K-chunks of 64 for its B tile to
+            // split over 8 waves (2-deep ring: 144 KB), 512 x 128 with K-chunks of 32 needs 120 KB (+ the u tile of the fused kernel).
+            a2.stagger = 0; a2.taps = 0;
+            GemmArgs a3 = a2; a3.e.out0 = TS2; a3.e.ld_out0 = G; a3.e.out1 = nullptr; a3.e.bias = bias;
+            for (int rnd = 0; rnd < 3; ++rnd) {
+                float t0 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_STORE_BF16, 1>(a3, M, 0); });
+                float t1k = time_ms([&] { launch_v2<4, 1, 4, 2, 64, 2, EPI_STORE_BF16, 1>(a3, M, 0); });
+                float t3k = time_ms([&] { launch_v2<4, 2, 4, 2, 32, 3, EPI_STORE_BF16, 1>(a3, M, 0); });
+                printf("K3 probe main loop only: 256x128 BK32 ring3 x2/CU %7.1f us %6.1f TF | 512x64 BK64 ring2 x1/CU %7.1f us %6.1f TF | 512x128 BK32 ring3 x1/CU %7.1f us %6.1f TF\n",
+                       t0 * 1e3, fl / t0 / 1e9, t1k * 1e3, fl / t1k / 1e9, t3k * 1e3, fl / t3k / 1e9);
+            }
+        }
 #endif
         a2.stagger = 0;
     }
