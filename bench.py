@@ -182,6 +182,20 @@ def cpu_synth_baseline(hp, steps=2200, seconds_budget=15.0):
     return out
 
 
+def other_workload_subprocess(key, device_index=0, hard_timeout=240):
+    import subprocess
+    code = ('import sys, json, torch; sys.path.insert(0, %r); import bench; torch.cuda.set_device(%d); '
+            'print("OTHERWL" + json.dumps(bench.measure_other_workload(%r, torch.device("cuda", %d))))' % (ROOT, device_index, key, device_index))
+    try:
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=hard_timeout)
+        for line in r.stdout.splitlines():
+            if line.startswith('OTHERWL'):
+                return json.loads(line[len('OTHERWL'):])
+        return {'error': 'failed: ' + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {'error': 'timed out after %d s' % hard_timeout}
+
+
 def cpu_full_batch_reference(workload, B, T):
     """The oracle on the WHOLE bench batch (not the bounded sample above): the GPU parity test of this geometry runs the oracle's forward +
     autograd backward on the same 8 x 11 000 batch on the GPU box's host cores and records its wall time; the newest committed record
@@ -594,16 +608,15 @@ def main():
             except Exception as e:          # never lose the training number to a synthesis problem
                 res['synthesis'] = {'error': str(e)[:300]}
         if world == 1 and not args.no_other_workloads and args.workload == 'c2':
-            # the headline engine's side streams must not exist while another engine is timed: streams are multiplexed onto a few
-            # hardware queues and merely existing ones serialise against the streams that carry the step
+            # In a FRESH process each: streams are multiplexed onto a few hardware queues in creation order, and by now this process has
+            # created and destroyed a dozen (engine side streams, synthesis contexts); an engine created here can get its two part
+            # streams on ONE queue and lose their overlap (measured: hparams.py defaults 6.46 ms/step in-process vs 3.77 in a new
+            # process, profiles/r4f_bench_default_flags.json vs r4f_other_workloads.json).  The headline engine is closed first.
             eng.close()
             res['other_workloads'] = {}
             for key in ('default_hparams', 'c5_stress'):
                 _log('other workload %s ...' % key)
-                try:
-                    res['other_workloads'][key] = measure_other_workload(key, device)
-                except Exception as e:          # never lose the headline to an extra
-                    res['other_workloads'][key] = {'error': str(e)[:300]}
+                res['other_workloads'][key] = other_workload_subprocess(key, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             _log('cpu baseline (oracle) ...')
             res['cpu_baseline'] = cpu_baseline_subprocess(args.workload)

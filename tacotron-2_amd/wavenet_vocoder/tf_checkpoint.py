@@ -13,6 +13,10 @@ Format (tensorflow/core/util/tensor_bundle, tensorflow/core/lib/io/table*, i.e. 
 The reference saves its variables under the names of their exponential-moving-average shadows
 (``<variable op name>/ExponentialMovingAverage``, wavenet_vocoder/train.py:67-83) plus ``global_step``.
 
+Targeted writers: ``tf.train.Saver`` of TensorFlow 1.0 - 1.15 with its default ``write_version = SaverDef.V2`` (what the reference's
+``train.py:67-87`` uses on TF 1.x): uncompressed index blocks, one or several data shards.  Not supported: the pre-1.0 single-file
+V1 format (``write_version = V1``), snappy-compressed index blocks (rejected with a message), TF-2 object-graph checkpoints.
+
 Verification status: no TensorFlow-written checkpoint is available offline.  The reader is exercised (a) against a fixture
 assembled byte by byte from the format documents by an INDEPENDENT script (oracle/gen_tf_bundle_fixture.py: own bit-serial CRC-32C
 pinned to the RFC 3720 known answers, own varint / proto / block / footer assembly; tests/golden/tf_bundle/), (b) against files
