@@ -330,17 +330,22 @@ def train(log_dir, args, hparams, input_path):
         # rank's feeder failed" flag, so that every rank leaves the loop at the SAME step instead of hanging in an all-reduce.
         late = _LateScalars(2, model.device)
         last_batch = None
+        feeder_error = None
         flag_const = (torch.zeros(1, device=model.device), torch.ones(1, device=model.device))     # (no H2D copy inside the loop)
         while not coord.should_stop() and step < args.wavenet_train_steps:
             start_time = time.time()
-            feeder_error = None
-            try:
-                batch = feeder.next_train_batch()
-                last_batch = batch
-            except RuntimeError as e:
-                if _dist() is None or world == 1 or last_batch is None:
-                    raise
-                feeder_error, batch = e, last_batch       # keep the collectives of this step matched; everyone stops right after
+            if feeder_error is None:
+                try:
+                    batch = feeder.next_train_batch()
+                    last_batch = batch
+                except RuntimeError as e:
+                    if _dist() is None or world == 1 or last_batch is None:
+                        raise
+                    feeder_error = e
+            if feeder_error is not None:
+                # keep this step's collectives matched with the last good batch and raise the flag.  The other ranks see it one step late,
+                # i.e. after they have enqueued one MORE step: this rank stays for that step too and everybody leaves at the same read.
+                batch = last_batch
             x, y, lengths, c, g = batch
             model.initialize(y, c, g, lengths, x=x)
             loss_t = model.add_loss()
@@ -350,13 +355,12 @@ def train(log_dir, args, hparams, input_path):
                 flag = flag.clone()
                 _dist().all_reduce(flag, op=_dist().ReduceOp.MAX)
             late.push(step, torch.cat([loss_t.reshape(1).float(), flag]))
-            if feeder_error is not None:
-                late.drain()
-                raise feeder_error
             prev = late.pop_ready(keep=1 if step < args.wavenet_train_steps else 0)     # the previous step's (the last step: its own)
             time_window.append(time.time() - start_time)
             for pstep, (loss, bad) in prev:
                 if bad > 0:
+                    if feeder_error is not None:
+                        raise feeder_error
                     raise RuntimeError('the feeder of another rank failed at step {}: stopping every rank'.format(pstep))
                 loss_window.append(loss)
                 message = 'Step {:7d} [{:.3f} sec/step, loss={:.5f}, avg_loss={:.5f}]'.format(pstep, time_window.average, loss, loss_window.average)

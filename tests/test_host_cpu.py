@@ -305,6 +305,82 @@ def test_product_add_optimizer_keeps_replicas_bit_identical_gloo(tmp_path):
         assert p.returncode == 0 and 'rank ok' in o, o[-3000:]
 
 
+_TRAIN_LOOP_WORKER = r'''
+import sys, types, os, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/tacotron-2_amd')
+import torch.distributed as dist
+rank, fail_at = int(sys.argv[1]), int(sys.argv[2])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=2)
+import hparams as H
+from wavenet_vocoder import train as T
+N = 256
+class FakeModel:
+    """What wavenet_vocoder.train.train() touches of WaveNet, on CPU tensors, with the product's collectives (loss mean, gradient mean)."""
+    def __init__(self, hp): self.device = torch.device('cpu'); self.global_step = 0; self.learning_rate = 1e-3; self.embedding_table = None; self.steps = []
+    def build(self, B, T):
+        self.params = torch.randn(N, generator=torch.Generator().manual_seed(3 + rank)); dist.broadcast(self.params, 0)
+        self.grads = torch.zeros(N); return self
+    def initialize(self, y, c, g, lengths, x=None): self._x = x
+    def add_loss(self):
+        l = self._x.mean().reshape(1).clone(); dist.all_reduce(l); return l / 2
+    def add_optimizer(self, step):
+        self.grads.copy_(torch.full((N,), float(self._x.mean()))); dist.all_reduce(self.grads); self.grads /= 2
+        self.params -= 0.01 * self.grads; self.global_step = step + 1; self.steps.append(self.global_step); return self.global_step
+    def state_dict(self): return {'params': self.params.clone(), 'global_step': self.global_step}
+class FakeFeeder:
+    def __init__(self, hp, B, T): self.i = 0; self.test_steps = 1
+    def start_threads(self, session=None): pass
+    def next_train_batch(self):
+        self.i += 1
+        if rank == 1 and fail_at and self.i >= fail_at: raise RuntimeError('feeder thread failed: missing file (injected)')
+        x = torch.full((2, 1, 8), 0.1 * self.i + rank)
+        return x, x.view(2, 8, 1), torch.full((2,), 8, dtype=torch.int32), torch.zeros(2, 4, 2), None
+    def next_eval_batch(self): return self.next_train_batch()
+model_box = []
+T.create_model = lambda name, hp: (model_box.append(FakeModel(hp)) or model_box[-1])
+T.SyntheticFeeder = FakeFeeder
+T.save_log = lambda *a, **k: None
+T.eval_step = lambda *a, **k: 0.0
+hp = H._build(); hp.parse('mi355_synthetic_data=True,wavenet_batch_size=4,max_time_steps=8,hop_size=4,upsample_scales=[2,2]')
+args = types.SimpleNamespace(base_dir=sys.argv[3], model='WaveNet', restore=False, wavenet_train_steps=7, checkpoint_interval=2, summary_interval=3,
+                             eval_interval=4, embedding_interval=100, eval_max_time=0)
+log_dir = os.path.join(sys.argv[3], 'logs'); os.makedirs(log_dir, exist_ok=True)
+ret = T.wavenet_train(args, log_dir, hp, 'no_such_map.txt')
+m = model_box[0]
+print('RESULT rank=%%d ret=%%s steps=%%d' %% (rank, 'ok' if ret else 'none', len(m.steps)))
+both = [torch.zeros(N), torch.zeros(N)]
+dist.all_gather(both, m.params)
+assert torch.equal(both[0], both[1]), 'replicas differ after the loop'
+dist.barrier(); dist.destroy_process_group()
+print('rank ok')
+'''
+
+
+@pytest.mark.parametrize('fail_at', [0, 4, 7])
+def test_training_loop_data_parallel_control_flow_gloo(tmp_path, fail_at):
+    """The PRODUCT training loop (wavenet_vocoder/train.py, mirror of the reference's train.py:345) on two gloo ranks with a stand-in
+    model / feeder: losses read one step late, the replica checksum guard at every checkpoint interval, rank-0-only logging behind
+    barriers -- and a feeder failure on ONE rank (at batch 4; at the last batch): the failing rank keeps its collectives matched with
+    its last good batch, every rank sees the flag at the same late read and leaves the loop after the SAME number of steps (nobody is
+    left inside an all-reduce), and the driver returns None like the reference's does after an exception (train.py:340-343)."""
+    port = 35500 + (os.getpid() % 2000) + fail_at
+    script = tmp_path / 'train_loop_worker.py'
+    script.write_text(_TRAIN_LOOP_WORKER % {'root': ROOT, 'port': port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(fail_at), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    res = []
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and 'rank ok' in o, o[-3000:]
+        res.append(re.search(r'RESULT rank=(\d) ret=(\w+) steps=(\d+)', o).groups())
+    steps = {int(r[2]) for r in res}
+    assert len(steps) == 1, res                                  # both ranks ran the same number of optimiser steps
+    if fail_at == 0:
+        assert steps == {7} and all(r[1] == 'ok' for r in res)
+        assert os.path.exists(os.path.join(str(tmp_path), 'logs', 'wave_pretrained', 'wavenet_model.ckpt-6.pt'))
+    else:
+        assert steps == {min(fail_at + 1, 7)} and all(r[1] == 'none' for r in res), res     # the failing step + the one the others had already enqueued
+
+
 def test_late_scalars_are_read_one_step_behind():
     """The training loop's host-side reads (train._LateScalars): the loss of step k is looked at after step k + 1 was enqueued."""
     from wavenet_vocoder.train import _LateScalars
