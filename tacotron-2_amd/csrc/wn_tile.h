@@ -1226,8 +1226,13 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             return WN_OK;
         }
     }
+    // A/B switch WN_MFMA_SMALL: 1 = an MFMA-bound taps launch (gate / d x) with fewer 256 x 128 tiles than workgroup slots (d x of a half
+    // batch: 344 for 512) takes 128 x 128 tiles instead (twice the workgroups, half the work each); 2 = every taps launch does
+    static const int mfma_small = [] { const char* e = getenv("WN_MFMA_SMALL"); return e ? atoi(e) : 0; }();
+    const bool small_taps = (EPI == EPI_GATE || EPI == EPI_DX) && a.taps == 3 && M % 128 == 0 &&
+                            (mfma_small >= 2 || (mfma_small == 1 && (int64_t)cdiv(a.T, 128) * a.B * (M / 256) < 512));
     if constexpr (EPI != EPI_STORE_F32_BOT) {
-        if (M % 256 == 0 && a.e.M_valid == M && a.zero) {
+        if (M % 256 == 0 && a.e.M_valid == M && a.zero && !small_taps) {
             // v2: 256 channels x 128 time rows per 8-wave workgroup, K-chunks of 32, 3-deep LDS-DMA ring, 2 workgroups per CU
             a.mblocks = M / 256;
             a.tiles_per_utt = cdiv(a.T, 128);
