@@ -44,6 +44,7 @@ WORKLOADS = {
     # name: (hparams overrides on top of paper_hparams, B per GPU, T)
     'c2': (dict(stacks=2), 8, 11000),
     'c2_4stack': (dict(), 8, 11000),
+    'c2_fp32': (dict(stacks=2, mi355_compute_dtype='fp32'), 8, 11000),      # C2 in the fp32 training mode (the reference's arithmetic; csrc/wn_f32.hip, vector-ALU SGEMM)
     'default_hparams': (None, 8, 11000),          # hparams.py defaults (Gaussian, R=128, SubPixel)
     'c5_stress': (dict(out_channels=2, residual_channels=512, gate_channels=1024, skip_out_channels=512, layers=30, stacks=3,
                        legacy=True, residual_legacy=True, upsample_type='SubPixel', upsample_scales=[15, 20], hop_size=300,
@@ -280,6 +281,8 @@ def measure_other_workload(key, device, steps=10, warmup=3):
     from wavenet_vocoder import _ext
     from wavenet_vocoder.models.modules import initialize_parameters
     hp, B, T = build_hparams(key)
+    if key.endswith('_fp32'):      # an accuracy mode on the vector ALU (~2 orders slower): three steps say what it costs
+        steps, warmup = 3, 1
     hop = int(np.prod(hp.upsample_scales)); T = T // hop * hop
     eng = _ext.Engine(hp, B, T, grad_buckets=1)
     flat = initialize_parameters(hp, eng.layout).to(device)
@@ -308,7 +311,7 @@ def measure_other_workload(key, device, steps=10, warmup=3):
     R, G, C = hp.residual_channels, hp.gate_channels, hp.cin_channels
     value = B * T / dt
     gate_tf = (2.0 * G * (3 * R + C) * rows / (k_ms / k_n * 1e-3) / 1e12) if k_n else None
-    out = {'workload_key': key, 'steps': steps, 'warmup': warmup, 'batch': B, 'time': T, 'layers': hp.layers, 'stacks': hp.stacks,
+    out = {'workload_key': key, 'dtype': 'f32' if getattr(hp, 'mi355_compute_dtype', 'bf16') == 'fp32' else 'bf16', 'steps': steps, 'warmup': warmup, 'batch': B, 'time': T, 'layers': hp.layers, 'stacks': hp.stacks,
            'R': R, 'G': G, 'S': hp.skip_out_channels, 'out_channels': hp.out_channels, 'params': int(eng.n_params),
            'ms_per_step': dt * 1e3, 'value': value, 'unit': 'audio_samples/s', 'final_loss': float(loss.item()),
            'train_tflops_algorithmic': 6.0 * mac_per_sample(hp) * value / 1e12,
@@ -614,7 +617,7 @@ def main():
             # process, profiles/r4f_bench_default_flags.json vs r4f_other_workloads.json).  The headline engine is closed first.
             eng.close()
             res['other_workloads'] = {}
-            for key in ('default_hparams', 'c5_stress'):
+            for key in ('default_hparams', 'c5_stress', 'c2_fp32'):
                 _log('other workload %s ...' % key)
                 res['other_workloads'][key] = other_workload_subprocess(key, local_rank)
         if world == 1 and not args.no_cpu_baseline:

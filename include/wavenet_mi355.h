@@ -50,12 +50,12 @@ enum wn_upsample_type {                                                         
 };
 enum wn_activation { WN_ACT_NONE = 0, WN_ACT_RELU = 1, WN_ACT_LEAKY_RELU = 2 };             /* hparams.py:220 */
 enum wn_lr_schedule { WN_LR_EXPONENTIAL = 0, WN_LR_NOAM = 1 };                              /* hparams.py:309 */
-/* Arithmetic of the teacher-forced forward (WaveNet.step, the training-mode loss value, evaluation):
- *   WN_COMPUTE_BF16     bf16 MFMA operands, fp32 accumulation (BASELINE configs[1]'s training dtype; the only mode with a backward);
- *   WN_COMPUTE_F32_FWD  the reference's own arithmetic -- fp32 activations, fp32 weights, fp32 accumulation (modules.py:306-320,
- *                       wavenet.py:650-721) -- for wn_train_fwd's y_hat / loss.  wn_train_bwd returns WN_E_UNSUPPORTED after such a
- *                       forward (gradients need the bf16 engine's saved activations); synthesis is unaffected. */
-enum wn_compute_dtype { WN_COMPUTE_BF16 = 0, WN_COMPUTE_F32_FWD = 1 };
+/* Arithmetic of training / the teacher-forced forward (WaveNet.step, add_loss, add_optimizer, evaluation):
+ *   WN_COMPUTE_BF16  bf16 MFMA operands, fp32 accumulation (BASELINE configs[1]'s training dtype; the tuned path);
+ *   WN_COMPUTE_F32   the reference's own arithmetic -- fp32 activations, fp32 weights, fp32 accumulation (modules.py:306-320,
+ *                    wavenet.py:650-721) -- for wn_train_fwd AND wn_train_bwd (vector-ALU SGEMMs, ~20x slower: an accuracy /
+ *                    validation mode; gradient buckets collapse to one).  Synthesis is unaffected. */
+enum wn_compute_dtype { WN_COMPUTE_BF16 = 0, WN_COMPUTE_F32 = 1 };
 
 #define WN_MAX_UPSAMPLE 8
 

@@ -208,7 +208,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     if (cfg->freq_axis_kernel_size % 2 == 0 || cfg->freq_axis_kernel_size > 9) WN_FAIL(z, WN_E_UNSUPPORTED, "freq_axis_kernel_size must be odd <= 9");
     if (cfg->max_batch <= 0 || cfg->max_time <= 0) WN_FAIL(z, WN_E_ARG, "max_batch/max_time must be positive");
     if (cfg->dropout < 0.f || cfg->dropout >= 1.f) WN_FAIL(z, WN_E_ARG, "dropout must be in [0,1)");
-    if (cfg->compute_dtype != WN_COMPUTE_BF16 && cfg->compute_dtype != WN_COMPUTE_F32_FWD) WN_FAIL(z, WN_E_ARG, "bad compute_dtype %d", cfg->compute_dtype);
+    if (cfg->compute_dtype != WN_COMPUTE_BF16 && cfg->compute_dtype != WN_COMPUTE_F32) WN_FAIL(z, WN_E_ARG, "bad compute_dtype %d", cfg->compute_dtype);
     int hop = 1; for (int i = 0; i < cfg->n_upsample; ++i) { if (cfg->upsample_scales[i] <= 0) WN_FAIL(z, WN_E_ARG, "bad upsample scale"); hop *= cfg->upsample_scales[i]; }
 
     wn_ctx* c = new wn_ctx();
@@ -367,7 +367,6 @@ extern "C" int wn_train_fwd(wn_ctx* c, const void* x, const float* cc, const voi
 extern "C" int wn_train_bwd(wn_ctx* c, float* grads, void* stream) {
     if (!c || !grads) return WN_E_ARG;
     if (!c->have_fwd) WN_FAIL(c, WN_E_STATE, "wn_train_bwd called without a preceding successful wn_train_fwd");
-    if (c->fwd_was_f32) WN_FAIL(c, WN_E_UNSUPPORTED, "wn_train_bwd after an fp32 forward (cfg.compute_dtype = WN_COMPUTE_F32_FWD): the backward runs on the bf16 engine's saved activations only");
     return wn_bwd_impl(c, grads, (hipStream_t)stream);
 }
 
@@ -447,7 +446,7 @@ extern "C" int wn_debug_copy(wn_ctx* c, const char* name, int32_t layer, float* 
     const int64_t NT = c->NT;
     const bf16_t* b = nullptr; const float* f = nullptr;
     std::string s = name;
-    if (c->cfg.compute_dtype == WN_COMPUTE_F32_FWD && (s == "X" || s == "U")) {
+    if (c->cfg.compute_dtype == WN_COMPUTE_F32 && (s == "X" || s == "U")) {
         f = wn_f32_debug(c, name, layer);
         if (!f) WN_FAIL(c, WN_E_STATE, "wn_debug_copy('%s'): no fp32 forward has run yet", name);
     }

@@ -176,8 +176,9 @@ struct wn_ctx {
     // synthesis state (lazy)
     struct Synth* synth = nullptr;
     void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)
-    void* f32 = nullptr;                  // fp32-forward state (wn_f32.hip), allocated on the first forward of a cfg.compute_dtype = WN_COMPUTE_F32_FWD context
+    void* f32 = nullptr;                  // fp32-forward state (wn_f32.hip), allocated on the first forward of a cfg.compute_dtype = WN_COMPUTE_F32 context
     bool fwd_was_f32 = false;
+    float* dy32_next = nullptr;           // the next wn_loss_run also writes d y_hat in fp32 here ([rows][ldDY]; fp32 training mode)
 };
 
 extern std::string g_create_err;
@@ -213,11 +214,15 @@ int wn_upsample_fwd(wn_ctx* ctx, const float* params_unused, const float* c, int
 int wn_weightnorm_apply(wn_ctx* ctx, const float* raw_params, hipStream_t st);     // raw (v, g, bias) -> params_dev (effective)
 int wn_weightnorm_grad(wn_ctx* ctx, float* raw_grads, hipStream_t st);             // deff (effective grads) -> raw grads
 int wn_gbias_fwd(wn_ctx* ctx, int B, hipStream_t st);                 // global-conditioning bias table of this batch
-int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st);           // d W_g, d b_g, d embedding
+int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st, bool have_colsum = false);           // d W_g, d b_g, d embedding
 int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const float* xw, int64_t rows, float* out_b, float* out_w, int slot, hipStream_t st);
 size_t wn_wgrad_partial_need(wn_ctx* ctx);
 void wn_plan_buckets(wn_ctx* ctx);
 int wn_f32_forward(wn_ctx* ctx, hipStream_t st);                  // fp32-accurate forward into YHAT (wn_f32.hip)
 void wn_f32_free(wn_ctx* ctx);
+int wn_f32_backward(wn_ctx* ctx, float* grads, hipStream_t st);       // fp32 backward of the last fp32 forward (wn_f32.hip)
+float* wn_f32_dy(wn_ctx* ctx);                                        // fp32 d y_hat buffer of the fp32 state (allocates it)
+int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t st);
+int wn_loss_fwd_bwd(wn_ctx* c, float* loss_out, hipStream_t st);
 const float* wn_f32_debug(const wn_ctx* ctx, const char* name, int layer);
 int wn_sample_impl(wn_ctx* ctx, const float* y_hat, int B, int T, const float* noise, void* out, hipStream_t st);

@@ -1,16 +1,20 @@
-// fp32-accurate FORWARD of the WaveNet stack (wn_config.compute_dtype = WN_COMPUTE_F32_FWD; hparams mi355_compute_dtype = 'fp32').
+// fp32 training mode: forward AND backward of the WaveNet stack in the reference's arithmetic (wn_config.compute_dtype = WN_COMPUTE_F32; hparams mi355_compute_dtype = 'fp32').
 //
 // The reference computes in fp32 end to end (modules.py:306-320, 471-521; wavenet.py:650-721).  The production tile engine multiplies
 // bf16 operands (BASELINE's prescribed training dtype), which leaves y_hat ~1e-2 rel-L2 from the fp32 arithmetic after 24 layers.  This
 // translation unit is the other option: the same forward -- input conv, dropout -> dilated taps -> conditioning -> gate -> out / skip 1x1,
 // skip sum, head -- with fp32 activations, fp32 weights read straight from the flat parameter buffer (TensorFlow [k][in][out] layouts:
-// no packing) and fp32 FMA accumulation in a fixed k order.  It serves WaveNet.step / evaluation / the training-mode loss value; the
-// BACKWARD stays on the bf16 engine's saved activations, so wn_train_bwd refuses a forward that ran here.  Not tuned: a 64 x 64 x 16
-// LDS-tiled SGEMM on the vector ALU (the f32 MFMA rate on gfx950 equals the f32 vector rate: nothing to gain from the matrix pipe).
+// no packing) and fp32 FMA accumulation in a fixed k order, AND its backward (replaces tf.gradients, wavenet.py:557, in the same
+// arithmetic): every data gradient as the same SGEMM with transposed weight strides, every weight gradient as a time contraction with
+// ordered partial sums (no atomics), the gate derivative from the saved fp32 pre-activations.  It serves WaveNet.step / evaluation and a
+// complete fp32 TRAINING step (wn_train_fwd + wn_train_bwd + the shared optimiser).  Not tuned: 64 x 64 x 16 LDS-tiled SGEMMs on the
+// vector ALU (the f32 MFMA rate on gfx950 equals the f32 vector rate: nothing to gain from the matrix pipe); 210 ms per C2 step (34 TFLOP/s algorithmic, profiles/r4i_other_workloads.json).
 #include "wn_common.h"
 
 struct F32State {
-    float *X = nullptr, *U = nullptr, *Z = nullptr, *SK = nullptr, *H1 = nullptr, *C32 = nullptr;
+    float *X = nullptr, *U = nullptr, *Z = nullptr, *SK = nullptr, *H1 = nullptr, *C32 = nullptr;      // forward: X [L][NT][R], U [L][NT][GH], Z [L][NT][G] (pre-activations)
+    float *DY = nullptr, *DH1 = nullptr, *DSK = nullptr, *GU = nullptr, *DZ = nullptr, *GX[2] = {nullptr, nullptr}, *DC = nullptr, *DCT = nullptr, *PART = nullptr;      // backward (lazy)
+    size_t part_floats = 0;
     size_t bytes = 0;
 };
 
@@ -20,7 +24,10 @@ struct SgemmArgs {
     const float* W; int32_t ldw;                 // W[k][m] row-major (the TF kernel slice)
     int32_t K, M;
     float* Out; int32_t ld_out;
-    int32_t accumulate;                          // Out = (accumulate ? Out : 0) + alpha * acc + bias + add, then * scale, then relu
+    int32_t wk, wm;                              // element strides of W along k / m (wk = ldw, wm = 1 unless transposed: the data gradients)
+    int32_t accumulate;                          // v = alpha * acc [dropout mask on the OUTPUT element]; Out = ((accumulate ? Out : 0) + v + bias + add) * scale, relu, * (mask > 0)
+    const float* mask; int32_t ld_mask;          // ReLU mask operand (the forward activation)
+    int32_t drop_on_out;                         // the dropout keys below mask the OUTPUT element (row, m) instead of the A operand (gradient wrt a dropped input)
     float alpha, scale;
     const float* bias; int32_t bias_bstride;     // bias[m] (+ utterance * bias_bstride: global conditioning)
     const float* add; int32_t ld_add;
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(256) void wn_f32_sgemm_kernel(const SgemmArgs a) {
                 const int k = k0 + ak + e;
                 if (k < a.K) {
                     float v = a.In[arow * a.ld_in + a.col0 + k];
-                    if (a.thresh16) {
+                    if (a.thresh16 && !a.drop_on_out) {
                         const uint32_t el = (uint32_t)(arow * a.drop_ld + a.col0 + k);
                         const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, el >> 1);
                         const uint32_t bits = (el & 1u) ? (w >> 16) : (w & 0xffffu);
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void wn_f32_sgemm_kernel(const SgemmArgs a) {
         float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (k0 + bk < a.K) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (m0 + bm + e < a.M) bv[e] = a.W[(int64_t)(k0 + bk) * a.ldw + m0 + bm + e];
+            for (int e = 0; e < 4; ++e) if (m0 + bm + e < a.M) bv[e] = a.W[(int64_t)(k0 + bk) * a.wk + (int64_t)(m0 + bm + e) * a.wm];
         }
         __syncthreads();
 #pragma unroll
@@ -103,11 +110,18 @@ __global__ __launch_bounds__(256) void wn_f32_sgemm_kernel(const SgemmArgs a) {
             if (m >= a.M) continue;
             float* o = a.out_bot ? a.Out + ((int64_t)b * a.M + m) * a.T + t : a.Out + row * a.ld_out + m;
             float v = a.alpha * acc[i][j];
+            if (a.thresh16 && a.drop_on_out) {
+                const uint32_t el = (uint32_t)(row * a.drop_ld + m);
+                const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, el >> 1);
+                const uint32_t bits = (el & 1u) ? (w >> 16) : (w & 0xffffu);
+                v = bits >= a.thresh16 ? v * a.keep_scale : 0.0f;
+            }
             if (a.accumulate) v += *o;
             if (a.bias) v += a.bias[(int64_t)b * a.bias_bstride + m];
             if (a.add) v += a.add[row * a.ld_add + m];
             v *= a.scale;
             if (a.relu) v = fmaxf(v, 0.0f);
+            if (a.mask && !(a.mask[row * a.ld_mask + m] > 0.0f)) v = 0.0f;
             *o = v;
         }
     }
@@ -145,7 +159,7 @@ __global__ void wn_f32_bias_relu(float* __restrict__ v, const float* __restrict_
 void wn_f32_free(wn_ctx* c) {
     F32State* s = (F32State*)c->f32;
     if (!s) return;
-    for (float* p : {s->X, s->U, s->Z, s->SK, s->H1, s->C32}) if (p) hipFree(p);
+    for (float* p : {s->X, s->U, s->Z, s->SK, s->H1, s->C32, s->DY, s->DH1, s->DSK, s->GU, s->DZ, s->GX[0], s->GX[1], s->DC, s->DCT, s->PART}) if (p) hipFree(p);
     delete s; c->f32 = nullptr;
 }
 static int f32_reserve(wn_ctx* c) {
@@ -154,11 +168,11 @@ static int f32_reserve(wn_ctx* c) {
     const int64_t NT = c->NT;
     WN_HIP(c, hipMalloc((void**)&s->X, (size_t)c->L * NT * c->R * 4));
     WN_HIP(c, hipMalloc((void**)&s->U, (size_t)c->L * NT * c->GH * 4));
-    WN_HIP(c, hipMalloc((void**)&s->Z, (size_t)NT * c->G * 4));
+    WN_HIP(c, hipMalloc((void**)&s->Z, (size_t)c->L * NT * c->G * 4));      // every layer's pre-activations: the gate derivative of the backward
     WN_HIP(c, hipMalloc((void**)&s->SK, (size_t)NT * c->S * 4));
     WN_HIP(c, hipMalloc((void**)&s->H1, (size_t)NT * c->S * 4));
     WN_HIP(c, hipMalloc((void**)&s->C32, (size_t)NT * c->C * 4));
-    s->bytes = (size_t)NT * 4 * ((size_t)c->L * (c->R + c->GH) + c->G + 2 * c->S + c->C);
+    s->bytes = (size_t)NT * 4 * ((size_t)c->L * (c->R + c->GH + c->G) + 2 * c->S + c->C);
     return WN_OK;
 }
 const float* wn_f32_debug(const wn_ctx* c, const char* name, int layer) {
@@ -178,7 +192,7 @@ static int sgemm(wn_ctx* c, SgemmArgs& a, hipStream_t st) {
 }
 static SgemmArgs mk(const float* In, int ld_in, int shift, const float* W, int ldw, int K, int M, float* Out, int ld_out) {
     SgemmArgs a; memset(&a, 0, sizeof a);
-    a.In = In; a.ld_in = ld_in; a.shift = shift; a.W = W; a.ldw = ldw; a.K = K; a.M = M; a.Out = Out; a.ld_out = ld_out; a.alpha = 1.0f; a.scale = 1.0f;
+    a.In = In; a.ld_in = ld_in; a.shift = shift; a.W = W; a.ldw = ldw; a.wk = ldw; a.wm = 1; a.K = K; a.M = M; a.Out = Out; a.ld_out = ld_out; a.alpha = 1.0f; a.scale = 1.0f;
     return a;
 }
 
@@ -199,8 +213,9 @@ int wn_f32_forward(wn_ctx* c, hipStream_t st) {
         const int d = c->dil[l];
         const float* Xl = s->X + (size_t)l * NT * R;
         float* Ul = s->U + (size_t)l * NT * GH;
+        float* Zl = s->Z + (size_t)l * NT * G;
         for (int tap = 0; tap < 3; ++tap) {      // z = b + sum_taps drop(x)(t - (2 - tap) d) W_tap    (modules.py:484-494; kernel index 2 is the current sample)
-            SgemmArgs a = mk(Xl, R, -(2 - tap) * d, P + c->lay[l].dil_k + (int64_t)tap * R * G, G, R, G, s->Z, G);
+            SgemmArgs a = mk(Xl, R, -(2 - tap) * d, P + c->lay[l].dil_k + (int64_t)tap * R * G, G, R, G, Zl, G);
             a.accumulate = tap > 0;
             if (tap == 0) {
                 if (c->gin > 0) { a.bias = c->gbias + (size_t)l * B * G; a.bias_bstride = G; }      // b_dil + b_cin + W_g^T g + b_g per utterance
@@ -210,10 +225,10 @@ int wn_f32_forward(wn_ctx* c, hipStream_t st) {
             if ((rc = sgemm(c, a, st))) return rc;
         }
         {   // + W_cin c   (modules.py:497-501)
-            SgemmArgs a = mk(s->C32, C, 0, P + c->lay[l].cin_k, G, C, G, s->Z, G); a.accumulate = 1;
+            SgemmArgs a = mk(s->C32, C, 0, P + c->lay[l].cin_k, G, C, G, Zl, G); a.accumulate = 1;
             if ((rc = sgemm(c, a, st))) return rc;
         }
-        hipLaunchKernelGGL(wn_f32_gate, dim3(cdiv(rows * GH, 256)), dim3(256), 0, st, s->Z, Ul, rows, GH);
+        hipLaunchKernelGGL(wn_f32_gate, dim3(cdiv(rows * GH, 256)), dim3(256), 0, st, Zl, Ul, rows, GH);
         {   // skip sum (wavenet.py:706-715 unrolled: the legacy factors are folded into skip_scale)
             SgemmArgs a = mk(Ul, GH, 0, P + c->lay[l].skip_k, S, GH, S, s->SK, S); a.accumulate = l > 0; a.alpha = c->skip_scale[l];
             if ((rc = sgemm(c, a, st))) return rc;
@@ -232,6 +247,261 @@ int wn_f32_forward(wn_ctx* c, hipStream_t st) {
     {   // final_convolution_2 -> y_hat [B][O][T]
         SgemmArgs a = mk(s->H1, S, 0, P + c->fin2_k, O, S, O, c->YHAT, 0); a.bias = P + c->fin2_b; a.out_bot = 1;
         if ((rc = sgemm(c, a, st))) return rc;
+    }
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
+// =============================================================================================== fp32 backward
+// Weight gradient: dW[k][m] = alpha * sum_rows A[row + shift][k] * Bm[row][m]  (contraction over TIME), per row slab into `part`
+// [slab][K][M]; wn_f32_wgrad_reduce sums the slabs in order into the TF-layout gradient tensor.  a_ones: A = 1 (K = 1: column sums = bias
+// gradients).  Dropout keys: the A operand is the dropout-applied layer input (modules.py:484).
+struct WgradF32Args {
+    const float* A; int32_t lda, shift, a_ones;
+    const float* Bm; int32_t ldb;
+    int32_t K, M;
+    float* part;
+    int32_t B, T, slab, slabs_per_utt;
+    uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;
+};
+__global__ __launch_bounds__(256) void wn_f32_wgrad_kernel(const WgradF32Args a) {
+    __shared__ float As[SG_K][SG_T + 4];       // [row in chunk][k]
+    __shared__ float Bs[SG_K][SG_T + 4];       // [row in chunk][m]
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * SG_T, m0 = blockIdx.y * SG_T;
+    const int b = blockIdx.z / a.slabs_per_utt, sl = blockIdx.z - b * a.slabs_per_utt;
+    const int t_lo = sl * a.slab, t_hi = min(a.T, t_lo + a.slab);
+    const int64_t rowbase = (int64_t)b * a.T;
+    const int tr = tid >> 4, tc = tid & 15;        // micro tile: k = tr*4.., m = tc*4..
+    const int lr = tid >> 4, lc = (tid & 15) * 4;  // staging: row lr of the chunk, 4 consecutive columns
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    for (int tc0 = t_lo; tc0 < t_hi; tc0 += SG_K) {
+        const int t = tc0 + lr;
+        float av[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (t < t_hi) {
+            const int ts = t + a.shift;
+            if (a.a_ones) { if (lc == 0) av[0] = 1.0f; }
+            else if (ts >= 0 && ts < a.T) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + lc + e;
+                    if (k < a.K) {
+                        float v = a.A[(rowbase + ts) * a.lda + k];
+                        if (a.thresh16) {
+                            const uint32_t el = (uint32_t)((rowbase + ts) * a.drop_ld + k);
+                            const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, el >> 1);
+                            const uint32_t bits = (el & 1u) ? (w >> 16) : (w & 0xffffu);
+                            v = bits >= a.thresh16 ? v * a.keep_scale : 0.0f;
+                        }
+                        av[e] = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (m0 + lc + e < a.M) bv[e] = a.Bm[(rowbase + t) * a.ldb + m0 + lc + e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { As[lr][lc + e] = av[e]; Bs[lr][lc + e] = bv[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SG_K; ++r) {
+            float x[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = As[r][tr * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = Bs[r][tc * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(x[i], w[j], acc[i][j]);
+        }
+    }
+    float* P = a.part + (int64_t)blockIdx.z * a.K * a.M;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + tr * 4 + i;
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int m = m0 + tc * 4 + j; if (m < a.M) P[(int64_t)k * a.M + m] = acc[i][j]; }
+    }
+}
+__global__ void wn_f32_wgrad_reduce(const float* __restrict__ part, int nslab, int K, int M, float* __restrict__ out, int ldo, float alpha, float* __restrict__ out2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)K * M) return;
+    float s = 0.0f;
+    for (int z = 0; z < nslab; ++z) s += part[(int64_t)z * K * M + i];
+    const int k = (int)(i / M), m = (int)(i - (int64_t)k * M);
+    out[(int64_t)k * ldo + m] = alpha * s;
+    if (out2) out2[(int64_t)k * ldo + m] = alpha * s;
+}
+// d z from d u and the saved pre-activations (modules.py:510 differentiated): da = g s (1 - t^2), db = g t s (1 - s)
+__global__ void wn_f32_gate_bwd(const float* __restrict__ GU, const float* __restrict__ Z, float* __restrict__ DZ, int64_t rows, int GH) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * GH) return;
+    const int64_t row = i / GH; const int g = (int)(i - row * GH);
+    const float t = tanhf(Z[row * 2 * GH + g]), s = 1.0f / (1.0f + expf(-Z[row * 2 * GH + GH + g])), gu = GU[i];
+    DZ[row * 2 * GH + g] = gu * s * (1.0f - t * t);
+    DZ[row * 2 * GH + GH + g] = gu * t * s * (1.0f - s);
+}
+// [B*T][C] -> [B][C][T]
+__global__ void wn_f32_transpose_back(const float* __restrict__ c32, float* __restrict__ cbt, int B, int C, int T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * C * T) return;
+    const int t = (int)(i % T); const int64_t bc = i / T; const int cc = (int)(bc % C), b = (int)(bc / C);
+    cbt[i] = c32[((int64_t)b * T + t) * C + cc];
+}
+// one-hot input convolution: d W[id][r] += g0[row][r]  (mu-law-quantize models; float atomics: a row scatter)
+__global__ void wn_f32_first_conv_bwd_ids(const int32_t* __restrict__ ids, const float* __restrict__ g0, float* __restrict__ dW, int64_t rows, int R) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * R) return;
+    const int64_t row = i / R; const int r = (int)(i - row * R);
+    unsafeAtomicAdd(&dW[(int64_t)ids[row] * R + r], g0[i]);
+}
+
+// colsum[b][g] = sum_t dz[b, t, g]  (global conditioning: the per-utterance bias gradient, modules.py:499-508); 64 columns x 4 time lanes, ordered
+__global__ __launch_bounds__(256) void wn_f32_colsum_utt(const float* __restrict__ DZ, float* __restrict__ colsum, int T, int G) {
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y, q = threadIdx.x >> 6;
+    __shared__ float red[4][64];
+    float a = 0.0f;
+    if (g < G) for (int t = q; t < T; t += 4) a += DZ[((int64_t)b * T + t) * G + g];
+    red[q][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (q == 0 && g < G) colsum[(int64_t)b * G + g] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+float* wn_f32_dy(wn_ctx* c) {
+    F32State* s = (F32State*)c->f32;
+    if (!s) return nullptr;
+    if (!s->DY) {
+        const int ldDY = (c->O + 15) / 16 * 16;
+        if (hipMalloc((void**)&s->DY, (size_t)c->NT * ldDY * 4) != hipSuccess) return nullptr;
+    }
+    return s->DY;
+}
+static int f32_reserve_bwd(wn_ctx* c) {
+    F32State* s = (F32State*)c->f32;
+    if (s->DZ) return WN_OK;
+    const int64_t NT = c->NT;
+    WN_HIP(c, hipMalloc((void**)&s->DH1, (size_t)NT * c->S * 4));
+    WN_HIP(c, hipMalloc((void**)&s->DSK, (size_t)NT * c->S * 4));
+    WN_HIP(c, hipMalloc((void**)&s->GU, (size_t)NT * c->GH * 4));
+    WN_HIP(c, hipMalloc((void**)&s->DZ, (size_t)NT * c->G * 4));
+    for (int k = 0; k < 2; ++k) WN_HIP(c, hipMalloc((void**)&s->GX[k], (size_t)NT * c->R * 4));
+    WN_HIP(c, hipMalloc((void**)&s->DC, (size_t)NT * c->C * 4));
+    WN_HIP(c, hipMalloc((void**)&s->DCT, (size_t)NT * c->C * 4));
+    const int maxk = std::max(std::max(c->R, c->GH), std::max(c->S, c->C)), maxm = std::max(std::max(c->G, c->S), std::max(c->R, c->O));
+    const int slabs = c->maxB * cdiv(c->maxT, 2048);
+    s->part_floats = (size_t)slabs * maxk * maxm;
+    WN_HIP(c, hipMalloc((void**)&s->PART, s->part_floats * 4));
+    return WN_OK;
+}
+// dW (TF layout, row pitch ldo) = alpha * A^T Bm over all rows; optional second target (the twin bias of the gate pre-activation)
+static int wgrad32(wn_ctx* c, const float* A, int lda, int shift, int K, const float* Bm, int ldb, int M, float* out, int ldo, float alpha,
+                   int drop_layer, float* out2, hipStream_t st) {
+    F32State* s = (F32State*)c->f32;
+    WgradF32Args a; memset(&a, 0, sizeof a);
+    a.A = A; a.lda = lda; a.shift = shift; a.a_ones = A == nullptr; a.Bm = Bm; a.ldb = ldb; a.K = K; a.M = M; a.part = s->PART;
+    a.B = c->fB; a.T = c->fT; a.slab = 2048; a.slabs_per_utt = cdiv(a.T, a.slab);
+    if (drop_layer >= 0 && c->cfg.dropout > 0.0f) {
+        wn_layer_key(c->fseed, drop_layer, &a.key_lo, &a.key_hi); a.thresh16 = (uint32_t)lrintf(c->cfg.dropout * 65536.0f);
+        a.keep_scale = 1.0f / (1.0f - c->cfg.dropout); a.drop_ld = lda;
+    }
+    const int nslab = a.B * a.slabs_per_utt;
+    if ((size_t)nslab * K * M > s->part_floats) WN_FAIL(c, WN_E_STATE, "fp32 weight-gradient partial buffer too small");
+    hipLaunchKernelGGL(wn_f32_wgrad_kernel, dim3(cdiv(K, SG_T), cdiv(M, SG_T), nslab), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wn_f32_wgrad_reduce, dim3(cdiv((int64_t)K * M, 256)), dim3(256), 0, st, s->PART, nslab, K, M, out, ldo, alpha, out2);
+    WN_LAUNCH_CHECK(c);
+    return WN_OK;
+}
+
+// Backward of the last fp32 forward into the flat gradient buffer (effective-parameter layout): heads, then every layer top to bottom
+// with its weight gradients computed on the spot, d c_up accumulated over the layers, input conv, upsample net (the fp32 kernels of
+// wn_misc.hip).  Replaces optimizer.compute_gradients (wavenet.py:557) in the reference's own arithmetic.
+int wn_f32_backward(wn_ctx* c, float* grads, hipStream_t st) {
+    F32State* s = (F32State*)c->f32;
+    if (!s || !s->DY) WN_FAIL(c, WN_E_STATE, "fp32 backward without an fp32 forward that computed the loss");
+    int rc = f32_reserve_bwd(c);
+    if (rc) return rc;
+    const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C, O = c->O, B = c->fB, T = c->fT;
+    const int ldDY = (O + 15) / 16 * 16;
+    const int64_t NT = c->NT, rows = (int64_t)B * T;
+    const float* P = c->params_dev;
+    // ---- head (wavenet.py:716-721 backwards)
+    if ((rc = wgrad32(c, s->H1, S, 0, S, s->DY, ldDY, O, grads + c->fin2_k, O, 1.0f, -1, nullptr, st))) return rc;
+    if ((rc = wgrad32(c, nullptr, 0, 0, 1, s->DY, ldDY, O, grads + c->fin2_b, O, 1.0f, -1, nullptr, st))) return rc;
+    {   // d pre1 = (dY W2^T) * (h1 > 0)
+        SgemmArgs a = mk(s->DY, ldDY, 0, P + c->fin2_k, O, O, S, s->DH1, S); a.wk = 1; a.wm = O; a.mask = s->H1; a.ld_mask = S;
+        if ((rc = sgemm(c, a, st))) return rc;
+    }
+    if ((rc = wgrad32(c, s->SK, S, 0, S, s->DH1, S, S, grads + c->fin1_k, S, 1.0f, -1, nullptr, st))) return rc;
+    if ((rc = wgrad32(c, nullptr, 0, 0, 1, s->DH1, S, S, grads + c->fin1_b, S, 1.0f, -1, nullptr, st))) return rc;
+    {   // d skips = (d pre1 W1^T) * (relu(skips) > 0)
+        SgemmArgs a = mk(s->DH1, S, 0, P + c->fin1_k, S, S, S, s->DSK, S); a.wk = 1; a.wm = S; a.mask = s->SK; a.ld_mask = S;
+        if ((rc = sgemm(c, a, st))) return rc;
+    }
+    WN_HIP(c, hipMemsetAsync(s->DC, 0, (size_t)rows * C * 4, st));
+    for (int l = L - 1; l >= 0; --l) {
+        const int d = c->dil[l];
+        const float* Xl = s->X + (size_t)l * NT * R;
+        const float* Ul = s->U + (size_t)l * NT * GH;
+        const float* Zl = s->Z + (size_t)l * NT * G;
+        const bool top = (l == L - 1);
+        float* gx_up = s->GX[(l + 1) & 1]; float* gx_dn = s->GX[l & 1];
+        {   // d u = c_l d skips W_skip^T (+ rho-scaled d h_{l+1} W_out^T)   (modules.py:512-520 backwards)
+            SgemmArgs a = mk(s->DSK, S, 0, P + c->lay[l].skip_k, S, S, GH, s->GU, GH); a.wk = 1; a.wm = S; a.alpha = c->skip_scale[l];
+            if ((rc = sgemm(c, a, st))) return rc;
+            if (!top) {
+                SgemmArgs o = mk(gx_up, R, 0, P + c->lay[l].out_k, R, R, GH, s->GU, GH); o.wk = 1; o.wm = R; o.accumulate = 1;
+                if ((rc = sgemm(c, o, st))) return rc;
+            }
+        }
+        hipLaunchKernelGGL(wn_f32_gate_bwd, dim3(cdiv(rows * GH, 256)), dim3(256), 0, st, s->GU, Zl, s->DZ, rows, GH);
+        // ---- weight gradients of this layer
+        if ((rc = wgrad32(c, Ul, GH, 0, GH, s->DSK, S, S, grads + c->lay[l].skip_k, S, c->skip_scale[l], -1, nullptr, st))) return rc;
+        if (c->lbias && (rc = wgrad32(c, nullptr, 0, 0, 1, s->DSK, S, S, grads + c->lay[l].skip_b, S, c->skip_scale[l], -1, nullptr, st))) return rc;
+        if (!top) {
+            if ((rc = wgrad32(c, Ul, GH, 0, GH, gx_up, R, R, grads + c->lay[l].out_k, R, 1.0f, -1, nullptr, st))) return rc;
+            if (c->lbias && (rc = wgrad32(c, nullptr, 0, 0, 1, gx_up, R, R, grads + c->lay[l].out_b, R, 1.0f, -1, nullptr, st))) return rc;
+        }
+        for (int tap = 0; tap < 3; ++tap)
+            if ((rc = wgrad32(c, Xl, R, -(2 - tap) * d, R, s->DZ, G, G, grads + c->lay[l].dil_k + (int64_t)tap * R * G, G, 1.0f, l, nullptr, st))) return rc;
+        if ((rc = wgrad32(c, s->C32, C, 0, C, s->DZ, G, G, grads + c->lay[l].cin_k, G, 1.0f, -1, nullptr, st))) return rc;
+        if (c->lbias && (rc = wgrad32(c, nullptr, 0, 0, 1, s->DZ, G, G, grads + c->lay[l].dil_b, G, 1.0f, -1, grads + c->lay[l].cin_b, st))) return rc;
+        if (c->gin > 0) hipLaunchKernelGGL(wn_f32_colsum_utt, dim3(cdiv(G, 64), B), dim3(256), 0, st, s->DZ, c->colsum + (size_t)l * B * G, T, G);
+        {   // d c_up += d z W_cin^T   (modules.py:497-501 backwards)
+            SgemmArgs a = mk(s->DZ, G, 0, P + c->lay[l].cin_k, G, G, C, s->DC, C); a.wk = 1; a.wm = G; a.accumulate = 1;
+            if ((rc = sgemm(c, a, st))) return rc;
+        }
+        // d h_l = rho (mask_l / keep * sum_taps d z(t + (2 - tap) d) W_tap^T + d h_{l+1})   (modules.py:484, 517-520 backwards)
+        const float scale = (l > 0) ? c->res_scale : 1.0f;
+        for (int tap = 0; tap < 3; ++tap) {
+            SgemmArgs a = mk(s->DZ, G, (2 - tap) * d, P + c->lay[l].dil_k + (int64_t)tap * R * G, G, G, R, gx_dn, R); a.wk = 1; a.wm = G;
+            a.accumulate = tap > 0;
+            if (tap == 0) { a.scale = scale; if (!top) { a.add = gx_up; a.ld_add = R; } }
+            else a.alpha = scale;
+            if (c->cfg.dropout > 0.0f) {
+                wn_layer_key(c->fseed, l, &a.key_lo, &a.key_hi); a.thresh16 = (uint32_t)lrintf(c->cfg.dropout * 65536.0f);
+                a.keep_scale = 1.0f / (1.0f - c->cfg.dropout); a.drop_ld = R; a.drop_on_out = 1;
+            }
+            if ((rc = sgemm(c, a, st))) return rc;
+        }
+    }
+    // ---- input convolution (wavenet.py:705): gx = GX[0] holds dL/dh_0
+    const float* g0 = s->GX[0];
+    if (c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE)
+        hipLaunchKernelGGL(wn_f32_first_conv_bwd_ids, dim3(cdiv(rows * R, 256)), dim3(256), 0, st, (const int32_t*)c->fx, g0, grads + c->first.dil_k, rows, R);
+    else if ((rc = wgrad32(c, (const float*)c->fx, 1, 0, 1, g0, R, R, grads + c->first.dil_k, R, 1.0f, -1, nullptr, st))) return rc;
+    if ((rc = wgrad32(c, nullptr, 0, 0, 1, g0, R, R, grads + c->first.dil_b, R, 1.0f, -1, nullptr, st))) return rc;
+    if ((rc = wn_gin_bwd(c, grads, st, true))) return rc;      // d W_g, d b_g, d embedding table from the per-utterance sums above
+    // ---- upsample net (modules.py:524-770 backwards: the fp32 kernels the bf16 engine uses too)
+    if (c->cfg.upsample_type != WN_UP_NEAREST) {
+        hipLaunchKernelGGL(wn_f32_transpose_back, dim3(cdiv(rows * C, 256)), dim3(256), 0, st, s->DC, s->DCT, B, C, T);
+        if ((rc = wn_upsample_bwd(c, s->DCT, grads, st))) return rc;
     }
     WN_LAUNCH_CHECK(c);
     return WN_OK;

@@ -943,10 +943,11 @@ __global__ void wn_gin_dg_kernel(const float* __restrict__ params, const float* 
     for (int s = 32; s > 0; s >>= 1) a += __shfl_down(a, s);
     if (lane == 0) { int id = ids[b]; id = id < 0 ? 0 : (id >= n_speakers ? n_speakers - 1 : id); unsafeAtomicAdd(&grads[emb_off + (int64_t)id * gin + k], a); }
 }
-int wn_gin_bwd(wn_ctx* c, float* grads, hipStream_t st) {
+// have_colsum: c->colsum already holds the per-utterance column sums (the fp32 backward of wn_f32.hip writes them layer by layer)
+int wn_gin_bwd(wn_ctx* c, float* grads, hipStream_t st, bool have_colsum) {
     if (c->gin <= 0) return WN_OK;
     const int B = c->fB, G = c->G, L = c->L;
-    hipLaunchKernelGGL(wn_colsum_kernel, dim3(G / 8, B, L), dim3(256), 0, st, c->DZ, c->colsum, c->NT, B, c->fT, G);
+    if (!have_colsum) hipLaunchKernelGGL(wn_colsum_kernel, dim3(G / 8, B, L), dim3(256), 0, st, c->DZ, c->colsum, c->NT, B, c->fT, G);
     GinOff o; for (int l = 0; l < L; ++l) { o.k[l] = c->lay[l].gin_k; o.b[l] = c->lay[l].gin_b; }
     hipLaunchKernelGGL(wn_gin_wgrad_kernel, dim3(cdiv(G, 256), c->gin + 1, L), dim3(256), 0, st, c->colsum, c->gvec, grads, B, G, c->gin, o, c->lbias ? 1 : 0);
     if (c->cfg.use_speaker_embedding)
@@ -973,13 +974,15 @@ __global__ void wn_loss_prep(const int32_t* __restrict__ lengths, int B, int T, 
 // one thread per (b, t): prediction at t scored against y[t+1] (wavenet.py:494-495).
 __global__ void wn_mol_loss(const float* __restrict__ yhat, const float* __restrict__ y, const int32_t* __restrict__ lengths,
                             bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, int B, int T, int M,
-                            float num_classes, float log_scale_min, int shift) {
+                            float num_classes, float log_scale_min, int shift, float* __restrict__ dY32) {
+    // dY32 (optional): the same gradient rows in fp32 (the fp32 backward of wn_f32.hip)
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float my = 0.0f;
     if (idx < (int64_t)B * T) {
         const int b = (int)(idx / T), t = (int)(idx - (int64_t)b * T);
         const bool valid = (t + shift < T) && (t + shift < lengths[b]);
         bf16_t* drow = dY + idx * ldDY;
+        if (dY32) for (int o = 0; o < ldDY; ++o) dY32[idx * ldDY + o] = 0.0f;
         if (!valid) {
             for (int o = 0; o < ldDY; ++o) drow[o] = 0;
         } else {
@@ -1032,6 +1035,7 @@ __global__ void wn_mol_loss(const float* __restrict__ yhat, const float* __restr
                 drow[i] = f2bf((pi - w) * inv_den);
                 drow[M + i] = f2bf(-w * dmu[i] * inv_den);
                 drow[2 * M + i] = f2bf(-w * dls[i] * inv_den);
+                if (dY32) { float* d32 = dY32 + idx * ldDY; d32[i] = (pi - w) * inv_den; d32[M + i] = -w * dmu[i] * inv_den; d32[2 * M + i] = -w * dls[i] * inv_den; }
             }
             for (int o = 3 * M; o < ldDY; ++o) drow[o] = 0;
         }
@@ -1054,7 +1058,7 @@ __device__ __forceinline__ float ndtrf_(float x) {      // TF special_math._ndtr
 // Gaussian MLE, gaussian.py:5-37 + modules.py:819-836, with its gradient.
 __global__ void wn_gauss_loss(const float* __restrict__ yhat, const float* __restrict__ y, const int32_t* __restrict__ lengths,
                               bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, int B, int T,
-                              float num_classes, float log_scale_min, int use_cdf, int shift) {
+                              float num_classes, float log_scale_min, int use_cdf, int shift, float* __restrict__ dY32) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float my = 0.0f;
     if (idx < (int64_t)B * T) {
@@ -1090,6 +1094,7 @@ __global__ void wn_gauss_loss(const float* __restrict__ yhat, const float* __res
         }
         drow[0] = f2bf(g0); drow[1] = f2bf(g1);
         for (int o = 2; o < ldDY; ++o) drow[o] = 0;
+        if (dY32) { float* d32 = dY32 + idx * ldDY; d32[0] = g0; d32[1] = g1; for (int o = 2; o < ldDY; ++o) d32[o] = 0.0f; }
     }
     for (int o = 32; o > 0; o >>= 1) my += __shfl_down(my, o);
     __shared__ float part[8];
@@ -1102,7 +1107,7 @@ __global__ void wn_gauss_loss(const float* __restrict__ yhat, const float* __res
 // pass 0: per-element loss into `tmp`, sum and non-zero count; pass 1: gradients (needs the count).
 __global__ void wn_ce_loss(const float* __restrict__ yhat, const int32_t* __restrict__ y, const int32_t* __restrict__ lengths,
                            bf16_t* __restrict__ dY, int ldDY, float* __restrict__ scal, float* __restrict__ tmp,
-                           int B, int T, int Q, int pass, int shift) {
+                           int B, int T, int Q, int pass, int shift, float* __restrict__ dY32) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float my = 0.0f, cnt = 0.0f;
     if (idx < (int64_t)B * T) {
@@ -1122,6 +1127,7 @@ __global__ void wn_ce_loss(const float* __restrict__ yhat, const int32_t* __rest
             tmp[idx] = l; my = l; cnt = (l != 0.0f) ? 1.0f : 0.0f;
         } else {
             bf16_t* drow = dY + idx * ldDY;
+            if (dY32) for (int q = 0; q < ldDY; ++q) dY32[idx * ldDY + q] = 0.0f;
             if (!valid) { for (int q = 0; q < ldDY; ++q) drow[q] = 0; }
             else {
                 const float inv = 1.0f / scal[3];
@@ -1130,7 +1136,11 @@ __global__ void wn_ce_loss(const float* __restrict__ yhat, const int32_t* __rest
                 float se = 0.0f;
                 for (int q = 0; q < Q; ++q) se += __expf(yh[(int64_t)q * T] - mx);
                 const int tgt = y[(int64_t)b * T + t + shift];
-                for (int q = 0; q < Q; ++q) drow[q] = f2bf((__expf(yh[(int64_t)q * T] - mx) / se - (q == tgt ? 1.0f : 0.0f)) * inv);
+                for (int q = 0; q < Q; ++q) {
+                    const float gq = (__expf(yh[(int64_t)q * T] - mx) / se - (q == tgt ? 1.0f : 0.0f)) * inv;
+                    drow[q] = f2bf(gq);
+                    if (dY32) dY32[idx * ldDY + q] = gq;
+                }
                 for (int q = Q; q < ldDY; ++q) drow[q] = 0;
             }
         }
@@ -1161,20 +1171,21 @@ int wn_loss_run(wn_ctx* c, const float* yhat, const void* y, const int32_t* leng
     const int64_t n = (int64_t)B * T;
     if (n > c->NT) WN_FAIL(c, WN_E_SHAPE, "loss: B*T exceeds the workspace");
     const int ldDY = (c->O + 15) / 16 * 16;
+    float* const dy32 = c->dy32_next; c->dy32_next = nullptr;      // set by the fp32 forward for ITS loss call only
     hipLaunchKernelGGL(wn_loss_prep, dim3(1), dim3(64), 0, st, lengths, B, T, c->scal, shift);
     if (c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE) {
         float* tmp = c->DC;      // scratch, free at this point of the step
-        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const int32_t*)y, lengths, c->DY, ldDY, c->scal, tmp, B, T, c->O, 0, shift);
-        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const int32_t*)y, lengths, c->DY, ldDY, c->scal, tmp, B, T, c->O, 1, shift);
+        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const int32_t*)y, lengths, c->DY, ldDY, c->scal, tmp, B, T, c->O, 0, shift, dy32);
+        hipLaunchKernelGGL(wn_ce_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const int32_t*)y, lengths, c->DY, ldDY, c->scal, tmp, B, T, c->O, 1, shift, dy32);
         hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 1);
     } else if (c->O == 2) {
         hipLaunchKernelGGL(wn_gauss_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const float*)y, lengths, c->DY, ldDY, c->scal, B, T,
-                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min_gauss, c->cfg.cdf_loss, shift);
+                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min_gauss, c->cfg.cdf_loss, shift, dy32);
         hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 0);
     } else {
         if (c->O / 3 > WN_MAX_MIX) WN_FAIL(c, WN_E_UNSUPPORTED, "more than %d mixture components", WN_MAX_MIX);
         hipLaunchKernelGGL(wn_mol_loss, dim3(cdiv(n, 256)), dim3(256), 0, st, yhat, (const float*)y, lengths, c->DY, ldDY, c->scal, B, T, c->O / 3,
-                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min, shift);
+                           (float)c->cfg.quantize_channels, c->cfg.log_scale_min, shift, dy32);
         hipLaunchKernelGGL(wn_loss_finalize, dim3(1), dim3(64), 0, st, c->scal, loss_out, 0);
     }
     WN_LAUNCH_CHECK(c);

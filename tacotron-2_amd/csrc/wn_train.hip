@@ -456,12 +456,16 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
     if ((rc = wn_upsample_fwd(c, nullptr, c->fc, c->fB, c->fTc, st))) return rc;     // wavenet.py:680-702
     if ((rc = wn_first_conv(c, st))) return rc;                                      // wavenet.py:705
     if ((rc = wn_gbias_fwd(c, c->fB, st))) return rc;                                // wavenet.py:669-678
-    c->fwd_was_f32 = (c->cfg.compute_dtype == WN_COMPUTE_F32_FWD);
+    c->fwd_was_f32 = (c->cfg.compute_dtype == WN_COMPUTE_F32);
     if (c->fwd_was_f32) {      // the reference's fp32 arithmetic for y_hat / the loss value (wn_f32.hip); no saved activations for a backward
         if ((rc = wn_f32_forward(c, st))) return rc;
         if (y_hat_out) WN_HIP(c, hipMemcpyAsync(y_hat_out, c->YHAT, (size_t)c->fB * c->O * c->fT * 4, hipMemcpyDeviceToDevice, st));
-        if (loss_out) { if ((rc = wn_loss_fwd_bwd(c, loss_out, st))) return rc; }
-        c->have_loss = false;
+        if (loss_out) {      // the loss kernel also writes d y_hat in fp32 for wn_f32_backward
+            c->dy32_next = wn_f32_dy(c);
+            if (!c->dy32_next) WN_FAIL(c, WN_E_HIP, "hipMalloc(fp32 d y_hat) failed");
+            if ((rc = wn_loss_fwd_bwd(c, loss_out, st))) return rc;
+        }
+        c->have_loss = loss_out != nullptr;
         return WN_OK;
     }
     if (n_parts(c) == 2 && fused_ok(c)) rc = fwd_fused(c, st);
@@ -724,6 +728,13 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     int rc;
     if ((rc = buckets_setup(c))) return rc;
     WN_HIP(c, hipMemsetAsync(grads, 0, (size_t)c->n_params * 4, st));
+    if (c->fwd_was_f32) {      // fp32 training mode: the whole backward in the reference's arithmetic, on the caller's stream (wn_f32.hip)
+        if ((rc = wn_f32_backward(c, grads, st))) return rc;
+        c->nearly_live = 0;
+        WN_HIP(c, hipEventRecord(c->ev_bucket[WN_MAX_BUCKETS], st));          // every bucket of the table is final here
+        c->have_bwd = true;
+        return WN_OK;
+    }
     const int64_t rows = (int64_t)c->fB * c->fT;
     WN_HIP(c, hipMemsetAsync(c->GXall + (size_t)L * NT * R, 0, (size_t)rows * R * 2, st));   // top layer: residual branch is dead
     bool grouped, fused;

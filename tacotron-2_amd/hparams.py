@@ -84,8 +84,8 @@ MI355 = dict(
     mi355_synthetic_data=False,    # train on LJSpeech-shaped synthetic tensors (no dataset on disk)
     mi355_grad_buckets=3,          # data-parallel training: pieces of the flat gradient that are all-reduced while the backward is still running
     mi355_synthesize_with_ema=False,   # Synthesizer.load: pack the EMA shadow weights instead of the raw ones
-    mi355_compute_dtype='bf16',     # 'bf16': bf16 MFMA operands, fp32 accumulation (training); 'fp32': the reference's own fp32 arithmetic for the FORWARD
-                                     # (WaveNet.step / evaluation / loss value; add_optimizer raises: the backward needs the bf16 engine's saved activations)
+    mi355_compute_dtype='bf16',     # 'bf16': bf16 MFMA operands, fp32 accumulation (the tuned path); 'fp32': the reference's own fp32 arithmetic for the
+                                     # forward, loss AND backward (csrc/wn_f32.hip; ~20x slower: validation of a run against the reference's numerics)
 )
 
 

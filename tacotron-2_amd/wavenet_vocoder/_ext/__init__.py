@@ -19,7 +19,7 @@ INPUT_TYPES = {'raw': 0, 'mulaw': 1, 'mulaw-quantize': 2}
 UPSAMPLE_TYPES = {'NearestNeighbor': 0, '2D': 1, 'SubPixel': 2, '1D': 3, 'Resize': 4}
 ACTIVATIONS = {None: 0, 'None': 0, 'Relu': 1, 'LeakyRelu': 2}
 LR_SCHEDULES = {'exponential': 0, 'noam': 1}
-COMPUTE_DTYPES = {'bf16': 0, 'fp32': 1, 'float32': 1}      # wn_compute_dtype: 'fp32' = the reference's arithmetic for the FORWARD (step / eval / loss value)
+COMPUTE_DTYPES = {'bf16': 0, 'fp32': 1, 'float32': 1}      # wn_compute_dtype: 'fp32' = the reference's arithmetic for forward, loss and backward (csrc/wn_f32.hip)
 STATUS = {0: 'WN_OK', -1: 'WN_E_ARG', -2: 'WN_E_SHAPE', -3: 'WN_E_HIP', -4: 'WN_E_UNSUPPORTED', -5: 'WN_E_STATE'}
 
 

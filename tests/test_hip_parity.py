@@ -298,10 +298,12 @@ def test_error_paths():
     assert ei.value.code == -2
 
 
-def test_training_reduces_loss_and_tracks_oracle_trajectory():
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_training_reduces_loss_and_tracks_oracle_trajectory(dtype):
     """Several full steps (fwd + bwd + clip + TF-Adam + EMA + re-pack) on one batch: the device loss trajectory follows the
-    oracle's train_step (fp32, same dropout masks) and the loss goes down."""
-    kw = dict(SMALL); kw.update(wavenet_dropout=0.05, wavenet_learning_rate=1e-3)
+    oracle's train_step (fp32, same dropout masks) and the loss goes down.  In the fp32 training mode (mi355_compute_dtype = 'fp32',
+    csrc/wn_f32.hip: the reference's arithmetic end to end) the trajectory is the oracle's to summation order."""
+    kw = dict(SMALL); kw.update(wavenet_dropout=0.05, wavenet_learning_rate=1e-3, mi355_compute_dtype=dtype)
     hp = make_hp(**kw)
     cfg = oracle_cfg(hp)
     B, T = 2, 320
@@ -328,9 +330,12 @@ def test_training_reduces_loss_and_tracks_oracle_trajectory():
         or_losses.append(float(l))
     print('\ndevice losses', ['%.4f' % l for l in dev_losses]); print('oracle losses', ['%.4f' % l for l in or_losses])
     assert dev_losses[-1] < dev_losses[0] - 0.05 and or_losses[-1] < or_losses[0] - 0.05
-    for a, b in zip(dev_losses, or_losses):
-        assert abs(a - b) <= 2e-3 * max(1.0, abs(b))                   # bf16 path vs fp32 oracle, compounding over the steps (measured <= 2.5e-4)
+    tol_loss, tol_par = (2e-3, 2e-2) if dtype == 'bf16' else (2.5e-5, 1e-4)      # measured 2.2e-4 / 1.0e-3 and 8.2e-6 / 1.9e-5 (profiles/r4i_pytest_fp32.log)
+    dl = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(dev_losses, or_losses))
     # parameters after 12 updates stay close to the oracle's
     p_or = torch.cat([params[k].reshape(-1) for k in eng.layout])
     p_dev = torch.cat([flat.cpu()[off:off + int(np.prod(shape))] for _, (shape, off) in eng.layout.items()])
-    assert rel_err(p_dev, p_or) < 2e-2
+    ep = rel_err(p_dev, p_or)
+    print('[%s] worst loss deviation over the steps %.2e; parameters after %d updates rel-L2 %.2e' % (dtype, dl, n_steps, ep))
+    assert dl <= tol_loss                   # bf16 path vs fp32 oracle, compounding over the steps (measured <= 2.5e-4)
+    assert ep < tol_par

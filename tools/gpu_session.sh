@@ -63,11 +63,11 @@ for st in "$@"; do
       for h in gemm_harness gemm_harness_ablate wgrad_harness; do [ -x $R/tools/$h ] && timeout 180 $R/tools/$h > $OUT/$h.txt 2>&1; done
       cd $R; tail -40 $OUT/gemm_harness.txt ;;
     pipetrace) for b in 1 8; do WN_PIPE_TRACE=1 timeout 200 python tools/pipe_trace.py $b > $OUT/pipe_trace_b$b.txt 2>&1; tail -4 $OUT/pipe_trace_b$b.txt; done ;;
-    other) timeout 400 python - > $OUT/other_workloads.json 2> $OUT/other.err <<'PY'
+    other) timeout 900 python - > $OUT/other_workloads.json 2> $OUT/other.err <<'PY'
 import json, sys, os
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 import bench, torch
-print(json.dumps({k: bench.measure_other_workload(k, torch.device('cuda', 0)) for k in ('default_hparams', 'c2_4stack', 'c5_stress')}, indent=1))
+print(json.dumps({k: bench.other_workload_subprocess(k, 0) for k in ('default_hparams', 'c2_4stack', 'c5_stress', 'c2_fp32')}, indent=1))      # a fresh process each (HW queue assignment)
 PY
       cut -c1-600 $OUT/other_workloads.json ;;
     *) echo "unknown stage $st" ;;
