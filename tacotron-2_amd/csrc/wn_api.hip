@@ -267,6 +267,7 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->skip_bias_total) hipFree(c->skip_bias_total);
     if (c->tensor_offsets_dev) hipFree(c->tensor_offsets_dev);
     if (c->kprof_dev) hipFree(c->kprof_dev);
+    if (c->trace_dev) hipFree(c->trace_dev);
     if (c->norm2_dev) hipFree(c->norm2_dev);
     if (c->norm_spans_dev) hipFree(c->norm_spans_dev);
     if (c->norm_first_dev) hipFree(c->norm_first_dev);

@@ -154,6 +154,12 @@ struct wn_ctx {
     const void* fx = nullptr; const void* fy = nullptr; const int32_t* flen = nullptr; const float* fc = nullptr;
     // live profiling of the dominant kernel (bench.py roofline): event pairs around every gate-GEMM launch
     bool prof = false; std::vector<hipEvent_t> pev; size_t pev_used = 0;
+    // WN_DEVTRACE=<file> (debug): in-kernel {first start, last end} stamps of EVERY tile-engine launch of one training step (the
+    // WN_DEVTRACE_STEP-th wn_train_fwd, default 8) -- the device timeline of the chain without a profiler attached (rocprofv3 slows the
+    // host's enqueue enough to change which stream runs ahead).  Written two steps later by wn_devtrace_poll.
+    unsigned long long* trace_dev = nullptr; int trace_n = 0, trace_calls = 0, trace_state = 0;      // state: 0 idle, 1 recording, 2 recorded
+#define WN_TRACE_MAX 1024
+    struct { int epi; void* st; int rows; } trace_tag[WN_TRACE_MAX];
     unsigned long long* kprof_dev = nullptr;      // [WN_KPROF_MAX][2] in-kernel {first start, last end} stamps of the timed gate launches
 #define WN_KPROF_MAX 8192
     // batch parts: the serial layer chain of the two half-batches runs on two streams so that the MFMA/power-bound GEMMs of
@@ -214,6 +220,7 @@ int wn_upsample_fwd(wn_ctx* ctx, const float* params_unused, const float* c, int
 int wn_weightnorm_apply(wn_ctx* ctx, const float* raw_params, hipStream_t st);     // raw (v, g, bias) -> params_dev (effective)
 int wn_weightnorm_grad(wn_ctx* ctx, float* raw_grads, hipStream_t st);             // deff (effective grads) -> raw grads
 int wn_gbias_fwd(wn_ctx* ctx, int B, hipStream_t st);                 // global-conditioning bias table of this batch
+void wn_devtrace_poll(wn_ctx* c, hipStream_t st, bool step_start);
 int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st, bool have_colsum = false);           // d W_g, d b_g, d embedding
 int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const float* xw, int64_t rows, float* out_b, float* out_w, int slot, hipStream_t st);
 size_t wn_wgrad_partial_need(wn_ctx* ctx);

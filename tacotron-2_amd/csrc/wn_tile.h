@@ -385,6 +385,19 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
 __device__ __forceinline__ void lds_dma16_s(uint64_t sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
+// One MFMA A fragment (lane i's 16 B of a fragment-ordered pack) straight into VGPRs: address = sbase (wave-uniform) + voff + IMM.
+// Inline asm on purpose: a load the compiler knows about makes its waitcnt pass put `s_waitcnt vmcnt(0)` in front of the first use --
+// which also drains every LDS-DMA in flight (they are asm too, so it cannot count them).  The caller waits by hand (counted vmcnt, in
+// order with the DMAs) through wn_wait_frags, which ties the registers to the wait so that no consumer can be scheduled above it.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int IMM>
+__device__ __forceinline__ void gload_frag_s(u32x4_t& dst, uint64_t sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void wn_wait_frags(u32x4_t& f0, u32x4_t& f1) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(VM) : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -407,6 +420,11 @@ struct LdsGemmCfg {
     static constexpr int MTILE = WM * MT * 32, TTILE = WN * NT * 32;
     static constexpr int KS = BK / 16;
     static constexpr int A_BYTES = MTILE * BK * 2, B_BYTES = TTILE * BK * 2, BUF_BYTES = A_BYTES + B_BYTES;
+    // ring layout: [B slot 0 .. B slot NBUF-1 | A slot 0 .. A slot NBUF-1].  The activation (B) slots come first so that every B
+    // fragment address of every slot is one VGPR base + a 16-bit immediate (< 64 KiB): with [A | B] per slot the last slot's reads
+    // lay beyond the immediate range and cost one address register per fragment.
+    static constexpr int b_base(int buf) { return buf * B_BYTES; }
+    static constexpr int a_base(int buf) { return NBUF * B_BYTES + buf * A_BYTES; }
     static constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;
     static constexpr int A_PW = A_INSTR / NW, B_PW = B_INSTR / NW, LPC = A_PW + B_PW;   // DMAs per wave per chunk
     static constexpr int RB = BK * 2, SPR = RB / 16, RPL = 256 / RB;                      // row bytes, 16-B slots per row, rows per bank line
@@ -420,9 +438,15 @@ struct LdsGemmCfg {
 
 // The kernel BODY is a device function of (arguments, LDS arena, workgroup id) so that two different launches can share one grid
 // (wn_fused_pair_kernel below); wn_gemm_lds_kernel is the one-launch wrapper.
-template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 0, int TAPS = 0>
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE_ = 0, int TAPS = 0>
 __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const lds, const int wg_id) {
     using Cfg = LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>;
+    // PIPE_ 8 ("A-direct"): the weight fragments of the K-interleaved taps go from the fragment-ordered pack straight into VGPRs
+    // (global_load_dwordx4, one chunk ahead) instead of through LDS: 1 LDS-DMA per wave and chunk instead of 3, no A ds_reads.  Needs
+    // one m-tile per wave that no other wave shares (MT == 1, WN == 1: 8 x 1 waves of 32 x 128).  Everything else is PIPE 1.
+    constexpr bool ADIRECT = (PIPE_ == 8);
+    constexpr int PIPE = ADIRECT ? 1 : PIPE_;
+    static_assert(!ADIRECT || (TAPS == 3 && NBUF == 3 && MT == 1 && WN == 1 && BK == 32), "A-direct: K-interleaved taps, 8 x 1 waves");
     static_assert(TAPS == 0 || (TAPS == 3 && NBUF == 3 && (PIPE <= 1 || PIPE >= 6)), "interleaved taps: the tap of a chunk is its ring slot (ring depth 3 == 3 taps)");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -558,8 +582,8 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
 
     auto stage = [&](auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
-        char* const abuf = lds + BUF * Cfg::BUF_BYTES;
-        char* const bbuf = abuf + Cfg::A_BYTES;
+        char* const abuf = lds + Cfg::a_base(BUF);
+        char* const bbuf = lds + Cfg::b_base(BUF);
         if constexpr (TAPS > 0) {
             if (t_left > 0) {
                 // chunk c lives in ring slot c % NBUF and NBUF == TAPS: this buffer always holds tap BUF
@@ -644,12 +668,12 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
 #pragma unroll
         for (int ks = 0; ks < Cfg::KS; ++ks) {
             const int row = (wn * NT + j) * 32 + (lane & 31);
-            b_rd[j][ks] = Cfg::A_BYTES + row * Cfg::RB + (((ks * 2 + (lane >> 5)) ^ ((row / Cfg::RPL) % Cfg::SPR)) * 16);
+            b_rd[j][ks] = row * Cfg::RB + (((ks * 2 + (lane >> 5)) ^ ((row / Cfg::RPL) % Cfg::SPR)) * 16);
         }
     const int a_rd = (wm * MT * Cfg::KS * 64 + lane) * 16;
     auto compute = [&](auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
-        const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+        const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
         // every k-step of the chunk, unconditionally: in a partial chunk (segment width % BK != 0) the tail k-steps of BOTH
         // operands were DMA'd from the zero page, so they add exact zeros -- no branch around the accumulators
 #pragma unroll
@@ -660,7 +684,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                 af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+                bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -700,7 +724,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
             if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
             compute(bufc);
         } else if constexpr (SPLIT) {
-            const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+            const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
             auto read_held = [&]() {
 #pragma unroll
                 for (int ks = 0; ks < Cfg::KS; ++ks) {
@@ -709,7 +733,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                         haf[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        hbf[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+                        hbf[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
                 }
             };
             if constexpr (decltype(latec)::value) {
@@ -731,7 +755,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         } else {
             // PIPE 1: every fragment of the chunk is requested from LDS straight after the barrier, the DMA issue + iterator
             // bookkeeping of the next chunk runs while those reads are in flight, then the chunk's MFMAs go back to back.
-            const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+            const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
             bf16x8_t af[Cfg::KS][MT], bfr[Cfg::KS][NT];
             if (dbg & 2) {
 #pragma unroll
@@ -749,7 +773,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                     af[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+                    bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
             }
             __builtin_amdgcn_sched_barrier(0);
             if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
@@ -776,13 +800,13 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         bf16x8_t fa[2][MT], fb[2][NT];
         auto read_frags = [&](auto bufc, auto ksc, auto setc) {
             constexpr int BUF = decltype(bufc)::value, ks = decltype(ksc)::value, SET = decltype(setc)::value;
-            const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+            const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
                 fa[SET][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                fb[SET][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+                fb[SET][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
         };
         auto mfma_set = [&](auto setc) {
             constexpr int SET = decltype(setc)::value;
@@ -857,11 +881,111 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         // the trailing fragment reads (of a buffer nobody multiplies) must retire before the epilogue reuses the registers / LDS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(fa[0][0]), "v"(fb[0][0]) : "memory");
     } else {
+    // A-direct: the fragments of chunk 0 are requested BEFORE the prologue's DMAs (vmcnt retires in order)
+    [[maybe_unused]] u32x4_t adf[Cfg::KS];                      // this wave's A fragments of ONE chunk (single set, see ad_step)
+    [[maybe_unused]] uint64_t ad_src = 0;                       // SGPR: pack address of the next chunk's first k-step of this wave's m-tile
+    [[maybe_unused]] bool ad_on = false;
+    if constexpr (ADIRECT) {
+        const int nkb = a.seg[0].nk / BK;
+        ad_on = nkb >= 2 && dbg == 0 && nchunks > 3 * (nkb - 1) + 1;
+        if (ad_on) {
+            const uint64_t v = (uint64_t)(a.Apk + (int64_t)mtile0 * a.ksteps_total * 512);
+            ad_src = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            gload_frag_s<0>(adf[0], ad_src, lane * 16);
+            gload_frag_s<1024>(adf[1], ad_src, lane * 16);
+            ad_src += Cfg::KS * 1024;
+        }
+    }
     // prologue: fill NBUF-1 buffers
     stage(std::integral_constant<int, 0>{});
     if constexpr (NBUF == 3) { if (nchunks > 1) stage(std::integral_constant<int, 1>{}); }
     int ch0 = 0;
-    if constexpr (TAPS == 3 && PIPE == 1 && NBUF == 3) {
+    if constexpr (ADIRECT) {
+        if (ad_on) {
+            static_assert(Cfg::KS == 2, "two k-steps per chunk");
+            const int nkb = a.seg[0].nk / BK;
+            uint64_t sa[APW];                                   // DMA sources of the weight panel (only the last two steps use them: the generic tail reads A from LDS)
+#pragma unroll
+            for (int p = 0; p < APW; ++p) {
+                const int f = wave + p * NWD;
+                const uint64_t v = (uint64_t)(a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512);
+                sa[p] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            }
+            const uint32_t a_voff = lane * 16;
+            const bf16_t* tpb = a.seg[0].base + a.seg[0].col0;
+            // One ring step of chunk ch (slot BUF == tap):
+            //     wait: the DMAs of chunk ch have landed | barrier | request the B fragments | DMA chunk ch + 2 (B only; MODE >= 1: A too --
+            //     a generic tail step will read it from LDS) | wait: A(ch) is in adf | the chunk's MFMAs | request A(ch + 1) INTO THE SAME
+            //     REGISTERS (the MFMAs have read them at issue; MODE 2, the last step, does not).
+            // The A request of the next chunk thus flies during the whole next step up to its MFMAs (> one L2 round trip) with a single
+            // register set.  vmcnt retires in order; issue order per step: [A DMAs], B DMA, ..., A request x 2.  VT = operations that may be in
+            // flight at the top (everything younger than the DMAs of chunk ch), VA = those younger than the A request of chunk ch.
+            auto ad_step = [&](auto bufc, auto vtc, auto modec) {
+                constexpr int BUF = decltype(bufc)::value, VT = decltype(vtc)::value, MODE = decltype(modec)::value;
+                constexpr int VA = (MODE == 0 ? 0 : APW) + BPW;
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VT) : "memory");
+                __builtin_amdgcn_s_barrier();
+                const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
+                bf16x8_t bfr[Cfg::KS][NT];
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    constexpr int SB = (BUF + NBUF - 1) % NBUF;          // slot (== tap) of chunk + 2
+                    char* const abuf = lds + Cfg::a_base(SB);
+                    char* const bbuf = lds + Cfg::b_base(SB);
+                    if constexpr (SB == 0) tpb += BK;
+#pragma unroll
+                    for (int p = 0; p < APW; ++p) {
+                        if constexpr (MODE != 0) lds_dma16_s(sa[p], a_voff, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + (wave + p * NWD) * 1024)));
+                        sa[p] += Cfg::KS * 1024;
+                    }
+#pragma unroll
+                    for (int p = 0; p < BPW; ++p) {
+                        const bf16_t* src = b_offt[SB][p] >= 0 ? tpb + b_offt[SB][p] : a.zero;
+                        lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                wn_wait_frags<VA>(adf[0], adf[1]);
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, adf[ks]), bfr[ks][j], acc[0][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MODE != 2) {
+                    gload_frag_s<0>(adf[0], ad_src, a_voff);
+                    gload_frag_s<1024>(adf[1], ad_src, a_voff);
+                    ad_src += Cfg::KS * 1024;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            using VT0 = std::integral_constant<int, BPW + Cfg::KS>;            // after a MODE 0 step: its B DMA + its A request
+            using VT1 = std::integral_constant<int, APW + BPW + Cfg::KS>;      // after a MODE 1 step
+            using VTP = std::integral_constant<int, Cfg::LPC>;                 // first step of the tile: the prologue's DMAs of chunk 1
+            auto kblock = [&](auto firstc, auto lastc) {
+                constexpr bool FIRST = decltype(firstc)::value, LAST = decltype(lastc)::value;
+                ad_step(I0{}, std::conditional_t<FIRST, VTP, VT0>{}, I0{});
+                ad_step(I1{}, VT0{}, std::conditional_t<LAST, I1, I0>{});
+                ad_step(I2{}, std::conditional_t<LAST, VT1, VT0>{}, std::conditional_t<LAST, I2, I0>{});
+            };
+            const int nb = nkb - 1;                              // k-blocks of the fast part (>= 1)
+            if (nb == 1) kblock(std::true_type{}, std::true_type{});
+            else {
+                kblock(std::true_type{}, std::false_type{});
+                for (int i = 1; i + 1 < nb; ++i) kblock(std::false_type{}, std::false_type{});
+                kblock(std::false_type{}, std::true_type{});
+            }
+            ch0 = 3 * nb;
+            s_kstep += Cfg::KS * ch0; t_left -= ch0;
+        }
+    }
+    if constexpr (TAPS == 3 && PIPE == 1 && NBUF == 3 && !ADIRECT) {
         // ---- regular part of the K-interleaved taps (all k-blocks but the last): the generic staging iterator above costs ~80 mostly
         // scalar, branchy instructions per chunk IN FRONT of the wave's MFMAs (in-order issue).  Here the three ring steps of one
         // k-block are unrolled with everything they need in registers: the weight panel source is an SGPR base advanced by one
@@ -880,8 +1004,8 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
             const bf16_t* tpb = a.seg[0].base + a.seg[0].col0;          // k-block of the chunk being staged (chunk 2 = tap 2 of k-block 0 is next)
             auto fast_stage = [&](auto bufc) {
                 constexpr int BUF = decltype(bufc)::value;              // ring slot == tap
-                char* const abuf = lds + BUF * Cfg::BUF_BYTES;
-                char* const bbuf = abuf + Cfg::A_BYTES;
+                char* const abuf = lds + Cfg::a_base(BUF);
+                char* const bbuf = lds + Cfg::b_base(BUF);
                 if constexpr (BUF == 0) tpb += BK;
 #pragma unroll
                 for (int p = 0; p < APW; ++p) {
@@ -901,7 +1025,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                 // MFMAs of chunk ch-1 and the waits in front of them below the barrier, and does
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::LPC) : "memory");
                 __builtin_amdgcn_s_barrier();
-                const char* const buf = lds + BUF * Cfg::BUF_BYTES;
+                const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
                 bf16x8_t af[Cfg::KS][MT], bfr[Cfg::KS][NT];
 #pragma unroll
                 for (int ks = 0; ks < Cfg::KS; ++ks) {
@@ -910,7 +1034,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                         af[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + b_rd[j][ks]));
+                        bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 fast_stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
@@ -1206,6 +1330,10 @@ static inline int wn_launch_fused_pair(wn_ctx* ctx, GemmArgs& a, int Ma, GemmArg
 template <int EPI>
 static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st) {
     if (EPI == EPI_GATE && M % 64 != 0) WN_FAIL(ctx, WN_E_SHAPE, "gate GEMM needs gate_channels %% 64 == 0 (got M=%d)", M);
+    if (ctx->trace_state == 1 && ctx->trace_n < WN_TRACE_MAX) {      // WN_DEVTRACE: this launch's own stamp slot (takes the slot of wn_profile for this step)
+        a.kprof = ctx->trace_dev + 2 * ctx->trace_n;
+        ctx->trace_tag[ctx->trace_n].epi = EPI; ctx->trace_tag[ctx->trace_n].st = (void*)st; ctx->trace_tag[ctx->trace_n].rows = a.B * a.T; ++ctx->trace_n;
+    }
     if constexpr (EPI == EPI_STORE_BF16) {
         // Launches with fewer 256 x 128 tiles than workgroup slots (2 x 256) -- the out conv / head convs of a half batch: 344 --
         // take 256 x 64 tiles instead (K-chunks of 64, 2-deep ring, still two workgroups per CU): twice the workgroups, half the

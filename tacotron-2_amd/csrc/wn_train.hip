@@ -36,6 +36,32 @@ __global__ void wn_kprof_init_kernel(unsigned long long* k, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { k[2 * i] = ~0ull; k[2 * i + 1] = 0ull; }
 }
+// WN_DEVTRACE (wn_common.h): called at the start of every wn_train_fwd and at the end of every wn_train_bwd
+void wn_devtrace_poll(wn_ctx* c, hipStream_t st, bool step_start) {
+    static const char* path = getenv("WN_DEVTRACE");
+    if (!path) return;
+    static const int at = [] { const char* e = getenv("WN_DEVTRACE_STEP"); return e ? atoi(e) : 8; }();
+    if (!step_start) { if (c->trace_state == 1) c->trace_state = 2; return; }
+    ++c->trace_calls;
+    if (c->trace_calls == at) {
+        if (!c->trace_dev && hipMalloc((void**)&c->trace_dev, (size_t)WN_TRACE_MAX * 16) != hipSuccess) return;
+        hipLaunchKernelGGL(wn_kprof_init_kernel, dim3(cdiv(WN_TRACE_MAX, 256)), dim3(256), 0, st, c->trace_dev, WN_TRACE_MAX);
+        c->trace_n = 0; c->trace_state = 1;
+    } else if (c->trace_calls == at + 2 && c->trace_state == 2) {
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h(2 * WN_TRACE_MAX);
+        if (hipMemcpy(h.data(), c->trace_dev, 16 * (size_t)c->trace_n, hipMemcpyDeviceToHost) == hipSuccess) {
+            FILE* f = fopen(path, "w");
+            if (f) {
+                fprintf(f, "# idx epi stream rows start_ticks end_ticks (100 MHz)\n");
+                for (int i = 0; i < c->trace_n; ++i)
+                    fprintf(f, "%d %d %p %d %llu %llu\n", i, c->trace_tag[i].epi, c->trace_tag[i].st, c->trace_tag[i].rows, h[2 * i], h[2 * i + 1]);
+                fclose(f);
+            }
+        }
+        c->trace_state = 0;
+    }
+}
 extern "C" int wn_profile(wn_ctx* c, int32_t enable) {
     if (!c) return WN_E_ARG;
     c->prof = enable != 0; c->pev_used = 0;
@@ -453,6 +479,7 @@ template <class F> static int for_each_part(wn_ctx* c, hipStream_t st, F f) {
 
 int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
     int rc;
+    wn_devtrace_poll(c, st, true);
     if ((rc = wn_upsample_fwd(c, nullptr, c->fc, c->fB, c->fTc, st))) return rc;     // wavenet.py:680-702
     if ((rc = wn_first_conv(c, st))) return rc;                                      // wavenet.py:705
     if ((rc = wn_gbias_fwd(c, c->fB, st))) return rc;                                // wavenet.py:669-678
@@ -864,5 +891,6 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
     WN_HIP(c, hipStreamWaitEvent(st, c->ev_w0, 0));
     WN_HIP(c, hipEventRecord(c->ev_bucket[WN_MAX_BUCKETS], st));          // everything (incl. the late buckets) is final here
     c->have_bwd = true;
+    wn_devtrace_poll(c, st, false);
     return WN_OK;
 }

@@ -203,6 +203,7 @@ struct WgBatchArgs {
     float* partial;                     // [unit][mtiles*128 + 8][N] fp32; row mtiles*128 = bias partial
     int32_t B, T, slab, spu, Mrows, mtiles, ntiles, nunits;
     const bf16_t* zero;
+    unsigned long long* kprof;          // WN_DEVTRACE: {first workgroup's start, last workgroup's end} of this launch (null: off)
     WgGroup g[WN_MAX_GROUPS];
 };
 #define WG2_KT 32
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
     const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
     const int tile = q % tpu, u = (q / tpu) * 8 + xcd;
     if (u >= a.nunits) return;
+    if (a.kprof && tid == 0) atomicMin(a.kprof, (unsigned long long)wall_clock64());
     const int mblk = tile % mt_u, nblk = tile / mt_u;
     const int upg = a.B * a.spu;
     const int grp = u / upg, b = (u - grp * upg) / a.spu, sl = (u - grp * upg) % a.spu;
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
             P[(int64_t)(a.mtiles * 128) * a.N + n0 + tid] = sum;
         }
     }
+    if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
 }
 
 // out[m][n] += scale_g * sum_{units of group g} partial[unit][m][n];  bias rows likewise.  One float4 per thread.
@@ -553,7 +556,11 @@ static inline bool wn_wgrad_v2_ok(const WgBatchArgs& a) {
 static int launch_wgrad_batch(wn_ctx* c, WgBatchArgs& a, hipStream_t st) {
     wn_wgrad_plan(a);
     if (wn_wgrad_partial_bytes(a) > c->wg_partial_bytes) WN_FAIL(c, WN_E_STATE, "wgrad partial buffer too small (%zu > %zu)", wn_wgrad_partial_bytes(a), c->wg_partial_bytes);
-    a.partial = c->wg_partial; a.zero = c->zero_page;
+    a.partial = c->wg_partial; a.zero = c->zero_page; a.kprof = nullptr;
+    if (c->trace_state == 1 && c->trace_n < WN_TRACE_MAX) {      // WN_DEVTRACE: tag 100 + na
+        a.kprof = c->trace_dev + 2 * c->trace_n;
+        c->trace_tag[c->trace_n].epi = 100 + a.na; c->trace_tag[c->trace_n].st = (void*)st; c->trace_tag[c->trace_n].rows = a.ngroups; ++c->trace_n;
+    }
     const int grid = cdiv(a.nunits, 8) * a.hblocks * a.ntiles * 8;
     if (a.na == 3) hipLaunchKernelGGL((wn_wgrad_lds_kernel<3, 3>), dim3(grid), dim3(512), 0, st, a);
     else if (a.na == 2) hipLaunchKernelGGL((wn_wgrad_lds_kernel<3, 2>), dim3(grid), dim3(512), 0, st, a);

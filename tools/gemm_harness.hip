@@ -60,6 +60,25 @@ static void launch_prod(GemmArgs a, int M, hipStream_t st) {
     a.stagger = grid >= 1024 ? 8000 : 0;
     hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, PIPE, 3>), dim3(grid), dim3(512), 0, st, a);
 }
+// A-direct variant of the production launch (PIPE_ 8: weight fragments straight from the pack into VGPRs, 8 x 1 waves of 32 x 128)
+template <int EPI>
+static void launch_prod_ad(GemmArgs a, int M, hipStream_t st) {
+    a.mblocks = M / 256; a.tiles_per_utt = cdiv(a.T, 128); a.ntiles = a.tiles_per_utt * a.B;
+    a.xcd_span = cdiv(a.ntiles, 8); a.taps = 3;
+    const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+    a.stagger = grid >= 1024 ? 8000 : 0;
+    hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 4, 8, 1, 32, 3, EPI, 8, 3>), dim3(grid), dim3(512), 0, st, a);
+}
+// 16-wave variant: ONE 1024-thread workgroup per CU computes a 256 x 256 tile as 4 x 4 waves of 64 x 64 (same per-wave code and VGPR budget as
+// the production 256 x 128 kernel, same 16 waves per CU), so the A chunk in LDS is shared by twice the time rows: 2 DMAs per wave and chunk instead of 3
+template <int EPI>
+static void launch_prod16(GemmArgs a, int M, hipStream_t st) {
+    a.mblocks = M / 256; a.tiles_per_utt = cdiv(a.T, 256); a.ntiles = a.tiles_per_utt * a.B;
+    a.xcd_span = cdiv(a.ntiles, 8); a.taps = 3;
+    const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
+    a.stagger = 0;
+    hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 4, 32, 3, EPI, 1, 3>), dim3(grid), dim3(1024), 0, st, a);
+}
 static float time_ms(const std::function<void()>& f, int iters = 10) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     f(); CK(hipDeviceSynchronize());
@@ -131,6 +150,21 @@ int main(int argc, char** argv) {
             TRY_GATE3(4, 4, 2, 2, 32, 3, 1) TRY_GATE3(4, 4, 2, 2, 32, 3, 2) TRY_GATE3(4, 4, 2, 2, 64, 2, 1)
             TRY_GATE3(4, 2, 2, 4, 32, 3, 1) TRY_GATE3(2, 4, 4, 2, 32, 3, 1) TRY_GATE3(4, 2, 2, 4, 32, 3, 2)
         }
+        {   // A-direct vs production (TAPS 3 + the conditioning segment), same pack: bitwise
+            bf16_t* TS3 = dev_zero<bf16_t>(NT_ * G); bf16_t* U3 = dev_zero<bf16_t>(NT_ * GH);
+            GemmArgs a3 = a; a3.e.out0 = TS3; a3.e.out1 = U3; GemmArgs ap = a2; ap.stagger = 0;
+            launch_prod<EPI_GATE, 1>(ap, M, 0); CK(hipDeviceSynchronize());
+            for (int rnd = 0; rnd < 3; ++rnd) {
+                CK(hipMemset(TS3, 0xff, NT_ * G * 2)); CK(hipMemset(U3, 0xff, NT_ * GH * 2));
+                float tp = time_ms([&] { launch_prod<EPI_GATE, 1>(ap, M, 0); }); float ta = time_ms([&] { launch_prod_ad<EPI_GATE>(a3, M, 0); }); CK(hipDeviceSynchronize());
+                bool ok = same({TS2, (size_t)NT_ * G * 2}, {TS3, (size_t)NT_ * G * 2}, "TS") & same({U2, (size_t)NT_ * GH * 2}, {U3, (size_t)NT_ * GH * 2}, "U");
+                printf("gate   A-direct 8x1 waves: production %8.1f us %7.1f TF   A-direct %8.1f us %7.1f TF  %s\n", tp * 1e3, fl / tp / 1e9, ta * 1e3, fl / ta / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+                CK(hipMemset(TS3, 0xff, NT_ * G * 2)); CK(hipMemset(U3, 0xff, NT_ * GH * 2));
+                float t16 = time_ms([&] { launch_prod16<EPI_GATE>(a3, M, 0); }); CK(hipDeviceSynchronize());
+                ok = same({TS2, (size_t)NT_ * G * 2}, {TS3, (size_t)NT_ * G * 2}, "TS") & same({U2, (size_t)NT_ * GH * 2}, {U3, (size_t)NT_ * GH * 2}, "U");
+                printf("gate   16 waves 256x256     : %8.1f us %7.1f TF  %s\n", t16 * 1e3, fl / t16 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+            }
+        }
         TRY_GATE3(2, 2, 4, 2, 32, 2, 1) TRY_GATE3(2, 2, 4, 2, 64, 3, 1) TRY_GATE3(2, 2, 4, 2, 64, 3, 6) TRY_GATE3(2, 2, 4, 2, 64, 2, 6) TRY_GATE3(2, 4, 4, 2, 32, 3, 6) TRY_GATE3(4, 2, 2, 4, 32, 3, 6)
 #ifdef WN_EPI_ABLATE
         {   // main-loop timeline of the first workgroups (wave 0 and wave 5): stamps [before vmcnt wait, after it, after barrier, after DMA issue]
@@ -184,7 +218,7 @@ int main(int argc, char** argv) {
             }
             a2.trace = nullptr; a2.stagger = 0;
         }
-        for (int dbgf : {0, 1, 2, 3, 7}) { a2.stagger = dbgf ? -dbgf : 0; printf("  probe flags %d (1 noDMA 2 noLDSread 4 nobarrier 8 hotDMA): ", dbgf); TRY_GATE3(2, 2, 4, 2, 32, 3, 2) }
+        for (int dbgf : {0, 1, 2, 3, 7, 8, 10}) { a2.stagger = dbgf ? -dbgf : 0; printf("  probe flags %d (1 noDMA 2 noLDSread 4 nobarrier 8 hotDMA): ", dbgf); TRY_GATE3(2, 2, 4, 2, 32, 3, 2) }
         {   // SURVEY K3 probe (round 3): the MAIN LOOP of a 512-row tile -- what a fused gate + out-conv workgroup (all 512 gate channels of its
             // time rows, u kept on chip) would run -- against the production 256 x 128 tile, same contraction (M = 512, K = 848, sequential
             // segments, epilogue ablated).  No 512-row shape lets two workgroups share a CU: 512 x 64 needs K-chunks of 64 for its B tile to
@@ -197,6 +231,12 @@ int main(int argc, char** argv) {
                 float t3k = time_ms([&] { launch_v2<4, 2, 4, 2, 32, 3, EPI_STORE_BF16, 1>(a3, M, 0); });
                 printf("K3 probe main loop only: 256x128 BK32 ring3 x2/CU %7.1f us %6.1f TF | 512x64 BK64 ring2 x1/CU %7.1f us %6.1f TF | 512x128 BK32 ring3 x1/CU %7.1f us %6.1f TF\n",
                        t0 * 1e3, fl / t0 / 1e9, t1k * 1e3, fl / t1k / 1e9, t3k * 1e3, fl / t3k / 1e9);
+                // 256 x 256 tiles (one workgroup per CU, 4 DMA pieces per wave per 16 MFMAs instead of 3 per 8): wave tile 128 x 64 (2 x 4 waves) or 64 x 128 (4 x 2)
+                float tq1 = time_ms([&] { launch_v2<4, 2, 2, 4, 32, 3, EPI_STORE_BF16, 1>(a3, M, 0); });
+                float tq2 = time_ms([&] { launch_v2<2, 4, 4, 2, 32, 3, EPI_STORE_BF16, 1>(a3, M, 0); });
+                float tq3 = time_ms([&] { launch_v2<4, 2, 2, 4, 64, 2, EPI_STORE_BF16, 1>(a3, M, 0); });
+                printf("256x256 probe main loop only: wave 128x64 BK32 ring3 %7.1f us %6.1f TF | wave 64x128 BK32 ring3 %7.1f us %6.1f TF | wave 128x64 BK64 ring2 %7.1f us %6.1f TF\n",
+                       tq1 * 1e3, fl / tq1 / 1e9, tq2 * 1e3, fl / tq2 / 1e9, tq3 * 1e3, fl / tq3 / 1e9);
             }
         }
 #endif
@@ -269,6 +309,20 @@ int main(int argc, char** argv) {
         for (int rnd = 0; rnd < 3; ++rnd) {      // production configuration (timing only)
             float t0 = time_ms([&] { launch_prod<EPI_DX, 0>(a2, M, 0); }); float t1p = time_ms([&] { launch_prod<EPI_DX, 1>(a2, M, 0); });
             printf("dx     production TAPS3 xcd_span: PIPE0 %8.1f us %7.1f TF   PIPE1 %8.1f us %7.1f TF\n", t0 * 1e3, fl / t0 / 1e9, t1p * 1e3, fl / t1p / 1e9);
+        }
+        {   // A-direct vs production, same (K-interleaved reading of the) pack: bitwise
+            bf16_t* O3 = dev_zero<bf16_t>(NT_ * R); GemmArgs a3 = a; a3.e.out0 = O3;
+            launch_prod<EPI_DX, 1>(a2, M, 0); CK(hipDeviceSynchronize());
+            for (int rnd = 0; rnd < 3; ++rnd) {
+                CK(hipMemset(O3, 0xff, NT_ * R * 2));
+                float tp = time_ms([&] { launch_prod<EPI_DX, 1>(a2, M, 0); }); float ta = time_ms([&] { launch_prod_ad<EPI_DX>(a3, M, 0); }); CK(hipDeviceSynchronize());
+                bool ok = same({O2, (size_t)NT_ * R * 2}, {O3, (size_t)NT_ * R * 2}, "GX");
+                printf("dx     A-direct 8x1 waves: production %8.1f us %7.1f TF   A-direct %8.1f us %7.1f TF  %s\n", tp * 1e3, fl / tp / 1e9, ta * 1e3, fl / ta / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+                CK(hipMemset(O3, 0xff, NT_ * R * 2));
+                float t16 = time_ms([&] { launch_prod16<EPI_DX>(a3, M, 0); }); CK(hipDeviceSynchronize());
+                ok = same({O2, (size_t)NT_ * R * 2}, {O3, (size_t)NT_ * R * 2}, "GX");
+                printf("dx     16 waves 256x256     : %8.1f us %7.1f TF  %s\n", t16 * 1e3, fl / t16 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+            }
         }
         { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DX>(a2, M, 0); }); CK(hipDeviceSynchronize());
           bool ok = same({O1, (size_t)NT_ * R * 2}, {O2, (size_t)NT_ * R * 2}, "GX");

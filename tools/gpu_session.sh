@@ -15,6 +15,7 @@
 #   harness      tools/gemm_harness + ablation + wgrad harness tables
 #   pipetrace    WN_PIPE_TRACE stage trace of the synthesis pipeline (B = 1, 8) -> pipe_trace_b*.txt
 #   other        10-step runs of the other workloads only
+#   devtrace     the engine's own in-kernel stamps of one un-profiled step (WN_DEVTRACE) -> devtrace.txt, devtrace_timeline.txt
 #   benchw:<w>   short bench of workload <w> (c2_4stack, default_hparams, c5_stress); ktw:<w> its rocprofv3 kernel statistics
 TAG=${1:-s}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -70,6 +71,8 @@ import bench, torch
 print(json.dumps({k: bench.other_workload_subprocess(k, 0) for k in ('default_hparams', 'c2_4stack', 'c5_stress', 'c2_fp32')}, indent=1))      # a fresh process each (HW queue assignment)
 PY
       cut -c1-600 $OUT/other_workloads.json ;;
+    devtrace) WN_DEVTRACE=$OUT/devtrace.txt timeout 300 python bench.py --steps 12 --warmup 3 $BQ > $OUT/devtrace_bench.json 2> $OUT/devtrace.err
+      python tools/devtrace.py $OUT/devtrace.txt --all > $OUT/devtrace_timeline.txt 2>&1; head -30 $OUT/devtrace_timeline.txt ;;
     *) echo "unknown stage $st" ;;
   esac
 done
