@@ -810,6 +810,9 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         };
         auto mfma_set = [&](auto setc) {
             constexpr int SET = decltype(setc)::value;
+#ifdef WN_EPI_ABLATE
+            if (dbg & 64) { asm volatile("" :: "v"(fa[SET][0]), "v"(fb[SET][0])); return; }      // probe: DMAs, LDS reads, waits and barriers only
+#endif
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll

@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
             }
             a2.trace = nullptr; a2.stagger = 0;
         }
-        for (int dbgf : {0, 1, 2, 3, 7, 8, 10}) { a2.stagger = dbgf ? -dbgf : 0; printf("  probe flags %d (1 noDMA 2 noLDSread 4 nobarrier 8 hotDMA): ", dbgf); TRY_GATE3(2, 2, 4, 2, 32, 3, 2) }
+        for (int dbgf : {0, 1, 7, 8, 64, 68}) { a2.stagger = dbgf ? -dbgf : 0; printf("  probe flags %d (1 noDMA 2 noLDSread 4 nobarrier 8 hotDMA 64 noMFMA): ", dbgf); TRY_GATE3(2, 2, 4, 2, 32, 3, 2) }
         {   // SURVEY K3 probe (round 3): the MAIN LOOP of a 512-row tile -- what a fused gate + out-conv workgroup (all 512 gate channels of its
             // time rows, u kept on chip) would run -- against the production 256 x 128 tile, same contraction (M = 512, K = 848, sequential
             // segments, epilogue ablated).  No 512-row shape lets two workgroups share a CU: 512 x 64 needs K-chunks of 64 for its B tile to
