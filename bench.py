@@ -508,6 +508,23 @@ def main():
         sustained = {'what': '3 blocks x %d steps right after the timed region, same step function; median block' % args.sustained,
                      'ms_per_step_blocks': blocks, 'ms_per_step': med, 'value': world * B * T / (med * 1e-3), 'unit': 'audio_samples/s', 'smi': smi.summary()}
         _log('sustained: %s ms/step' % ', '.join('%.2f' % b for b in blocks))
+    # untimed extra: the device timeline of ONE step from the engine's in-kernel stamps (no profiler: rocprofv3 slows the host's enqueue
+    # enough to change which stream runs ahead) -- forward / backward chain / weight-gradient tail and how long two launches overlap
+    device_timeline = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import devtrace
+        torch.cuda.synchronize()
+        eng.trace_arm(6)                              # the 6th step from here: the host is ahead of the device again by then
+        for _i in range(9):
+            one_step(args.warmup + args.steps + _i)
+        device_timeline = devtrace.summarise(eng.trace_read())
+        if device_timeline:
+            device_timeline['what'] = ('one un-profiled step of the same loop, {first workgroup start, last workgroup end} stamps of every tile-engine / grouped '
+                                       'weight-gradient launch on the 100 MHz wall clock (wn_trace_arm / wn_trace_read, tools/devtrace.py)')
+            _log('device timeline: forward %.2f ms, backward chain %.2f ms, weight-gradient tail %.2f ms' % tuple((device_timeline[k] or 0) / 1e3 for k in ('forward_us', 'backward_chain_us', 'weight_gradient_tail_us')))
+    except Exception as e:          # a reported extra: never lose the JSON line to it
+        device_timeline = {'error': str(e)[:200]}
     # untimed extra: host time to ENQUEUE one step (the four C-ABI calls + the exchange, no device wait inside) next to the device time
     # of that step: the margin by which host launch cost hides behind the GPU (what a hipGraph capture of the step could remove)
     host_enqueue = None
@@ -597,7 +614,7 @@ def main():
                                         'traffic_write_per_step': traffic['write_bytes_per_step'] if traffic else None,
                                         'traffic_source': (traffic['source'] + ': sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE per step') if traffic else None},
             'mfma_whole_step_frac': 6.0 * mac * value / world / 1e12 / peak,
-            'sustained': sustained, 'host_enqueue': host_enqueue,
+            'sustained': sustained, 'host_enqueue': host_enqueue, 'device_timeline': device_timeline,
             'grad_buckets': [list(b) for b in eng.grad_buckets()], 'force_dist': bool(args.force_dist),
             'emulated_allreduce': ({'gbps': args.emulate_allreduce_gbps, 'bytes': int(eng.n_params) * 4,
                                     'serial_ms': int(eng.n_params) * 4 / (args.emulate_allreduce_gbps * 1e9) * 1e3,

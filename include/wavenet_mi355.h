@@ -243,6 +243,14 @@ int wn_profile_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
 int wn_profile_kernel_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
 /* time rows (utterances x samples) one timed launch processed: the layer chain runs per half-batch on two streams */
 int64_t wn_profile_rows_per_launch(const wn_ctx* ctx);
+/* Device timeline of ONE training step from in-kernel stamps, no profiler attached (a profiler slows the host's enqueue enough to change
+ * which stream runs ahead).  wn_trace_arm: every tile-engine and grouped weight-gradient launch of the `steps_from_now`-th next
+ * wn_train_fwd .. wn_train_bwd stamps {first workgroup's start, last workgroup's end} on the 100 MHz wall clock into its own slot.
+ * wn_trace_read (SYNCHRONISES the device): copies up to `cap` launches in enqueue order -- kind (0 gate, 1 out / skip / head conv,
+ * 2 fp32-output GEMM, 3 d z, 4 head mask GEMM, 5 d x, 100 + n: grouped weight gradient with n A tiles), stream handle, start / end
+ * ticks -- and returns their number (0 while no armed step has completed; negative wn_status on error). */
+int wn_trace_arm(wn_ctx* ctx, int32_t steps_from_now);
+int wn_trace_read(wn_ctx* ctx, int32_t cap, int32_t* kind, uint64_t* stream, uint64_t* start_ticks, uint64_t* end_ticks);
 /* A/B switch of the stream structure.  0: default (2 when the batch has >= 2 utterances), 1: whole batch on the caller's stream,
  * 2: two half-batches on two streams */
 int wn_set_batch_parts(wn_ctx* ctx, int32_t parts);

@@ -157,7 +157,7 @@ struct wn_ctx {
     // WN_DEVTRACE=<file> (debug): in-kernel {first start, last end} stamps of EVERY tile-engine launch of one training step (the
     // WN_DEVTRACE_STEP-th wn_train_fwd, default 8) -- the device timeline of the chain without a profiler attached (rocprofv3 slows the
     // host's enqueue enough to change which stream runs ahead).  Written two steps later by wn_devtrace_poll.
-    unsigned long long* trace_dev = nullptr; int trace_n = 0, trace_calls = 0, trace_state = 0;      // state: 0 idle, 1 recording, 2 recorded
+    unsigned long long* trace_dev = nullptr; int trace_n = 0, trace_calls = 0, trace_state = 0, trace_arm_at = 0;      // state: 0 idle, 1 recording, 2 recorded
 #define WN_TRACE_MAX 1024
     struct { int epi; void* st; int rows; } trace_tag[WN_TRACE_MAX];
     unsigned long long* kprof_dev = nullptr;      // [WN_KPROF_MAX][2] in-kernel {first start, last end} stamps of the timed gate launches

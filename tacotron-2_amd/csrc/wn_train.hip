@@ -36,18 +36,23 @@ __global__ void wn_kprof_init_kernel(unsigned long long* k, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { k[2 * i] = ~0ull; k[2 * i + 1] = 0ull; }
 }
-// WN_DEVTRACE (wn_common.h): called at the start of every wn_train_fwd and at the end of every wn_train_bwd
+// Device timeline from in-kernel stamps (wn_common.h): called at the start of every wn_train_fwd and at the end of every wn_train_bwd.
+// Armed by wn_trace_arm (results through wn_trace_read) or by WN_DEVTRACE=<file> (the WN_DEVTRACE_STEP-th forward, written two steps later).
+static bool devtrace_begin(wn_ctx* c, hipStream_t st) {
+    if (!c->trace_dev && hipMalloc((void**)&c->trace_dev, (size_t)WN_TRACE_MAX * 16) != hipSuccess) return false;
+    hipLaunchKernelGGL(wn_kprof_init_kernel, dim3(cdiv(WN_TRACE_MAX, 256)), dim3(256), 0, st, c->trace_dev, WN_TRACE_MAX);
+    c->trace_n = 0; c->trace_state = 1;
+    return true;
+}
 void wn_devtrace_poll(wn_ctx* c, hipStream_t st, bool step_start) {
     static const char* path = getenv("WN_DEVTRACE");
-    if (!path) return;
     static const int at = [] { const char* e = getenv("WN_DEVTRACE_STEP"); return e ? atoi(e) : 8; }();
     if (!step_start) { if (c->trace_state == 1) c->trace_state = 2; return; }
     ++c->trace_calls;
-    if (c->trace_calls == at) {
-        if (!c->trace_dev && hipMalloc((void**)&c->trace_dev, (size_t)WN_TRACE_MAX * 16) != hipSuccess) return;
-        hipLaunchKernelGGL(wn_kprof_init_kernel, dim3(cdiv(WN_TRACE_MAX, 256)), dim3(256), 0, st, c->trace_dev, WN_TRACE_MAX);
-        c->trace_n = 0; c->trace_state = 1;
-    } else if (c->trace_calls == at + 2 && c->trace_state == 2) {
+    if (c->trace_arm_at && c->trace_calls == c->trace_arm_at) { c->trace_arm_at = 0; devtrace_begin(c, st); return; }
+    if (!path) return;
+    if (c->trace_calls == at) devtrace_begin(c, st);
+    else if (c->trace_calls == at + 2 && c->trace_state == 2) {
         (void)hipDeviceSynchronize();
         std::vector<unsigned long long> h(2 * WN_TRACE_MAX);
         if (hipMemcpy(h.data(), c->trace_dev, 16 * (size_t)c->trace_n, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -61,6 +66,25 @@ void wn_devtrace_poll(wn_ctx* c, hipStream_t st, bool step_start) {
         }
         c->trace_state = 0;
     }
+}
+extern "C" int wn_trace_arm(wn_ctx* c, int32_t steps_from_now) {
+    if (!c || steps_from_now < 1) return WN_E_ARG;
+    if (c->inference) WN_FAIL(c, WN_E_STATE, "wn_trace_arm: no training workspace on an inference-only context");
+    c->trace_arm_at = c->trace_calls + steps_from_now; c->trace_state = 0;
+    return WN_OK;
+}
+extern "C" int wn_trace_read(wn_ctx* c, int32_t cap, int32_t* kind, uint64_t* stream, uint64_t* start_ticks, uint64_t* end_ticks) {
+    if (!c || cap < 0 || !kind || !stream || !start_ticks || !end_ticks) return WN_E_ARG;
+    if (c->trace_state != 2) return 0;
+    WN_HIP(c, hipDeviceSynchronize());
+    std::vector<unsigned long long> h(2 * (size_t)WN_TRACE_MAX);
+    WN_HIP(c, hipMemcpy(h.data(), c->trace_dev, 16 * (size_t)c->trace_n, hipMemcpyDeviceToHost));
+    const int n = std::min<int>(cap, c->trace_n);
+    for (int i = 0; i < n; ++i) {
+        kind[i] = c->trace_tag[i].epi; stream[i] = (uint64_t)(uintptr_t)c->trace_tag[i].st;
+        start_ticks[i] = h[2 * i]; end_ticks[i] = h[2 * i + 1];
+    }
+    return n;
 }
 extern "C" int wn_profile(wn_ctx* c, int32_t enable) {
     if (!c) return WN_E_ARG;

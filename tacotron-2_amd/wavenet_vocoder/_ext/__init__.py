@@ -109,6 +109,8 @@ def load_library():
         'wn_profile_rows_per_launch': (i64, [vp]),
         'wn_set_batch_parts': (ctypes.c_int, [vp, i32]),
         'wn_debug_copy': (ctypes.c_int, [vp, ctypes.c_char_p, i32, vp, i64, vp]),
+        'wn_trace_arm': (ctypes.c_int, [vp, i32]),
+        'wn_trace_read': (ctypes.c_int, [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
         'wn_set_global_condition': (ctypes.c_int, [vp, vp, i32, vp]),
         'wn_workspace_bytes': (i64, [vp]),
         'wn_dominant_kernel_name': (ctypes.c_char_p, []),
@@ -359,6 +361,18 @@ class Engine:
 
     def profile_rows_per_launch(self):
         return int(self.lib.wn_profile_rows_per_launch(self.h))
+
+    def trace_arm(self, steps_from_now=1):
+        """Stamp every tile-engine / grouped weight-gradient launch of the `steps_from_now`-th next training step (wn_trace_arm)."""
+        self._ok(self.lib.wn_trace_arm(self.h, int(steps_from_now)))
+
+    def trace_read(self, cap=1024):
+        """[(kind, stream, start_tick, end_tick)] of the armed step in enqueue order, 100 MHz ticks; [] if it has not completed.  Synchronises."""
+        k = (ctypes.c_int32 * cap)(); st = (ctypes.c_uint64 * cap)(); t0 = (ctypes.c_uint64 * cap)(); t1 = (ctypes.c_uint64 * cap)()
+        n = self.lib.wn_trace_read(self.h, cap, k, st, t0, t1)
+        if n < 0:
+            self._ok(n)
+        return [(int(k[i]), int(st[i]), int(t0[i]), int(t1[i])) for i in range(n)]
 
     def debug_copy(self, name, layer, rows, cols):
         import torch

@@ -139,6 +139,43 @@ def test_backward_and_optimizer_are_bit_reproducible():
     assert not torch.equal(outs[0][0], flat)
 
 
+def test_device_timeline_stamps_cover_every_chain_launch():
+    """wn_trace_arm / wn_trace_read (test hooks; bench.py's `device_timeline`): the armed step stamps every tile-engine and grouped
+    weight-gradient launch -- one gate and one d x launch per layer and batch part, ends after starts, the backward after the forward --
+    and nothing is reported before the armed step has run."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import devtrace
+    from wavenet_vocoder import _ext
+    hp = make_hp(**dict(PAPER, layers=6, stacks=2))
+    cfg = oracle_cfg(hp)
+    B, T = 4, 2200
+    eng = _ext.Engine(hp, B, T)
+    params = O.init_params(cfg, seed=5339, bias_scale=0.05)
+    eng.pack_weights(upload_params(eng, params))
+    wav, c = synth_batch(cfg, B, T, seed=3)
+    x, y = wav.view(B, 1, T).contiguous().cuda(), wav.view(B, T, 1).contiguous().cuda()
+    ln = torch.full((B,), T, dtype=torch.int32, device='cuda')
+    loss = torch.zeros(1, device='cuda'); grads = torch.empty(eng.n_params, device='cuda')
+    eng.trace_arm(2)
+    assert eng.trace_read() == []
+    for i in range(3):
+        eng.train_fwd(x, c.cuda(), y, ln, 10 + i, loss)
+        if i == 0:
+            assert eng.trace_read() == []                 # armed for the second step
+        eng.train_bwd(grads)
+    rows = eng.trace_read()
+    valid = [r for r in rows if r[2] != devtrace.NEVER]          # (launches of the few kernels that carry no stamp code keep their slot's initial value)
+    kinds = [r[0] for r in valid]
+    assert kinds.count(0) == 6 * 2 and kinds.count(5) == 6 * 2 and kinds.count(3) == 6 * 2 and any(k >= 100 for k in kinds), kinds
+    assert all(r[3] >= r[2] for r in valid) and len(valid) >= len(rows) - 4
+    s = devtrace.summarise(rows)
+    assert len(s['streams']) >= 2 and s['forward_us'] > 0 and s['backward_chain_us'] > 0 and s['weight_gradient_tail_us'] > 0
+    assert max(r[3] for r in rows if r[0] == 0) <= min(r[2] for r in rows if r[0] == 5)      # every gate launch ends before the first d x starts
+    print('\ndevice timeline (6 layers, B = 4 x 2200): forward %.0f us, backward chain %.0f us, tail %.0f us; in flight %s'
+          % (s['forward_us'], s['backward_chain_us'], s['weight_gradient_tail_us'], s['in_flight_us']))
+
+
 @pytest.mark.parametrize('layers,stacks,want', [(8, 2, 3), (12, 2, 5), (14, 2, 6), (16, 2, 7), (6, 2, 3)])
 def test_gradient_buckets_of_narrow_models(layers, stacks, want):
     """narrow models (G % 256 != 0) take the per-layer weight-gradient kernels AFTER the chain, so no early bucket

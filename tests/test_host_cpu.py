@@ -809,3 +809,25 @@ def test_bench_traffic_constants_come_from_the_committed_pmc_summary():
     assert abs(sum(v['bytes_per_step'] for v in t['kernels'].values()) - t['bytes_per_step']) < 1.0
     assert 20e9 < t['bytes_per_step'] < 60e9 and t['gate_launches_per_step'] == 48
     assert bench.load_traffic('c2', 4, 11000) is None and bench.load_traffic('c5_stress', 8, 12000) is None
+
+
+def test_device_timeline_summary_of_in_kernel_stamps(tmp_path):
+    """tools/devtrace.py (what bench.py's `device_timeline` block and the WN_DEVTRACE file view are made of): phases and overlap of a
+    hand-made two-stream step -- forward until the first backward launch, backward chain until the last d x, tail until the last weight
+    gradient; launches that never ran (start stamp still ~0ull) are ignored."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import devtrace
+    T0 = 5_000_000
+    rows = [(0, 'a', T0, T0 + 6000), (0, 'b', T0 + 10, T0 + 7000), (1, 'a', T0 + 6000, T0 + 10000), (1, 'b', T0 + 7000, T0 + 10000),      # forward: 100 us
+            (4, 'b', T0 + 10000, T0 + 11000), (4, 'a', T0 + 10500, T0 + 11500), (3, 'a', T0 + 11500, T0 + 15000), (5, 'a', T0 + 15000, T0 + 20000),
+            (3, 'b', T0 + 11000, T0 + 14000), (5, 'b', T0 + 14000, T0 + 19000),                                                           # chain ends at 200 us
+            (103, 'c', T0 + 20000, T0 + 29000), (101, 'c', T0 + 29000, T0 + 30000), (2, 'a', T0 + 20000, T0 + 25000),
+            (102, 'c', devtrace.NEVER, 0)]
+    s = devtrace.summarise(rows)
+    assert s['launches'] == 13 and abs(s['span_us'] - 300.0) < 1e-9
+    assert abs(s['forward_us'] - 100.0) < 1e-9 and abs(s['backward_chain_us'] - 100.0) < 1e-9 and abs(s['weight_gradient_tail_us'] - 100.0) < 1e-9
+    assert abs(sum(s['in_flight_us'].values()) - 300.0) < 1e-6 and abs(s['in_flight_us']['1'] - (0.1 + 5 + 10 + 40 + 10)) < 1e-6
+    assert [st['launches'] for st in s['streams']] == [6, 5, 2] and s['streams'][1]['first_backward_start_us'] == 100.0
+    f = tmp_path / 'trace.txt'
+    f.write_text('# idx epi stream rows start end\n' + ''.join('%d %d %s 1 %d %d\n' % (i, r[0], r[1], r[2], r[3]) for i, r in enumerate(rows)))
+    assert devtrace.summarise(devtrace.parse_file(str(f))) == s
