@@ -995,7 +995,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         // scalar add per chunk (SGPR-base DMA form), the activation source one 64-bit add per lane and tap; no segment
         // bookkeeping, no division, one loop branch per three chunks.  Same chunk order, same sums.
         const int nkb = a.seg[0].nk / BK;
-        if (nkb >= 2 && dbg == 0 && nchunks > 3 * (nkb - 1) + 1) {
+        if (nkb >= 2 && (dbg == 0 || dbg == 128) && nchunks > 3 * (nkb - 1) + 1) {      // (dbg 128: harness probe, see below)
             uint64_t sa[APW];
 #pragma unroll
             for (int p = 0; p < APW; ++p) {
@@ -1012,6 +1012,9 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                 if constexpr (BUF == 0) tpb += BK;
 #pragma unroll
                 for (int p = 0; p < APW; ++p) {
+#ifdef WN_EPI_ABLATE      // probe 128: only the first A piece per wave is DMA'd (wrong sums; the DMA count of a 128 x 256 tile that shares its B rows between the taps)
+                    if (dbg == 128 && p > 0) { sa[p] += Cfg::KS * 1024; continue; }
+#endif
                     lds_dma16_s(sa[p], a_voff, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + (wave + p * NWD) * 1024)));
                     sa[p] += Cfg::KS * 1024;
                 }
@@ -1026,6 +1029,9 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                 // chunk ch landed (only chunk ch+1 may still be in flight); lgkmcnt(0): this wave's fragment reads of chunk ch-1 have
                 // RETURNED before the barrier releases its ring slot to the next DMA -- the compiler is free to sink the (register-only)
                 // MFMAs of chunk ch-1 and the waits in front of them below the barrier, and does
+#ifdef WN_EPI_ABLATE
+                if (dbg == 128) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::LPC - APW + 1) : "memory"); else
+#endif
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::LPC) : "memory");
                 __builtin_amdgcn_s_barrier();
                 const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);

@@ -163,6 +163,11 @@ int main(int argc, char** argv) {
                 float t16 = time_ms([&] { launch_prod16<EPI_GATE>(a3, M, 0); }); CK(hipDeviceSynchronize());
                 ok = same({TS2, (size_t)NT_ * G * 2}, {TS3, (size_t)NT_ * G * 2}, "TS") & same({U2, (size_t)NT_ * GH * 2}, {U3, (size_t)NT_ * GH * 2}, "U");
                 printf("gate   16 waves 256x256     : %8.1f us %7.1f TF  %s\n", t16 * 1e3, fl / t16 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+#ifdef WN_EPI_ABLATE
+                { float tq = time_ms([&] { GemmArgs q = ap; q.mblocks = M / 256; q.tiles_per_utt = cdiv(q.T, 128); q.ntiles = q.tiles_per_utt * q.B; q.xcd_span = cdiv(q.ntiles, 8); q.taps = 3; q.stagger = -128;
+                      hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI_GATE, 1, 3>), dim3(cdiv(q.ntiles, 8) * q.mblocks * 8), dim3(512), 0, 0, q); });
+                  printf("gate   probe 128 (2 DMAs per wave and chunk instead of 3, sums wrong): %8.1f us %7.1f TF\n", tq * 1e3, fl / tq / 1e9); }
+#endif
             }
         }
         TRY_GATE3(2, 2, 4, 2, 32, 2, 1) TRY_GATE3(2, 2, 4, 2, 64, 3, 1) TRY_GATE3(2, 2, 4, 2, 64, 3, 6) TRY_GATE3(2, 2, 4, 2, 64, 2, 6) TRY_GATE3(2, 4, 4, 2, 32, 3, 6) TRY_GATE3(4, 2, 2, 4, 32, 3, 6)
@@ -322,6 +327,11 @@ int main(int argc, char** argv) {
                 float t16 = time_ms([&] { launch_prod16<EPI_DX>(a3, M, 0); }); CK(hipDeviceSynchronize());
                 ok = same({O2, (size_t)NT_ * R * 2}, {O3, (size_t)NT_ * R * 2}, "GX");
                 printf("dx     16 waves 256x256     : %8.1f us %7.1f TF  %s\n", t16 * 1e3, fl / t16 / 1e9, ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+#ifdef WN_EPI_ABLATE
+                { GemmArgs ap2 = a2; float tq = time_ms([&] { GemmArgs q = ap2; q.mblocks = M / 256; q.tiles_per_utt = cdiv(q.T, 128); q.ntiles = q.tiles_per_utt * q.B; q.xcd_span = cdiv(q.ntiles, 8); q.taps = 3; q.stagger = -128;
+                      hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI_DX, 1, 3>), dim3(cdiv(q.ntiles, 8) * q.mblocks * 8), dim3(512), 0, 0, q); });
+                  printf("dx     probe 128 (2 DMAs per wave and chunk instead of 3, sums wrong): %8.1f us %7.1f TF\n", tq * 1e3, fl / tq / 1e9); }
+#endif
             }
         }
         { float t2 = time_ms([&] { launch_v2<2, 2, 4, 2, 32, 3, EPI_DX>(a2, M, 0); }); CK(hipDeviceSynchronize());
