@@ -245,7 +245,7 @@ static void wgrad_head2_args(wn_ctx* c, WgBatchArgs& w, int B, int T) {
 }
 static bool wgrad_heads_ok(wn_ctx* c) {
     static const int v = [] { const char* e = getenv("WN_WGRAD_HEADS"); return e ? atoi(e) : 1; }();      // A/B switch (0: round-1 kernel)
-    if (!v || c->S % 256 != 0 || c->O > 128) return false;
+    if (!v || c->S % 8 != 0 || c->O > 128) return false;
     WgBatchArgs w; wgrad_head1_args(c, w, 1, c->maxT); if (!wn_wgrad_v2_ok(w)) return false;
     wgrad_head2_args(c, w, 1, c->maxT); return wn_wgrad_v2_ok(w);
 }

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = a_mrow[x] + (wk * 2 + i) * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                P[(int64_t)m * a.N + n] = acc[x][i][j][r];
+                if (n < a.N) P[(int64_t)m * a.N + n] = acc[x][i][j][r];          // (N % 256 != 0: the last column tile is partial)
             }
         }
     }
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(512, (NA == 1 ? 4 : 2)) void wn_wgrad_lds_kernel(co
             float sum = 0.0f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) sum += red[g * 256 + tid];
-            P[(int64_t)(a.mtiles * 128) * a.N + n0 + tid] = sum;
+            if (n0 + tid < a.N) P[(int64_t)(a.mtiles * 128) * a.N + n0 + tid] = sum;
         }
     }
     if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(const WgBatchArgs 
 // plan the unit split: enough workgroups for >= ~2 rounds of 2 x 256, slabs a multiple of the 32-row chunk
 static inline void wn_wgrad_plan(WgBatchArgs& a) {
     a.Mrows = 0; for (int s = 0; s < a.nseg; ++s) a.Mrows += a.seg_nk[s];
-    a.mtiles = cdiv(a.Mrows, 128); a.ntiles = a.N / 256;
+    a.mtiles = cdiv(a.Mrows, 128); a.ntiles = cdiv(a.N, 256);
     if (a.na <= 1) { a.na = 1; a.hblocks = a.mtiles; }
     const int tpu = a.hblocks * a.ntiles;
     // time slabs per utterance: multi-A workgroups are alone on their CU (one round = 256 workgroups) and every extra slab costs a
@@ -549,7 +549,9 @@ static inline void wn_wgrad_plan(WgBatchArgs& a) {
 }
 static inline size_t wn_wgrad_partial_bytes(const WgBatchArgs& a) { return (size_t)a.nunits * (a.mtiles * 128 + 8) * a.N * 4; }
 static inline bool wn_wgrad_v2_ok(const WgBatchArgs& a) {
-    if (a.N % 256 != 0 || (a.ldw % 4 != 0 && !a.transpose_out) || a.ngroups > WN_MAX_GROUPS) return false;
+    // N: whole 8-column DMA slots and float4 reduce items (the last 256-column tile may be partial: its missing columns stage the zero
+    // page and are not written); with a split B operand both halves likewise
+    if (a.N % 8 != 0 || (a.split_n > 0 && a.split_n % 8 != 0) || (a.ldw % 4 != 0 && !a.transpose_out) || (a.split_n > 0 && a.ldw_hi % 4 != 0) || a.ngroups > WN_MAX_GROUPS) return false;
     for (int s = 0; s < a.nseg; ++s) if (a.seg_nk[s] % 8 != 0 || (a.seg_nk[s] % 128 != 0 && s != a.nseg - 1)) return false;
     return true;
 }
