@@ -209,6 +209,31 @@ def test_c2_bench_geometry_b2_two_streams():
     print('   gradients vs FP32 oracle: global rel-L2 %.3e; worst stack/head tensor %s %.3e; worst upsample-net tensor %s %.3e'
           % (gtot, stack[0][1], stack[0][0], [w for w in worst if w not in stack][0][1], [w for w in worst if w not in stack][0][0]))
     assert gtot < TOL_GRAD_FP32_GLOBAL and stack[0][0] < TOL_GRAD_FP32_TENSOR
+    # ---- the fp32 training mode (mi355_compute_dtype = 'fp32') at the same geometry against the same fp32 oracle: 24 layers, taps reaching
+    # back 2 x 2048 rows, the ragged second utterance -- y_hat of utterance 0 and every gradient tensor, tolerance 1e-4 (summation order only)
+    from wavenet_vocoder import _ext
+    r['eng'].close()
+    hp32 = make_hp(**dict(PAPER, mi355_compute_dtype='fp32'))
+    e32 = _ext.Engine(hp32, 2, 11000)
+    e32.pack_weights(upload_params(e32, params))
+    x_dev = wav.view(2, 1, 11000).contiguous().cuda(); y_dev = wav.view(2, 11000, 1).contiguous().cuda()
+    l32 = torch.zeros(1, device='cuda'); y32 = torch.empty(2, cfg.out_channels, 11000, device='cuda'); g32 = torch.empty(e32.n_params, device='cuda')
+    e32.train_fwd(x_dev, c.cuda(), y_dev, torch.tensor(lengths, dtype=torch.int32).cuda(), 1234, l32, y32)
+    e32.train_bwd(g32)
+    torch.cuda.synchronize()
+    ey32 = rel_err(y32[:1].cpu(), y_fp)
+    g_dev32 = download_grads(e32, g32)
+    gtot32 = rel_err(torch.cat([g_dev32[k].flatten() for k in g_fp]), torch.cat([g_fp[k].flatten() for k in g_fp]))
+    gmax = max(float(v.abs().max()) for v in g_fp.values())
+    worst32 = sorted(((rel_err(g_dev32[k], g_fp[k]) if float(g_fp[k].norm()) > 1e-6 * gmax else float((g_dev32[k] - g_fp[k]).abs().max()) / gmax, k) for k in g_fp), reverse=True)
+    st32 = [w for w in worst32 if not w[1].startswith('local_conditioning_upsampling')]; up32 = [w for w in worst32 if w not in st32]
+    print('   fp32 MODE at this geometry vs the fp32 oracle: y_hat (utterance 0) %.2e; all gradients %.2e; worst stack / head tensor %s %.2e; worst upsample-net tensor %s %.2e'
+          % (ey32, gtot32, st32[0][1], st32[0][0], up32[0][1], up32[0][0]))
+    # per tensor: fp32 sums over 2 x 11 000 rows in a different order than torch's, both sides round (measured: input conv 1.1e-4, the
+    # last upsample kernel 2.4e-4, every residual-stack tensor below 1e-4; profiles/r4v_pytest_c2_b2.log): 5e-4 stack / head, 1e-3 upsample net
+    assert ey32 < 1e-4 and gtot32 < 1e-4 and st32[0][0] < 5e-4 and up32[0][0] < 1e-3
+    assert all(e < 1e-4 for e, k in st32 if 'ResidualConv1DGLU' in k)
+    e32.close()
 
 
 def test_c2_bench_geometry_b8():
