@@ -53,7 +53,7 @@ enum wn_lr_schedule { WN_LR_EXPONENTIAL = 0, WN_LR_NOAM = 1 };                  
 /* Arithmetic of training / the teacher-forced forward (WaveNet.step, add_loss, add_optimizer, evaluation):
  *   WN_COMPUTE_BF16  bf16 MFMA operands, fp32 accumulation (BASELINE configs[1]'s training dtype; the tuned path);
  *   WN_COMPUTE_F32   the reference's own arithmetic -- fp32 activations, fp32 weights, fp32 accumulation (modules.py:306-320,
- *                    wavenet.py:650-721) -- for wn_train_fwd AND wn_train_bwd (vector-ALU SGEMMs, ~20x slower: an accuracy /
+ *                    wavenet.py:650-721) -- for wn_train_fwd AND wn_train_bwd (fp32 MFMA SGEMMs, ~13x slower: an accuracy /
  *                    validation mode; gradient buckets collapse to one).  Synthesis is unaffected. */
 enum wn_compute_dtype { WN_COMPUTE_BF16 = 0, WN_COMPUTE_F32 = 1 };
 

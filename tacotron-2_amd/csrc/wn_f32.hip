@@ -7,8 +7,8 @@
 // no packing) and fp32 FMA accumulation in a fixed k order, AND its backward (replaces tf.gradients, wavenet.py:557, in the same
 // arithmetic): every data gradient as the same SGEMM with transposed weight strides, every weight gradient as a time contraction with
 // ordered partial sums (no atomics), the gate derivative from the saved fp32 pre-activations.  It serves WaveNet.step / evaluation and a
-// complete fp32 TRAINING step (wn_train_fwd + wn_train_bwd + the shared optimiser).  Not tuned: 64 x 64 x 16 LDS-tiled SGEMMs on the
-// vector ALU (the f32 MFMA rate on gfx950 equals the f32 vector rate: nothing to gain from the matrix pipe); 210 ms per C2 step (34 TFLOP/s algorithmic, profiles/r4i_other_workloads.json).
+// complete fp32 TRAINING step (wn_train_fwd + wn_train_bwd + the shared optimiser).  128 x 128 x 16 LDS-tiled SGEMMs on the fp32 matrix
+// instruction (v_mfma_f32_32x32x2_f32: the vector FMA's peak with 1/64 of its instruction count); 128 ms per C2 step (56 TFLOP/s algorithmic, profiles/r4w_bench_c2_fp32.json).
 #include "wn_common.h"
 
 struct F32State {
@@ -37,79 +37,132 @@ struct SgemmArgs {
     uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;      // thresh16 > 0: dropout mask on the A operand (modules.py:484)
 };
 
-#define SG_T 64
+#define SG_T 128          // workgroup tile: 128 time rows x 128 output channels, 4 waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32)
 #define SG_K 16
+// v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation, in a fixed order.  A operand: lane l holds A[l % 32][l / 32]; B operand
+// B[l / 32][l % 32]; accumulator register r of lane l is element (8 (r / 4) + 4 (l / 32) + r % 4, l % 32).  Same peak as the vector FMA
+// (157 TFLOP/s) with 1/64 of the instruction count: the loop below is 4 ds_read_b32 per 4 MFMAs.
 __global__ __launch_bounds__(256) void wn_f32_sgemm_kernel(const SgemmArgs a) {
-    __shared__ float As[SG_K][SG_T + 4];
-    __shared__ float Bs[SG_K][SG_T + 4];
-    const int tid = threadIdx.x;
+    __shared__ float As[SG_K][SG_T + 4];       // [k][row]
+    __shared__ float Bs[SG_K][SG_T + 4];       // [k][m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
     const int tiles_per_utt = (a.T + SG_T - 1) / SG_T;
     const int b = blockIdx.x / tiles_per_utt, t0 = (blockIdx.x - b * tiles_per_utt) * SG_T;
     const int m0 = blockIdx.y * SG_T;
     const int64_t rowbase = (int64_t)b * a.T;
-    const int tr = tid >> 4, tc = tid & 15;        // this thread's 4 x 4 micro tile: rows tr*4.., columns tc*4..
-    float acc[4][4];
+    f32x16_t acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
-    // staging assignment: A: row = tid >> 2, 4 consecutive k = (tid & 3) * 4;  B: k = tid >> 4, 4 consecutive m = (tid & 15) * 4
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // staging assignment: A: rows ar and ar + 64, 4 consecutive k = (tid & 3) * 4;  B: k = tid >> 4, 8 consecutive m = (tid & 15) * 8
     const int ar = tid >> 2, ak = (tid & 3) * 4;
-    const int bk = tid >> 4, bm = (tid & 15) * 4;
-    const int ts = t0 + ar + a.shift;
-    const bool a_ok = (t0 + ar < a.T) && ts >= 0 && ts < a.T;
-    const int64_t arow = rowbase + ts;
-    for (int k0 = 0; k0 < a.K; k0 += SG_K) {
-        float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (a_ok) {
+    const int bk = tid >> 4, bm = (tid & 15) * 8;
+    // 16-B loads where the operand allows it (row pitches / offsets multiples of 4 floats; transposed weights are read along their pitch: scalar)
+    const bool vecA = (a.ld_in % 4 == 0) && (a.col0 % 4 == 0) && (a.drop_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.In) & 15) == 0);
+    const bool vecB = (a.wm == 1) && (a.wk % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
+    const bool vecBT = (a.wk == 1) && (a.wm % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
+    float av[2][4], bv[8];
+    const int tm = tid >> 1, tk = (tid & 1) * 8;      // transposed weights (data gradients: wk == 1): 8 consecutive k of output channel m0 + tm
+    auto load_chunk = [&](const int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tl = t0 + ar + 64 * h, ts = tl + a.shift;
+            const bool a_ok = (tl < a.T) && ts >= 0 && ts < a.T;
+            const int64_t arow = rowbase + ts;
+            const int kb = k0 + ak;
+            if (a_ok && vecA && kb + 4 <= a.K) {      // one 16-B load, one dropout word per element pair (wn_drop_word: 2 x 16 bits)
+                const float4 q = *reinterpret_cast<const float4*>(a.In + arow * a.ld_in + a.col0 + kb);
+                av[h][0] = q.x; av[h][1] = q.y; av[h][2] = q.z; av[h][3] = q.w;
+                if (a.thresh16 && !a.drop_on_out) {
+                    const uint32_t el = (uint32_t)(arow * a.drop_ld + a.col0 + kb);          // multiple of 4
+                    const uint32_t w0 = wn_drop_word(a.key_lo, a.key_hi, el >> 1), w1 = wn_drop_word(a.key_lo, a.key_hi, (el >> 1) + 1);
+                    av[h][0] = (w0 & 0xffffu) >= a.thresh16 ? av[h][0] * a.keep_scale : 0.0f;
+                    av[h][1] = (w0 >> 16) >= a.thresh16 ? av[h][1] * a.keep_scale : 0.0f;
+                    av[h][2] = (w1 & 0xffffu) >= a.thresh16 ? av[h][2] * a.keep_scale : 0.0f;
+                    av[h][3] = (w1 >> 16) >= a.thresh16 ? av[h][3] * a.keep_scale : 0.0f;
+                }
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int k = k0 + ak + e;
-                if (k < a.K) {
-                    float v = a.In[arow * a.ld_in + a.col0 + k];
+                const int k = kb + e;
+                float v = 0.0f;
+                if (a_ok && k < a.K) {
+                    v = a.In[arow * a.ld_in + a.col0 + k];
                     if (a.thresh16 && !a.drop_on_out) {
                         const uint32_t el = (uint32_t)(arow * a.drop_ld + a.col0 + k);
                         const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, el >> 1);
                         const uint32_t bits = (el & 1u) ? (w >> 16) : (w & 0xffffu);
                         v = bits >= a.thresh16 ? v * a.keep_scale : 0.0f;
                     }
-                    av[e] = v;
                 }
+                av[h][e] = v;
+            }
             }
         }
-        float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (k0 + bk < a.K) {
+        if (vecBT) {
+            if (m0 + tm < a.M && k0 + tk + 8 <= a.K) {
+                const float4* wp = reinterpret_cast<const float4*>(a.W + (int64_t)(m0 + tm) * a.wm + k0 + tk);
+                const float4 q0 = wp[0], q1 = wp[1];
+                bv[0] = q0.x; bv[1] = q0.y; bv[2] = q0.z; bv[3] = q0.w; bv[4] = q1.x; bv[5] = q1.y; bv[6] = q1.z; bv[7] = q1.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (m0 + bm + e < a.M) bv[e] = a.W[(int64_t)(k0 + bk) * a.wk + (int64_t)(m0 + bm + e) * a.wm];
+                for (int e = 0; e < 8; ++e) bv[e] = (m0 + tm < a.M && k0 + tk + e < a.K) ? a.W[(int64_t)(m0 + tm) * a.wm + k0 + tk + e] : 0.0f;
+            }
+        } else
+        if (vecB && k0 + bk < a.K && m0 + bm + 8 <= a.M) {
+            const float4* wp = reinterpret_cast<const float4*>(a.W + (int64_t)(k0 + bk) * a.wk + m0 + bm);
+            const float4 q0 = wp[0], q1 = wp[1];
+            bv[0] = q0.x; bv[1] = q0.y; bv[2] = q0.z; bv[3] = q0.w; bv[4] = q1.x; bv[5] = q1.y; bv[6] = q1.z; bv[7] = q1.w;
+        } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (k0 + bk < a.K && m0 + bm + e < a.M) ? a.W[(int64_t)(k0 + bk) * a.wk + (int64_t)(m0 + bm + e) * a.wm] : 0.0f;
+        }
+    };
+    // the global loads of chunk k + 1 are in flight while chunk k is multiplied (registers av / bv)
+    load_chunk(0);
+    for (int k0 = 0; k0 < a.K; k0 += SG_K) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[ak + e][ar + 64 * h] = av[h][e];
+        if (vecBT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Bs[tk + e][tm] = bv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Bs[bk][bm + e] = bv[e];
         }
         __syncthreads();
+        if (k0 + SG_K < a.K) load_chunk(k0 + SG_K);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { As[ak + e][ar] = av[e]; Bs[bk][bm + e] = bv[e]; }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < SG_K; ++kk) {
-            float x[4], w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = As[kk][tr * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = Bs[kk][tc * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(x[i], w[j], acc[i][j]);
+        for (int kk = 0; kk < SG_K; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            const float a0 = As[kr][wr * 64 + (lane & 31)], a1 = As[kr][wr * 64 + 32 + (lane & 31)];
+            const float b0 = Bs[kr][wc * 64 + (lane & 31)], b1 = Bs[kr][wc * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int t = t0 + tr * 4 + i;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + wr * 64 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
         if (t >= a.T) continue;
         const int64_t row = rowbase + t;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + tc * 4 + j;
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wc * 64 + j * 32 + (lane & 31);
             if (m >= a.M) continue;
             float* o = a.out_bot ? a.Out + ((int64_t)b * a.M + m) * a.T + t : a.Out + row * a.ld_out + m;
-            float v = a.alpha * acc[i][j];
+            float v = a.alpha * acc[i][j][r];
             if (a.thresh16 && a.drop_on_out) {
                 const uint32_t el = (uint32_t)(row * a.drop_ld + m);
                 const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, el >> 1);
@@ -257,7 +310,8 @@ int wn_f32_forward(wn_ctx* c, hipStream_t st) {
 // [slab][K][M]; wn_f32_wgrad_reduce sums the slabs in order into the TF-layout gradient tensor.  a_ones: A = 1 (K = 1: column sums = bias
 // gradients).  Dropout keys: the A operand is the dropout-applied layer input (modules.py:484).
 struct WgradF32Args {
-    const float* A; int32_t lda, shift, a_ones;
+    const float* A; int32_t lda, shift, a_ones;          // a_ones: A = 1 (K = 1);  ones_row: one extra A column of ones at k = K - 1 (the bias gradient falls out as the last row)
+    int32_t ones_row;
     const float* Bm; int32_t ldb;
     int32_t K, M;
     float* part;
@@ -267,29 +321,49 @@ struct WgradF32Args {
 __global__ __launch_bounds__(256) void wn_f32_wgrad_kernel(const WgradF32Args a) {
     __shared__ float As[SG_K][SG_T + 4];       // [row in chunk][k]
     __shared__ float Bs[SG_K][SG_T + 4];       // [row in chunk][m]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;       // this wave's 64 x 64 piece of the 128 (k) x 128 (m) tile
     const int k0 = blockIdx.x * SG_T, m0 = blockIdx.y * SG_T;
     const int b = blockIdx.z / a.slabs_per_utt, sl = blockIdx.z - b * a.slabs_per_utt;
     const int t_lo = sl * a.slab, t_hi = min(a.T, t_lo + a.slab);
     const int64_t rowbase = (int64_t)b * a.T;
-    const int tr = tid >> 4, tc = tid & 15;        // micro tile: k = tr*4.., m = tc*4..
-    const int lr = tid >> 4, lc = (tid & 15) * 4;  // staging: row lr of the chunk, 4 consecutive columns
-    float acc[4][4];
+    const int lr = tid >> 4, lc = (tid & 15) * 8;  // staging: row lr of the chunk, 8 consecutive columns
+    f32x16_t acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
-    for (int tc0 = t_lo; tc0 < t_hi; tc0 += SG_K) {
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float av[8], bv[8];
+    const bool vecA = !a.a_ones && (a.lda % 4 == 0) && (a.drop_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+    const bool vecB = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.Bm) & 15) == 0);
+    auto load_chunk = [&](const int tc0) {
         const int t = tc0 + lr;
-        float av[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { av[e] = 0.0f; bv[e] = 0.0f; }
         if (t < t_hi) {
             const int ts = t + a.shift;
             if (a.a_ones) { if (lc == 0) av[0] = 1.0f; }
             else if (ts >= 0 && ts < a.T) {
+                if (vecA && k0 + lc + 8 <= a.K - a.ones_row) {
+                    const float4* ap = reinterpret_cast<const float4*>(a.A + (rowbase + ts) * a.lda + k0 + lc);
+                    const float4 q0 = ap[0], q1 = ap[1];
+                    av[0] = q0.x; av[1] = q0.y; av[2] = q0.z; av[3] = q0.w; av[4] = q1.x; av[5] = q1.y; av[6] = q1.z; av[7] = q1.w;
+                    if (a.thresh16) {      // one dropout word per element pair
+                        const uint32_t el = (uint32_t)((rowbase + ts) * a.drop_ld + k0 + lc);          // multiple of 8
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t w = wn_drop_word(a.key_lo, a.key_hi, (el >> 1) + q);
+                            av[2 * q] = (w & 0xffffu) >= a.thresh16 ? av[2 * q] * a.keep_scale : 0.0f;
+                            av[2 * q + 1] = (w >> 16) >= a.thresh16 ? av[2 * q + 1] * a.keep_scale : 0.0f;
+                        }
+                    }
+                } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
                     const int k = k0 + lc + e;
-                    if (k < a.K) {
+                    if (k < a.K - a.ones_row) {
                         float v = a.A[(rowbase + ts) * a.lda + k];
                         if (a.thresh16) {
                             const uint32_t el = (uint32_t)((rowbase + ts) * a.drop_ld + k);
@@ -300,44 +374,62 @@ __global__ __launch_bounds__(256) void wn_f32_wgrad_kernel(const WgradF32Args a)
                         av[e] = v;
                     }
                 }
+                }
             }
+            if (a.ones_row && a.K - 1 >= k0 + lc && a.K - 1 < k0 + lc + 8) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (m0 + lc + e < a.M) bv[e] = a.Bm[(rowbase + t) * a.ldb + m0 + lc + e];
+                for (int e = 0; e < 8; ++e) if (k0 + lc + e == a.K - 1) av[e] = 1.0f;
+            }
+            if (vecB && m0 + lc + 8 <= a.M) {
+                const float4* bp = reinterpret_cast<const float4*>(a.Bm + (rowbase + t) * a.ldb + m0 + lc);
+                const float4 q0 = bp[0], q1 = bp[1];
+                bv[0] = q0.x; bv[1] = q0.y; bv[2] = q0.z; bv[3] = q0.w; bv[4] = q1.x; bv[5] = q1.y; bv[6] = q1.z; bv[7] = q1.w;
+            } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (m0 + lc + e < a.M) bv[e] = a.Bm[(rowbase + t) * a.ldb + m0 + lc + e];
+            }
         }
+    };
+    load_chunk(t_lo);
+    for (int tc0 = t_lo; tc0 < t_hi; tc0 += SG_K) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { As[lr][lc + e] = av[e]; Bs[lr][lc + e] = bv[e]; }
+        for (int e = 0; e < 8; ++e) { As[lr][lc + e] = av[e]; Bs[lr][lc + e] = bv[e]; }
         __syncthreads();
+        if (tc0 + SG_K < t_hi) load_chunk(tc0 + SG_K);      // in flight while this chunk is multiplied
 #pragma unroll
-        for (int r = 0; r < SG_K; ++r) {
-            float x[4], w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = As[r][tr * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = Bs[r][tc * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(x[i], w[j], acc[i][j]);
+        for (int rr = 0; rr < SG_K; rr += 2) {      // D[k][m] += sum_r A[r][k] B[r][m]: the MFMA's A operand is A^T (lane l: k = l % 32, row = l / 32)
+            const int r = rr + (lane >> 5);
+            const float a0 = As[r][wr * 64 + (lane & 31)], a1 = As[r][wr * 64 + 32 + (lane & 31)];
+            const float b0 = Bs[r][wc * 64 + (lane & 31)], b1 = Bs[r][wc * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
     float* P = a.part + (int64_t)blockIdx.z * a.K * a.M;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = k0 + tr * 4 + i;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = k0 + wr * 64 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
         if (k >= a.K) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int m = m0 + tc * 4 + j; if (m < a.M) P[(int64_t)k * a.M + m] = acc[i][j]; }
+        for (int j = 0; j < 2; ++j) { const int m = m0 + wc * 64 + j * 32 + (lane & 31); if (m < a.M) P[(int64_t)k * a.M + m] = acc[i][j][r]; }
     }
 }
-__global__ void wn_f32_wgrad_reduce(const float* __restrict__ part, int nslab, int K, int M, float* __restrict__ out, int ldo, float alpha, float* __restrict__ out2) {
+__global__ void wn_f32_wgrad_reduce(const float* __restrict__ part, int nslab, int K, int M, float* __restrict__ out, int ldo, float alpha,
+                                    int ones_row, float* __restrict__ bias_out, float* __restrict__ bias_out2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)K * M) return;
     float s = 0.0f;
     for (int z = 0; z < nslab; ++z) s += part[(int64_t)z * K * M + i];
     const int k = (int)(i / M), m = (int)(i - (int64_t)k * M);
-    out[(int64_t)k * ldo + m] = alpha * s;
-    if (out2) out2[(int64_t)k * ldo + m] = alpha * s;
+    if (ones_row && k == K - 1) {
+        if (bias_out) bias_out[m] = alpha * s;
+        if (bias_out2) bias_out2[m] = alpha * s;
+    } else out[(int64_t)k * ldo + m] = alpha * s;
 }
 // d z from d u and the saved pre-activations (modules.py:510 differentiated): da = g s (1 - t^2), db = g t s (1 - s)
 __global__ void wn_f32_gate_bwd(const float* __restrict__ GU, const float* __restrict__ Z, float* __restrict__ DZ, int64_t rows, int GH) {
@@ -396,25 +488,31 @@ static int f32_reserve_bwd(wn_ctx* c) {
     WN_HIP(c, hipMalloc((void**)&s->DCT, (size_t)NT * c->C * 4));
     const int maxk = std::max(std::max(c->R, c->GH), std::max(c->S, c->C)), maxm = std::max(std::max(c->G, c->S), std::max(c->R, c->O));
     const int slabs = c->maxB * cdiv(c->maxT, 2048);
-    s->part_floats = (size_t)slabs * maxk * maxm;
+    s->part_floats = (size_t)slabs * (maxk + 1) * maxm;      // + the bias row
     WN_HIP(c, hipMalloc((void**)&s->PART, s->part_floats * 4));
     return WN_OK;
 }
-// dW (TF layout, row pitch ldo) = alpha * A^T Bm over all rows; optional second target (the twin bias of the gate pre-activation)
+// dW (TF layout, row pitch ldo) = alpha * A^T Bm over all rows; bias_out (optional): alpha * column sums of Bm from one extra A column of
+// ones in the same launch (bias_out2: the twin bias of the gate pre-activation).  A == nullptr: only the column sums.
 static int wgrad32(wn_ctx* c, const float* A, int lda, int shift, int K, const float* Bm, int ldb, int M, float* out, int ldo, float alpha,
-                   int drop_layer, float* out2, hipStream_t st) {
+                   int drop_layer, float* bias_out, float* bias_out2, hipStream_t st) {
     F32State* s = (F32State*)c->f32;
     WgradF32Args a; memset(&a, 0, sizeof a);
-    a.A = A; a.lda = lda; a.shift = shift; a.a_ones = A == nullptr; a.Bm = Bm; a.ldb = ldb; a.K = K; a.M = M; a.part = s->PART;
+    a.A = A; a.lda = lda; a.shift = shift; a.a_ones = A == nullptr; a.Bm = Bm; a.ldb = ldb; a.M = M; a.part = s->PART;
+    a.ones_row = (A != nullptr && (bias_out || bias_out2)) ? 1 : 0;
+    a.K = (A ? K : 1) + a.ones_row;
     a.B = c->fB; a.T = c->fT; a.slab = 2048; a.slabs_per_utt = cdiv(a.T, a.slab);
     if (drop_layer >= 0 && c->cfg.dropout > 0.0f) {
         wn_layer_key(c->fseed, drop_layer, &a.key_lo, &a.key_hi); a.thresh16 = (uint32_t)lrintf(c->cfg.dropout * 65536.0f);
         a.keep_scale = 1.0f / (1.0f - c->cfg.dropout); a.drop_ld = lda;
     }
     const int nslab = a.B * a.slabs_per_utt;
-    if ((size_t)nslab * K * M > s->part_floats) WN_FAIL(c, WN_E_STATE, "fp32 weight-gradient partial buffer too small");
-    hipLaunchKernelGGL(wn_f32_wgrad_kernel, dim3(cdiv(K, SG_T), cdiv(M, SG_T), nslab), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(wn_f32_wgrad_reduce, dim3(cdiv((int64_t)K * M, 256)), dim3(256), 0, st, s->PART, nslab, K, M, out, ldo, alpha, out2);
+    if ((size_t)nslab * a.K * M > s->part_floats) WN_FAIL(c, WN_E_STATE, "fp32 weight-gradient partial buffer too small");
+    hipLaunchKernelGGL(wn_f32_wgrad_kernel, dim3(cdiv(a.K, SG_T), cdiv(M, SG_T), nslab), dim3(256), 0, st, a);
+    if (a.a_ones)      // column sums only: the single row goes to the bias target(s)
+        hipLaunchKernelGGL(wn_f32_wgrad_reduce, dim3(cdiv((int64_t)M, 256)), dim3(256), 0, st, s->PART, nslab, 1, M, (float*)nullptr, 0, alpha, 1, bias_out, bias_out2);
+    else
+        hipLaunchKernelGGL(wn_f32_wgrad_reduce, dim3(cdiv((int64_t)a.K * M, 256)), dim3(256), 0, st, s->PART, nslab, a.K, M, out, ldo, alpha, a.ones_row, bias_out, bias_out2);
     WN_LAUNCH_CHECK(c);
     return WN_OK;
 }
@@ -432,14 +530,12 @@ int wn_f32_backward(wn_ctx* c, float* grads, hipStream_t st) {
     const int64_t NT = c->NT, rows = (int64_t)B * T;
     const float* P = c->params_dev;
     // ---- head (wavenet.py:716-721 backwards)
-    if ((rc = wgrad32(c, s->H1, S, 0, S, s->DY, ldDY, O, grads + c->fin2_k, O, 1.0f, -1, nullptr, st))) return rc;
-    if ((rc = wgrad32(c, nullptr, 0, 0, 1, s->DY, ldDY, O, grads + c->fin2_b, O, 1.0f, -1, nullptr, st))) return rc;
+    if ((rc = wgrad32(c, s->H1, S, 0, S, s->DY, ldDY, O, grads + c->fin2_k, O, 1.0f, -1, grads + c->fin2_b, nullptr, st))) return rc;
     {   // d pre1 = (dY W2^T) * (h1 > 0)
         SgemmArgs a = mk(s->DY, ldDY, 0, P + c->fin2_k, O, O, S, s->DH1, S); a.wk = 1; a.wm = O; a.mask = s->H1; a.ld_mask = S;
         if ((rc = sgemm(c, a, st))) return rc;
     }
-    if ((rc = wgrad32(c, s->SK, S, 0, S, s->DH1, S, S, grads + c->fin1_k, S, 1.0f, -1, nullptr, st))) return rc;
-    if ((rc = wgrad32(c, nullptr, 0, 0, 1, s->DH1, S, S, grads + c->fin1_b, S, 1.0f, -1, nullptr, st))) return rc;
+    if ((rc = wgrad32(c, s->SK, S, 0, S, s->DH1, S, S, grads + c->fin1_k, S, 1.0f, -1, grads + c->fin1_b, nullptr, st))) return rc;
     {   // d skips = (d pre1 W1^T) * (relu(skips) > 0)
         SgemmArgs a = mk(s->DH1, S, 0, P + c->fin1_k, S, S, S, s->DSK, S); a.wk = 1; a.wm = S; a.mask = s->SK; a.ld_mask = S;
         if ((rc = sgemm(c, a, st))) return rc;
@@ -461,17 +557,12 @@ int wn_f32_backward(wn_ctx* c, float* grads, hipStream_t st) {
             }
         }
         hipLaunchKernelGGL(wn_f32_gate_bwd, dim3(cdiv(rows * GH, 256)), dim3(256), 0, st, s->GU, Zl, s->DZ, rows, GH);
-        // ---- weight gradients of this layer
-        if ((rc = wgrad32(c, Ul, GH, 0, GH, s->DSK, S, S, grads + c->lay[l].skip_k, S, c->skip_scale[l], -1, nullptr, st))) return rc;
-        if (c->lbias && (rc = wgrad32(c, nullptr, 0, 0, 1, s->DSK, S, S, grads + c->lay[l].skip_b, S, c->skip_scale[l], -1, nullptr, st))) return rc;
-        if (!top) {
-            if ((rc = wgrad32(c, Ul, GH, 0, GH, gx_up, R, R, grads + c->lay[l].out_k, R, 1.0f, -1, nullptr, st))) return rc;
-            if (c->lbias && (rc = wgrad32(c, nullptr, 0, 0, 1, gx_up, R, R, grads + c->lay[l].out_b, R, 1.0f, -1, nullptr, st))) return rc;
-        }
+        // ---- weight gradients of this layer (bias gradients ride along as a ones column of the A operand)
+        if ((rc = wgrad32(c, Ul, GH, 0, GH, s->DSK, S, S, grads + c->lay[l].skip_k, S, c->skip_scale[l], -1, c->lbias ? grads + c->lay[l].skip_b : nullptr, nullptr, st))) return rc;
+        if (!top && (rc = wgrad32(c, Ul, GH, 0, GH, gx_up, R, R, grads + c->lay[l].out_k, R, 1.0f, -1, c->lbias ? grads + c->lay[l].out_b : nullptr, nullptr, st))) return rc;
         for (int tap = 0; tap < 3; ++tap)
-            if ((rc = wgrad32(c, Xl, R, -(2 - tap) * d, R, s->DZ, G, G, grads + c->lay[l].dil_k + (int64_t)tap * R * G, G, 1.0f, l, nullptr, st))) return rc;
-        if ((rc = wgrad32(c, s->C32, C, 0, C, s->DZ, G, G, grads + c->lay[l].cin_k, G, 1.0f, -1, nullptr, st))) return rc;
-        if (c->lbias && (rc = wgrad32(c, nullptr, 0, 0, 1, s->DZ, G, G, grads + c->lay[l].dil_b, G, 1.0f, -1, grads + c->lay[l].cin_b, st))) return rc;
+            if ((rc = wgrad32(c, Xl, R, -(2 - tap) * d, R, s->DZ, G, G, grads + c->lay[l].dil_k + (int64_t)tap * R * G, G, 1.0f, l, nullptr, nullptr, st))) return rc;
+        if ((rc = wgrad32(c, s->C32, C, 0, C, s->DZ, G, G, grads + c->lay[l].cin_k, G, 1.0f, -1, c->lbias ? grads + c->lay[l].dil_b : nullptr, c->lbias ? grads + c->lay[l].cin_b : nullptr, st))) return rc;
         if (c->gin > 0) hipLaunchKernelGGL(wn_f32_colsum_utt, dim3(cdiv(G, 64), B), dim3(256), 0, st, s->DZ, c->colsum + (size_t)l * B * G, T, G);
         {   // d c_up += d z W_cin^T   (modules.py:497-501 backwards)
             SgemmArgs a = mk(s->DZ, G, 0, P + c->lay[l].cin_k, G, G, C, s->DC, C); a.wk = 1; a.wm = G; a.accumulate = 1;
@@ -495,8 +586,8 @@ int wn_f32_backward(wn_ctx* c, float* grads, hipStream_t st) {
     const float* g0 = s->GX[0];
     if (c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE)
         hipLaunchKernelGGL(wn_f32_first_conv_bwd_ids, dim3(cdiv(rows * R, 256)), dim3(256), 0, st, (const int32_t*)c->fx, g0, grads + c->first.dil_k, rows, R);
-    else if ((rc = wgrad32(c, (const float*)c->fx, 1, 0, 1, g0, R, R, grads + c->first.dil_k, R, 1.0f, -1, nullptr, st))) return rc;
-    if ((rc = wgrad32(c, nullptr, 0, 0, 1, g0, R, R, grads + c->first.dil_b, R, 1.0f, -1, nullptr, st))) return rc;
+    else if ((rc = wgrad32(c, (const float*)c->fx, 1, 0, 1, g0, R, R, grads + c->first.dil_k, R, 1.0f, -1, grads + c->first.dil_b, nullptr, st))) return rc;
+    if (c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE && (rc = wgrad32(c, nullptr, 0, 0, 1, g0, R, R, nullptr, 0, 1.0f, -1, grads + c->first.dil_b, nullptr, st))) return rc;
     if ((rc = wn_gin_bwd(c, grads, st, true))) return rc;      // d W_g, d b_g, d embedding table from the per-utterance sums above
     // ---- upsample net (modules.py:524-770 backwards: the fp32 kernels the bf16 engine uses too)
     if (c->cfg.upsample_type != WN_UP_NEAREST) {
