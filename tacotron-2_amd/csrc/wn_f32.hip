@@ -216,21 +216,21 @@ void wn_f32_free(wn_ctx* c) {
     delete s; c->f32 = nullptr;
 }
 static int f32_reserve(wn_ctx* c) {
-    if (c->f32) return WN_OK;
-    F32State* s = new F32State(); c->f32 = s;
+    if (!c->f32) c->f32 = new F32State();
+    F32State* s = (F32State*)c->f32;
     const int64_t NT = c->NT;
-    WN_HIP(c, hipMalloc((void**)&s->X, (size_t)c->L * NT * c->R * 4));
-    WN_HIP(c, hipMalloc((void**)&s->U, (size_t)c->L * NT * c->GH * 4));
-    WN_HIP(c, hipMalloc((void**)&s->Z, (size_t)c->L * NT * c->G * 4));      // every layer's pre-activations: the gate derivative of the backward
-    WN_HIP(c, hipMalloc((void**)&s->SK, (size_t)NT * c->S * 4));
-    WN_HIP(c, hipMalloc((void**)&s->H1, (size_t)NT * c->S * 4));
-    WN_HIP(c, hipMalloc((void**)&s->C32, (size_t)NT * c->C * 4));
+    // (each buffer on its own: after a failed allocation the next call retries the missing ones only)
+    auto need = [&](float** p, size_t floats) -> int { if (!*p) WN_HIP(c, hipMalloc((void**)p, floats * 4)); return WN_OK; };
+    int rc;
+    if ((rc = need(&s->X, (size_t)c->L * NT * c->R)) || (rc = need(&s->U, (size_t)c->L * NT * c->GH)) ||
+        (rc = need(&s->Z, (size_t)c->L * NT * c->G)) ||      // every layer's pre-activations: the gate derivative of the backward
+        (rc = need(&s->SK, (size_t)NT * c->S)) || (rc = need(&s->H1, (size_t)NT * c->S)) || (rc = need(&s->C32, (size_t)NT * c->C))) return rc;
     s->bytes = (size_t)NT * 4 * ((size_t)c->L * (c->R + c->GH + c->G) + 2 * c->S + c->C);
     return WN_OK;
 }
 const float* wn_f32_debug(const wn_ctx* c, const char* name, int layer) {
     const F32State* s = (const F32State*)c->f32;
-    if (!s) return nullptr;
+    if (!s || !s->X || !s->U) return nullptr;
     if (!strcmp(name, "X")) return s->X + (size_t)layer * c->NT * c->R;
     if (!strcmp(name, "U")) return s->U + (size_t)layer * c->NT * c->GH;
     return nullptr;
@@ -477,19 +477,20 @@ float* wn_f32_dy(wn_ctx* c) {
 }
 static int f32_reserve_bwd(wn_ctx* c) {
     F32State* s = (F32State*)c->f32;
-    if (s->DZ) return WN_OK;
     const int64_t NT = c->NT;
-    WN_HIP(c, hipMalloc((void**)&s->DH1, (size_t)NT * c->S * 4));
-    WN_HIP(c, hipMalloc((void**)&s->DSK, (size_t)NT * c->S * 4));
-    WN_HIP(c, hipMalloc((void**)&s->GU, (size_t)NT * c->GH * 4));
-    WN_HIP(c, hipMalloc((void**)&s->DZ, (size_t)NT * c->G * 4));
-    for (int k = 0; k < 2; ++k) WN_HIP(c, hipMalloc((void**)&s->GX[k], (size_t)NT * c->R * 4));
-    WN_HIP(c, hipMalloc((void**)&s->DC, (size_t)NT * c->C * 4));
-    WN_HIP(c, hipMalloc((void**)&s->DCT, (size_t)NT * c->C * 4));
-    const int maxk = std::max(std::max(c->R, c->GH), std::max(c->S, c->C)), maxm = std::max(std::max(c->G, c->S), std::max(c->R, c->O));
-    const int slabs = c->maxB * cdiv(c->maxT, 2048);
-    s->part_floats = (size_t)slabs * (maxk + 1) * maxm;      // + the bias row
-    WN_HIP(c, hipMalloc((void**)&s->PART, s->part_floats * 4));
+    // each buffer on its own: a failed allocation leaves the others to be reused (or freed by wn_f32_free), never leaked by a retry
+    auto need = [&](float** p, size_t floats) -> int { if (!*p) WN_HIP(c, hipMalloc((void**)p, floats * 4)); return WN_OK; };
+    int rc;
+    if ((rc = need(&s->DH1, (size_t)NT * c->S)) || (rc = need(&s->DSK, (size_t)NT * c->S)) || (rc = need(&s->GU, (size_t)NT * c->GH)) ||
+        (rc = need(&s->DZ, (size_t)NT * c->G)) || (rc = need(&s->GX[0], (size_t)NT * c->R)) || (rc = need(&s->GX[1], (size_t)NT * c->R)) ||
+        (rc = need(&s->DC, (size_t)NT * c->C)) || (rc = need(&s->DCT, (size_t)NT * c->C))) return rc;
+    if (!s->PART) {
+        const int maxk = std::max(std::max(c->R, c->GH), std::max(c->S, c->C)), maxm = std::max(std::max(c->G, c->S), std::max(c->R, c->O));
+        const int slabs = c->maxB * cdiv(c->maxT, 2048);
+        const size_t floats = (size_t)slabs * (maxk + 1) * maxm;      // + the bias row
+        if ((rc = need(&s->PART, floats))) return rc;
+        s->part_floats = floats;
+    }
     return WN_OK;
 }
 // dW (TF layout, row pitch ldo) = alpha * A^T Bm over all rows; bias_out (optional): alpha * column sums of Bm from one extra A column of
