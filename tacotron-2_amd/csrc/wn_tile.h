@@ -1425,8 +1425,11 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.ntiles = a.tiles_per_utt * a.B;
             a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * 8;
-            static const int bk64 = [] { const char* e = getenv("WN_DC_BK64"); return e ? atoi(e) : 0; }();      // A/B switch: K-chunks of 64, 2-deep ring (half the ring steps)
-            bool k64 = bk64 != 0; for (int sgi = 0; sgi < a.nseg; ++sgi) k64 = k64 && a.seg[sgi].nk % 64 == 0;
+            // K-chunks of 64 with a 2-deep ring (half the ring steps) for narrow gate widths: -1 .. -2.4 % on the step of hparams.py's
+            // defaults (G = 256), neutral at G = 512 (gpurun_out r4u A/B; WN_DC_BK64 = 0 / 1 forces either)
+            static const int bk64 = [] { const char* e = getenv("WN_DC_BK64"); return e ? atoi(e) : -1; }();
+            bool k64 = bk64 < 0 ? a.seg[0].nk <= 256 : bk64 != 0;
+            for (int sgi = 0; sgi < a.nseg; ++sgi) k64 = k64 && a.seg[sgi].nk % 64 == 0;
             if (k64) hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 3, 3, 2, 64, 2, EPI, 1>), dim3(grid), dim3(384), 0, st, a);
             else
             hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 3, 3, 2, 32, 3, EPI, 1>), dim3(grid), dim3(384), 0, st, a);
