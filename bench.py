@@ -139,7 +139,7 @@ def cpu_baseline(hp, seconds_budget=20.0):
         if time.time() - t0 > seconds_budget or n >= 50:
             break
     dt = time.time() - t0
-    return {'value': B * T * n / dt, 'unit': 'audio_samples/s', 'cores': cores, 'kind': 'port',
+    return {'value': B * T * n / dt, 'unit': 'audio_samples/s', 'cores': cores, 'host_cores_total': os.cpu_count(), 'kind': 'port',
             'sample': 'oracle train step (fwd+loss+autograd bwd+clip+TF-Adam+EMA), same architecture, batch %dx%d samples, %d steps in %.1f s, torch-CPU fp32 %d threads'
                       % (B, T, n, dt, cores)}
 
@@ -157,7 +157,7 @@ def cpu_synth_baseline(hp, steps=2200, seconds_budget=15.0):
     g = torch.Generator().manual_seed(0)
     Tc = max(2, -(-steps // cfg.hop))
     c = torch.rand(1, cfg.cin_channels, Tc, generator=g)
-    out = {'unit': 'audio_samples/s', 'cores': cores, 'kind': 'port', 'sample_rate': hp.sample_rate}
+    out = {'unit': 'audio_samples/s', 'cores': cores, 'host_cores_total': os.cpu_count(), 'kind': 'port', 'sample_rate': hp.sample_rate}
     with torch.no_grad():
         for form in ('reference', 'ring'):
             # time in slices so that a slow host stops at the budget instead of running all the steps
@@ -197,32 +197,49 @@ def other_workload_subprocess(key, device_index=0, hard_timeout=240):
         return {'error': 'timed out after %d s' % hard_timeout}
 
 
-def cpu_full_batch_reference(workload, B, T):
-    """The oracle on the WHOLE bench batch (not the bounded sample above): the GPU parity test of this geometry runs the oracle's forward +
-    autograd backward on the same 8 x 11 000 batch on the GPU box's host cores and records its wall time; the newest committed record
-    (profiles/*parity_c2_b8.json) is quoted here so that the bounded-sample figure has the full-size one beside it.  Nothing is run."""
-    import glob
-    if workload != 'c2':
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*parity_c2_b8.json')))      # r2e < r2x < r3f < r4a ...: the newest session sorts last
-    for path in reversed(files):
-        try:
-            d = json.load(open(path))
-            if (int(d['B']), int(d['T'])) == (B, T) and d.get('oracle_seconds'):
-                return {'value': B * T / float(d['oracle_seconds']), 'unit': 'audio_samples/s', 'oracle_seconds': float(d['oracle_seconds']),
-                        'what': 'oracle forward + autograd backward (no optimiser) of the full %d x %d batch, utterance by utterance, all host cores of the GPU box' % (B, T),
-                        'source': os.path.relpath(path, ROOT)}
-        except (OSError, ValueError, KeyError):
-            continue
-    return None
+def cpu_full_batch(hp, B=None, T=None):
+    """The oracle on the WHOLE bench batch (not the bounded sample of cpu_baseline): forward + loss + autograd backward utterance by
+    utterance (the masked-mean loss of the batch is the length-weighted mean of the per-utterance losses, so the gradients add up),
+    then ONE clip + TF-Adam + EMA update -- the full training step on all host cores.  Run only on request (--cpu-full-batch): about a
+    minute on the GPU box's 256 cores, far more on a small host."""
+    from collections import OrderedDict
+    from oracle import wavenet_oracle as O
+    B, T = B or 8, T or 11000
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig.from_hparams(hp)
+    T = T // cfg.hop * cfg.hop
+    params = O.init_params(cfg, seed=5339)
+    state = O.init_opt_state(params)
+    g = torch.Generator().manual_seed(0)
+    wav = torch.rand(B, T, generator=g) * 1.6 - 0.8
+    c = torch.rand(B, cfg.cin_channels, T // cfg.hop, generator=g)
+    t0 = time.time()
+    total = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+    for b in range(B):
+        masks = [(torch.rand(1, cfg.residual_channels, T, generator=g) >= cfg.wavenet_dropout).float() for _ in range(cfg.layers)]
+        leaf = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in params.items())
+        y_hat = O.step(leaf, cfg, wav[b:b + 1].view(1, 1, T), c[b:b + 1], dropout_masks=masks)
+        loss = O.training_loss(cfg, y_hat, wav[b:b + 1].view(1, T, 1), [T])
+        gr = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
+        for k, gk in zip(leaf, gr):
+            if gk is not None:
+                total[k] += gk / B
+    lr = O.learning_rate(0)
+    for k, pk in params.items():
+        m, v, e = state[k]
+        O.adam_ema_update(pk, O.clip_gradient(total[k]), m, v, e, 1, lr)
+    dt = time.time() - t0
+    return {'value': B * T / dt, 'unit': 'audio_samples/s', 'cores': cores, 'host_cores_total': os.cpu_count(), 'kind': 'port', 'wall_s': dt,
+            'sample': 'oracle training step (fwd + loss + autograd bwd per utterance, one clip + TF-Adam + EMA) on the FULL %d x %d batch, torch-CPU fp32 %d threads, run here' % (B, T, cores)}
 
 
 def cpu_baseline_subprocess(workload, hard_timeout=150, fn='cpu_baseline'):
     """Run the CPU leg in a child process so that a pathological host (thread oversubscription) can never
     take the GPU number down with it."""
     import subprocess
-    code = ('import sys, json; sys.path.insert(0, %r); import bench; hp, _, _ = bench.build_hparams(%r); '
-            'print("CPUBASE" + json.dumps(bench.%s(hp)))' % (ROOT, workload, fn))
+    code = ('import sys, json; sys.path.insert(0, %r); import bench; hp, B, T = bench.build_hparams(%r); '
+            'print("CPUBASE" + json.dumps(bench.%s(hp%s)))' % (ROOT, workload, fn, ', B, T' if fn == 'cpu_full_batch' else ''))
     try:
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=hard_timeout)
         for line in r.stdout.splitlines():
@@ -311,19 +328,80 @@ def measure_other_workload(key, device, steps=10, warmup=3):
     R, G, C = hp.residual_channels, hp.gate_channels, hp.cin_channels
     value = B * T / dt
     gate_tf = (2.0 * G * (3 * R + C) * rows / (k_ms / k_n * 1e-3) / 1e12) if k_n else None
+    f32 = getattr(hp, 'mi355_compute_dtype', 'bf16') == 'fp32'
+    peak_tf = 157.3 if f32 else 2500.0
+    e_act = 4 if f32 else 2
     out = {'workload_key': key, 'dtype': 'f32' if getattr(hp, 'mi355_compute_dtype', 'bf16') == 'fp32' else 'bf16', 'steps': steps, 'warmup': warmup, 'batch': B, 'time': T, 'layers': hp.layers, 'stacks': hp.stacks,
            'R': R, 'G': G, 'S': hp.skip_out_channels, 'out_channels': hp.out_channels, 'params': int(eng.n_params),
            'ms_per_step': dt * 1e3, 'value': value, 'unit': 'audio_samples/s', 'final_loss': float(loss.item()),
            'train_tflops_algorithmic': 6.0 * mac_per_sample(hp) * value / 1e12,
-           'mfma_whole_step_frac': 6.0 * mac_per_sample(hp) * value / 1e12 / 2500.0,
-           'hbm_whole_step_frac': alg_bytes_per_sample(hp) * value / 8e12, 'alg_bytes_per_sample': alg_bytes_per_sample(hp),
-           'gate_kernel': {'achieved_TFLOPs': gate_tf, 'frac_of_2500': (gate_tf / 2500.0) if gate_tf else None, 'launches_timed': int(k_n),
+           # the matrix-pipe peak of the dtype the workload computes in: 2500 TFLOP/s dense bf16; 157.3 TFLOP/s fp32 (v_mfma_f32_32x32x2_f32)
+           'mfma_peak_TFLOPs': peak_tf,
+           'mfma_whole_step_frac': 6.0 * mac_per_sample(hp) * value / 1e12 / peak_tf,
+           'hbm_whole_step_frac': alg_bytes_per_sample(hp, e_act) * value / 8e12, 'alg_bytes_per_sample': alg_bytes_per_sample(hp, e_act),
+           'gate_kernel': {'achieved_TFLOPs': gate_tf, 'frac_of_peak': (gate_tf / peak_tf) if gate_tf else None, 'launches_timed': int(k_n),
                            'rows_per_launch': rows, 'timing': 'in-kernel stamps (pure kernel time), live in the two-stream step'},
-           'bound': 'hbm' if alg_bytes_per_sample(hp) * 2500e12 > 6.0 * mac_per_sample(hp) * 8e12 else 'mfma'}
+           'bound': 'hbm' if alg_bytes_per_sample(hp, e_act) * peak_tf * 1e12 > 6.0 * mac_per_sample(hp) * 8e12 else 'mfma'}
     eng.close()
     del flat, grads, m, v, ema
     torch.cuda.empty_cache()
     return out
+
+
+def measure_with_feeder(hp, B, T, device, one_step, steps=30, n_utt=40):
+    """K steps of the same step function with every batch coming from wavenet_vocoder.feeder.Feeder over a synthetic LJSpeech-shaped
+    dataset written to a temp dir (utterances of 3-8 s, float32 audio + [-4, 4] mels): disk -> producer thread -> pinned -> H2D."""
+    import shutil
+    import tempfile
+    from wavenet_vocoder.feeder import Feeder
+    hop = int(np.prod(hp.upsample_scales))
+    tmp = tempfile.mkdtemp(prefix='wn_bench_feeder_')
+    try:
+        rng = np.random.RandomState(5339)
+        os.makedirs(os.path.join(tmp, 'audio')); os.makedirs(os.path.join(tmp, 'mels'))
+        lines = []
+        for i in range(n_utt):
+            frames = int(rng.randint(3 * hp.sample_rate // hop, 8 * hp.sample_rate // hop))
+            t = np.arange(frames * hop, dtype=np.float32)
+            wav = np.clip(0.3 * np.sin(2 * np.pi * rng.uniform(80, 400) * t / hp.sample_rate) + 0.1 * rng.randn(frames * hop), -0.999, 0.999).astype(np.float32)
+            mel = rng.uniform(-hp.max_abs_value, hp.max_abs_value, size=(frames, hp.num_mels)).astype(np.float32)
+            a, m = os.path.join(tmp, 'audio', 'audio-%03d.npy' % i), os.path.join(tmp, 'mels', 'mel-%03d.npy' % i)
+            np.save(a, wav); np.save(m, mel)
+            lines.append('|'.join([a, m, m, '<no_g>', 'synthetic %d' % i]))
+        meta = os.path.join(tmp, 'map.txt')
+        with open(meta, 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+        import copy
+        fhp = copy.deepcopy(hp)
+        fhp.parse('wavenet_batch_size=%d,max_time_steps=%d,wavenet_test_batches=1' % (B, T))
+
+        class _Coord(object):
+            stop = False
+
+            def should_stop(self):
+                return self.stop
+        coord = _Coord()
+        fd = Feeder(coord, meta, tmp, fhp, device=device)
+        fd.start_threads()
+        try:
+            def fed_step(i):
+                bx, by, bl, bc, _ = fd.next_train_batch()
+                one_step(70000 + i, batch=(bx, bc, by, bl))
+            for i in range(5):
+                fed_step(i)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for i in range(steps):
+                fed_step(5 + i)
+            torch.cuda.synchronize()
+            dt = (time.time() - t0) / steps
+        finally:
+            coord.stop = True
+        return {'what': '%d untimed-by-contract steps, every batch from wavenet_vocoder.feeder.Feeder: %d .npy utterances (3-8 s) on local disk -> producer thread '
+                        '(bucketing, hop-aligned crop to %d, mel clip + [0,1]) -> pinned host tensors -> non_blocking H2D -> the same step' % (steps, n_utt, T),
+                'steps': steps, 'ms_per_step': dt * 1e3, 'value': B * T / dt, 'unit': 'audio_samples/s'}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 class SmiSampler:
@@ -370,6 +448,64 @@ class SmiSampler:
         return out
 
 
+class _DryEngine(object):
+    """Stand-in for the HIP engine in --dry-run: the bucket interface allreduce_mean_buckets_ walks, nothing else."""
+
+    def __init__(self, n_params, buckets=3):
+        self.n_params = n_params
+        per = -(-n_params // buckets)
+        self._b = [(o, min(per, n_params - o)) for o in range(0, n_params, per)]
+
+    def grad_buckets(self):
+        return self._b
+
+    def wait_bucket(self, i, stream):
+        return None
+
+
+def dry_run(args):
+    """Launch / rendezvous rehearsal on CPU (gloo): proves that `python bench.py --gpus N` starts N ranks that find each other and walk
+    the product's bucketed tower-gradient mean (wavenet_vocoder.parallel) in step.  Prints ONE line marked dry_run; value is null."""
+    import torch.distributed as dist
+    from wavenet_vocoder.parallel import allreduce_mean_buckets_
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    eng = _DryEngine(1000)
+    flat = torch.zeros(eng.n_params)
+    dist.barrier()
+    t0 = time.time()
+    ok = True
+    for i in range(args.warmup + args.steps):
+        grads = torch.full((eng.n_params,), float(rank + 1 + i))
+        allreduce_mean_buckets_(eng, grads)
+        want = sum(r + 1 + i for r in range(world)) / world               # the tower mean every rank must hold
+        ok = ok and bool(torch.allclose(grads, torch.full_like(grads, want)))
+        flat -= 0.1 * grads
+    dist.barrier()
+    dt = time.time() - t0
+    cs = flat.sum().reshape(1).double()
+    lo, hi = cs.clone(), cs.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'metric': 'wavenet_train_audio_samples_per_sec', 'value': None, 'unit': 'audio_samples/s', 'dry_run': True,
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
+                          'collective': {'backend': 'gloo', 'world_size': dist.get_world_size(), 'ranks_counted_by_allreduce': int(round(ones.item())),
+                                         'self_launched': os.environ.get('WN_SELF_LAUNCHED') == '1'},
+                          'tower_mean_correct': ok, 'replicas_identical': bool(lo.item() == hi.item()), 'wall_s': dt,
+                          'note': 'launch rehearsal on CPU: no kernel ran, nothing here is a measurement'}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -379,6 +515,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-synth', action='store_true')
     ap.add_argument('--no-other-workloads', action='store_true', help='skip the 10-step runs of c5_stress / default_hparams appended under other_workloads')
+    ap.add_argument('--no-feeder', action='store_true', help='skip the untimed block of steps fed through the on-disk feeder (feeder -> pinned -> H2D)')
+    ap.add_argument('--cpu-full-batch', action='store_true', help='also RUN the oracle (forward + autograd backward) on the whole bench batch on the host cores (~1 min on the GPU box)')
     ap.add_argument('--no-exclusive', action='store_true', help='skip the untimed single-stream pass (keeps a rocprofv3 trace to the timed configuration)')
     ap.add_argument('--sustained', type=int, default=100, help='steps per block of the untimed-by-contract sustained measurement (3 blocks after the timed region; 0 = off)')
     ap.add_argument('--emulate-allreduce-gbps', type=float, default=0.0,
@@ -389,7 +527,20 @@ def main():
     ap.add_argument('--time', type=int, default=None, help='override T (debug)')
     ap.add_argument('--force-dist', action='store_true', help='take the multi-rank code path (process group, bucketed RCCL exchange, barriers) even with one rank: '
                     'a single-GPU rehearsal of what torch.distributed.run --nproc-per-node N executes')
+    ap.add_argument('--dry-run', action='store_true', help='launch / rendezvous rehearsal without a GPU: the same self-launch, the same bucketed exchange walk over gloo '
+                    'with a stand-in engine; prints a line marked dry_run with value null (never a measurement)')
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with no launcher around it starts the N ranks itself (one process per GPU, the environment
+    # torch.distributed.run would set); under a launcher (WORLD_SIZE / RANK present) this process IS one of the ranks.
+    from wavenet_vocoder import launch
+    if args.gpus > 1 and not launch.launched():
+        if not args.dry_run:
+            launch.require_gpus(args.gpus)
+        _log('no launcher found: starting %d ranks (one per GPU) on 127.0.0.1' % args.gpus)
+        raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if args.dry_run:
+        return dry_run(args)
 
     # stdout carries exactly ONE line (the result): native libraries that write to fd 1 (RCCL's version banner at the first
     # collective, rocm tools) are sent to stderr for the whole run; the JSON line goes to the saved descriptor at the end
@@ -402,6 +553,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch `python bench.py --gpus %d` (starts its own ranks) or torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus, args.gpus))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit('rank %d has no GPU: %d visible' % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
@@ -414,7 +570,16 @@ def main():
             dist.init_process_group(backend='nccl', device_id=device)
         else:
             dist.init_process_group(backend='nccl', device_id=device, rank=0, world_size=1)
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    collective = None
+    if use_dist:
+        # count the ranks with a real collective: the number RCCL actually connected, not the number the environment promised
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        collective = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks_counted_by_allreduce': int(round(ones.item())),
+                      'self_launched': os.environ.get('WN_SELF_LAUNCHED') == '1', 'gpus_visible': torch.cuda.device_count()}
+        if collective['ranks_counted_by_allreduce'] != args.gpus and not (args.force_dist and world == 1):
+            raise SystemExit('all-reduce counted %d ranks, --gpus %d' % (collective['ranks_counted_by_allreduce'], args.gpus))
+        _log('process group: %s' % json.dumps(collective))
 
     from wavenet_vocoder import _ext
     from wavenet_vocoder.models.modules import initialize_parameters
@@ -454,13 +619,15 @@ def main():
                 torch.cuda._sleep(int(n * 4 / (args.emulate_allreduce_gbps * 1e9) * emu_clock_hz))
         cur.wait_stream(emu_stream)
 
-    def one_step(i):
+    def one_step(i, exchange=True, batch=None):
+        bx, bc, by, bl = batch if batch is not None else (x, c, y, lengths)
         eng.pack_weights(flat)
-        eng.train_fwd(x, c, y, lengths, 1000 + i, loss)
+        eng.train_fwd(bx, bc, by, bl, 1000 + i, loss)
         eng.train_bwd(grads)
         if emu_stream is not None:
             emulated_allreduce()
-        allreduce_mean_buckets_(eng, grads, single_rank_ok=args.force_dist)          # per gradient bucket on a side stream, under the rest of the backward
+        if exchange:
+            allreduce_mean_buckets_(eng, grads, single_rank_ok=args.force_dist)          # per gradient bucket on a side stream, under the rest of the backward
         lr = _ext.learning_rate(hp.wavenet_lr_schedule, hp.wavenet_learning_rate, i, hp.wavenet_decay_rate, hp.wavenet_decay_steps, hp.wavenet_warmup)
         eng.optim_step(flat, grads, m, v, ema, lr, i)
 
@@ -508,6 +675,16 @@ def main():
         sustained = {'what': '3 blocks x %d steps right after the timed region, same step function; median block' % args.sustained,
                      'ms_per_step_blocks': blocks, 'ms_per_step': med, 'value': world * B * T / (med * 1e-3), 'unit': 'audio_samples/s', 'smi': smi.summary()}
         _log('sustained: %s ms/step' % ', '.join('%.2f' % b for b in blocks))
+    # untimed extra: the same step fed by the PRODUCT's feeder (wavenet_vocoder/feeder.py, reference feeder.py:266-340): .npy utterances
+    # on disk -> background thread (length bucketing, hop-aligned crop, mel normalisation) -> pinned host batch -> non_blocking H2D ->
+    # step.  `value` keeps the contract's resident inputs; this says what the input pipeline costs next to it.
+    with_feeder = None
+    if not args.no_feeder and world == 1 and not args.workload.endswith('_fp32'):
+        try:
+            with_feeder = measure_with_feeder(hp, B, T, device, one_step, steps=max(args.steps, 30))
+            _log('with feeder: %.2f ms/step' % with_feeder['ms_per_step'])
+        except Exception as e:          # a reported extra: never lose the JSON line to it
+            with_feeder = {'error': str(e)[:300]}
     # untimed extra: the device timeline of ONE step from the engine's in-kernel stamps (no profiler: rocprofv3 slows the host's enqueue
     # enough to change which stream runs ahead) -- forward / backward chain / weight-gradient tail and how long two launches overlap
     device_timeline = None
@@ -556,6 +733,24 @@ def main():
         tmax = torch.tensor([dt], device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # untimed extra under N > 1 ranks: the same K steps on rank 0 ALONE with the exchange switched off (the other ranks idle at a
+    # barrier), i.e. this box's own N = 1 figure next to the N-rank one.  The driver computes scaling from its own N = 1 run; this is
+    # the builder-side cross-check that both numbers come from one process on one box.
+    n1_reference = None
+    if use_dist and world > 1:
+        torch.cuda.synchronize(); dist.barrier()
+        if rank == 0:
+            for i in range(2):
+                one_step(90000 + i, exchange=False)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            for i in range(args.steps):
+                one_step(90010 + i, exchange=False)
+            torch.cuda.synchronize()
+            d1 = time.time() - t1
+            n1_reference = {'what': 'rank 0 alone, same %d steps, gradient exchange off, other ranks idle at a barrier' % args.steps,
+                            'ms_per_step': d1 / args.steps * 1e3, 'value': B * T * args.steps / d1, 'unit': 'audio_samples/s'}
+        dist.barrier()
 
     if rank == 0:
         samples = world * B * T * args.steps
@@ -614,8 +809,10 @@ def main():
                                         'traffic_write_per_step': traffic['write_bytes_per_step'] if traffic else None,
                                         'traffic_source': (traffic['source'] + ': sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE per step') if traffic else None},
             'mfma_whole_step_frac': 6.0 * mac * value / world / 1e12 / peak,
-            'sustained': sustained, 'host_enqueue': host_enqueue, 'device_timeline': device_timeline,
+            'sustained': sustained, 'with_feeder': with_feeder, 'host_enqueue': host_enqueue, 'device_timeline': device_timeline,
             'grad_buckets': [list(b) for b in eng.grad_buckets()], 'force_dist': bool(args.force_dist),
+            'collective': collective, 'n1_reference': n1_reference,
+            'scaling_vs_n1': (value / n1_reference['value']) if n1_reference else None,      # speed-up factor over this box's own 1-rank run
             'emulated_allreduce': ({'gbps': args.emulate_allreduce_gbps, 'bytes': int(eng.n_params) * 4,
                                     'serial_ms': int(eng.n_params) * 4 / (args.emulate_allreduce_gbps * 1e9) * 1e3,
                                     'what': 'single-GPU model: each gradient bucket occupies the communication stream for bytes / bandwidth once its event fired'}
@@ -640,7 +837,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             _log('cpu baseline (oracle) ...')
             res['cpu_baseline'] = cpu_baseline_subprocess(args.workload)
-            res['cpu_baseline']['full_batch'] = cpu_full_batch_reference(args.workload, B, T)
+            if args.cpu_full_batch:          # measured here or absent: never a number quoted from a file
+                _log('cpu baseline on the full batch (oracle, ~1 min on 256 cores) ...')
+                res['cpu_baseline']['full_batch'] = cpu_baseline_subprocess(args.workload, hard_timeout=900, fn='cpu_full_batch')
             if not args.no_synth:
                 _log('cpu baseline, synthesis (oracle incremental loop) ...')
                 try:

@@ -2,7 +2,9 @@
 tree (the Tacotron feature-prediction model is out of scope); ``Tacotron`` / ``Tacotron-2`` raise a clear error.
 
 Single GPU:   python train.py --model WaveNet
-N GPUs:       python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 train.py --model WaveNet
+N GPUs:       python train.py --model WaveNet --hparams wavenet_num_gpus=N      (the reference's single command, hparams.py:37: this
+              process starts the N ranks itself, one per GPU -- wavenet_vocoder/launch.py)
+     or:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 train.py --model WaveNet
 """
 import argparse
 import os
@@ -28,9 +30,25 @@ def prepare_run(args):
     return log_dir, modified_hp
 
 
+def _self_launch_if_asked(args):
+    """``wavenet_num_gpus = N > 1`` with no launcher around this process: start the N ranks (this same command line) and return their
+    exit code; None when this process is itself a rank (or a single-GPU run)."""
+    import sys
+    from wavenet_vocoder import launch
+    n = int(hparams.parse(args.hparams).wavenet_num_gpus)
+    if n <= 1 or launch.launched():
+        if launch.launched() and n > 1 and int(os.environ['WORLD_SIZE']) != n:
+            raise SystemExit('wavenet_num_gpus={} but the launcher started {} ranks'.format(n, os.environ['WORLD_SIZE']))
+        return None
+    launch.require_gpus(n)
+    print('wavenet_num_gpus={}: starting {} ranks, one per GPU'.format(n, n), flush=True)
+    return launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], n)
+
+
 def _init_distributed():
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    infolog.set_rank(int(os.environ.get('RANK', '0')))
     if not torch.cuda.is_available():
         raise SystemExit('train.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)')
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -70,6 +88,9 @@ def main():
     if args.model != 'WaveNet':
         raise NotImplementedError('--model {}: the Tacotron feature-prediction model is out of scope of this tree; '
                                   'train it with the reference and pass its GTA map.txt via --wavenet_input, then run --model WaveNet'.format(args.model))
+    rc = _self_launch_if_asked(args)
+    if rc is not None:
+        raise SystemExit(rc)
     _init_distributed()
     log_dir, hp = prepare_run(args)
     from wavenet_vocoder.train import wavenet_train

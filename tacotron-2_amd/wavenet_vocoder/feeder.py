@@ -78,7 +78,7 @@ class Feeder(object):
         self._train_q = queue.Queue(maxsize=8)
         self._eval_q = queue.Queue(maxsize=1)
         self._threads = []
-        self._error = None
+        self._errors = {}
 
     # ------------------------------------------------------------------ threads
     def start_threads(self, session=None):
@@ -103,12 +103,12 @@ class Feeder(object):
                     if self._put(q, self._pin(self._prepare_batch(batch))):
                         return
         except BaseException as e:          # noqa: BLE001 -- forwarded, not swallowed
-            self._error = e
-            # blocking puts (they give up only when the coordinator stops): the consumer of EITHER queue will reach the error -- the
-            # training loop must hear of a dead eval producer before the eval step blocks on it, and vice versa
-            for qq in (q, self._eval_q if q is self._train_q else self._train_q):
-                if self._put(qq, _FeederError(e)):
-                    return
+            # The error belongs to THIS queue: its consumer reaches it behind the good batches (blocking put; gives up only when the
+            # coordinator stops), and a consumer that finds the queue empty sees it in ``_errors``.  The other queue's consumer is
+            # not told: a dead eval producer surfaces when rank 0 runs the eval step, and the training loop (train.py: ``agree``)
+            # then stops every rank together.
+            self._errors[id(q)] = e
+            self._put(q, _FeederError(e))
 
     @staticmethod
     def _pin(batch):
@@ -139,8 +139,9 @@ class Feeder(object):
             try:
                 item = q.get(timeout=1.0)
             except queue.Empty:
-                if self._error is not None:
-                    raise RuntimeError('feeder thread failed: {!r}'.format(self._error)) from self._error
+                err = self._errors.get(id(q))
+                if err is not None:
+                    raise RuntimeError('feeder thread failed: {!r}'.format(err)) from err
                 continue
             if isinstance(item, _FeederError):
                 raise RuntimeError('feeder thread failed: {!r}'.format(item.error)) from item.error
@@ -151,10 +152,6 @@ class Feeder(object):
 
     def next_eval_batch(self):
         return self._to_device(self._get(self._eval_q))
-
-    def failed(self):
-        """The producer thread's exception, if any (the training loop polls it to stop every rank at the same step)."""
-        return self._error
 
     def _to_device(self, batch):
         dev = self._device or torch.device('cuda', torch.cuda.current_device())

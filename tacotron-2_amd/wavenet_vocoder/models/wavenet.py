@@ -15,7 +15,7 @@ import torch
 from datasets import audio
 from infolog import log
 from wavenet_vocoder import _ext, util
-from wavenet_vocoder.parallel import allreduce_mean_buckets_
+from wavenet_vocoder.parallel import allreduce_loss_and_flags, allreduce_mean_buckets_
 from wavenet_vocoder.util import is_mulaw, is_mulaw_quantize, is_scalar_input
 
 from .modules import initialize_parameters, receptive_field_size
@@ -158,17 +158,20 @@ class WaveNet(object):
         self.tower_y_hat.append(y_hat)
         self.tower_synth_upsampled_local_features.append(self.upsampled_local_features)
 
-    def add_loss(self):
-        """wavenet.py:476-519.  The masked loss is fused into the forward call; this exposes it."""
+    def add_loss(self, flags=None):
+        """wavenet.py:476-519.  The masked loss is fused into the forward call; this exposes it.  Data parallel: the reported loss is
+        the mean of the per-tower losses (wavenet.py:515-516; logging and the NaN guard only -- gradients never see it), and the
+        training loop's per-step flags (``flags``: a float vector, e.g. "my feeder failed") ride in the SAME small all-reduce:
+        ``self.reduced_flags`` = how many ranks raised each."""
         if self.is_training:
-            self.loss = self._loss_dev
-            if self._dist is not None and self._world > 1:
-                # reported loss = mean of the per-tower losses (wavenet.py:515-516); logging only
-                self._loss_avg = self._loss_dev.clone()
-                self._dist.all_reduce(self._loss_avg, op=self._dist.ReduceOp.SUM)
-                self._loss_avg.mul_(1.0 / self._world)
-                self.loss = self._loss_avg
             self.tower_loss = [self._loss_dev]
+            if flags is None:
+                flags = self._loss_dev.new_zeros(0)
+            if self._dist is not None and self._world > 1:
+                vec = allreduce_loss_and_flags(self._loss_dev, flags)
+                self.loss, self.reduced_flags = vec[:1], vec[1:]
+            else:
+                self.loss, self.reduced_flags = self._loss_dev, flags
             return self.loss
         if self.is_evaluating:
             return self.eval_loss
@@ -281,7 +284,7 @@ class WaveNet(object):
             # Models the pipeline does not fit (wn_synth_pipe_eligible) take the launch-per-layer graph path, whose time per step is
             # nearly independent of the batch: the whole batch in one run.
             piped = spg_ <= 0 and self.engine.pipeline_eligible(min(B, 8))
-            group = 8 if (piped and B > 8) else B
+            group = 8 if piped else min(B, 32)          # wn_synthesize takes at most 32 streams per run on the graph path too
             for b0 in range(0, B, group):
                 b1 = min(B, b0 + group)
                 nz = None if noise is None else noise[:, b0:b1].contiguous()

@@ -21,13 +21,33 @@ def rank():
     return torch.distributed.get_rank() if is_distributed() else 0
 
 
+def _mean_(t):
+    """ONE collective per piece: RCCL averages in the reduction itself (ReduceOp.AVG, no second kernel on the communication
+    stream); gloo has no AVG, so CPU tensors (the world-size-2 tests) take SUM and a scale."""
+    d = torch.distributed
+    if t.is_cuda:
+        d.all_reduce(t, op=d.ReduceOp.AVG)
+    else:
+        d.all_reduce(t, op=d.ReduceOp.SUM)
+        t.mul_(1.0 / world_size())
+    return t
+
+
 def allreduce_mean_(flat):
     """In-place mean over ranks of a flat tensor (tower-gradient mean, wavenet.py:564-575)."""
     if not is_distributed() or world_size() == 1:
         return flat
-    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
-    flat.mul_(1.0 / world_size())
-    return flat
+    return _mean_(flat)
+
+
+def allreduce_loss_and_flags(loss, flags):
+    """The step's two host-visible scalars in ONE small collective: the reported loss is the mean of the per-tower losses
+    (wavenet.py:515-516) and every rank must learn whether ANY rank raised a flag (feeder failure, local abort).  SUM of
+    [loss / world, flag_0, flag_1, ...]: element 0 comes back as the mean, the rest as the number of ranks that raised each flag."""
+    vec = torch.cat([loss.reshape(1).float() / world_size(), flags.reshape(-1).float()])
+    if is_distributed() and world_size() > 1:
+        torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM)
+    return vec
 
 
 _COMM_STREAMS = {}
@@ -45,7 +65,7 @@ def allreduce_mean_buckets_(engine, flat, single_rank_ok=False):
     """Tower-gradient mean (wavenet.py:564-575) overlapped with the backward pass.
 
     ``engine.train_bwd(flat)`` completes the flat gradient in ``engine.grad_buckets()`` contiguous pieces, top layers first, on
-    ctx-owned streams.  Each piece is all-reduced (SUM, then 1/world) on a communication stream as soon as its event fires,
+    ctx-owned streams.  Each piece is all-reduced (ReduceOp.AVG: one RCCL call, no scaling kernel) on a communication stream as soon as its event fires,
     i.e. while the weight gradients of the layers below are still being computed; the caller's stream is ordered after the last
     piece.  xGMI is point-to-point (7 x ~153 GB/s per GPU): the pieces stay large (4-6 of ~10-15 MB for the paper model), never
     one call per tensor.  Must be called right after ``engine.train_bwd(flat)`` on the same stream.  CPU tensors (gloo tests) take
@@ -54,24 +74,19 @@ def allreduce_mean_buckets_(engine, flat, single_rank_ok=False):
     """
     if not is_distributed() or (world_size() == 1 and not single_rank_ok):
         return flat
-    w = world_size()
     buckets = engine.grad_buckets()
     covered = sum(n for _, n in buckets)
     if not flat.is_cuda:
         for i, (off, n) in enumerate(buckets):
             engine.wait_bucket(i, None)
-            piece = flat[off:off + n]
-            torch.distributed.all_reduce(piece, op=torch.distributed.ReduceOp.SUM)
-            piece.mul_(1.0 / w)
+            _mean_(flat[off:off + n])
     else:
         cur = torch.cuda.current_stream(flat.device)
         comm = _comm_stream(flat.device)
         for i, (off, n) in enumerate(buckets):
             engine.wait_bucket(i, comm)                     # comm stream waits for bucket i only (not for the rest of the backward)
             with torch.cuda.stream(comm):
-                piece = flat[off:off + n]
-                torch.distributed.all_reduce(piece, op=torch.distributed.ReduceOp.SUM)
-                piece.mul_(1.0 / w)
+                _mean_(flat[off:off + n])
         cur.wait_stream(comm)
     if covered != flat.numel():                             # alignment padding between tensors is inside the buckets; anything else is a bug
         raise RuntimeError('gradient buckets cover %d of %d floats' % (covered, flat.numel()))
@@ -101,10 +116,10 @@ def assert_replicas_in_sync(flat, what='parameters'):
     if not is_distributed() or world_size() == 1:
         return True
     cs = param_checksum(flat).reshape(1)
-    lo, hi = cs.clone(), cs.clone()
-    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-    if int(lo.item()) != int(hi.item()):
+    both = torch.cat([cs, -cs])                             # MAX of (cs, -cs) = (max, -min): one collective
+    torch.distributed.all_reduce(both, op=torch.distributed.ReduceOp.MAX)
+    hi, lo = int(both[0].item()), -int(both[1].item())
+    if lo != hi:
         raise RuntimeError('data-parallel replicas diverged: %s differ between ranks (checksum %d on rank %d, range [%d, %d])'
-                           % (what, int(cs.item()), rank(), int(lo.item()), int(hi.item())))
+                           % (what, int(cs.item()), rank(), lo, hi))
     return True

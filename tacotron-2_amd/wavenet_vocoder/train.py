@@ -255,6 +255,7 @@ def train(log_dir, args, hparams, input_path):
     tensorboard_dir = os.path.join(log_dir, 'wavenet_events')
     meta_folder = os.path.join(log_dir, 'metas')
     rank = _rank()
+    infolog.set_rank(rank)            # rank 0 owns the terminal and Terminal_train_log; the others speak only through all_ranks=True
     if rank == 0:
         for d in (save_dir, plot_dir, wav_dir, eval_dir, eval_plot_dir, eval_wav_dir, tensorboard_dir, meta_folder):
             os.makedirs(d, exist_ok=True)
@@ -325,85 +326,120 @@ def train(log_dir, args, hparams, input_path):
 
         # The host reads the loss ONE STEP LATE: step k's loss travels to pinned memory behind step k's kernels and is looked at after
         # step k+1 has been enqueued, so the device never waits for the host (the reference's session.run returns the loss of the step
-        # it ran: one host round trip per step, which here would expose the ~1 ms of enqueue time every step).  The NaN / > 100
-        # guard (train.py:307-309) therefore trips one step after the fact.  Data parallel: the same late read carries a "some
-        # rank's feeder failed" flag, so that every rank leaves the loop at the SAME step instead of hanging in an all-reduce.
+        # it ran: one host round trip per step, which here would expose the ~1 ms of enqueue time every step).  On steps that WRITE
+        # something (summary, checkpoint, eval, the last step) the read is not late: the NaN / > 100 guard (train.py:307-309) runs on
+        # the step's own loss before anything is saved, so `--restore` can never resume from an exploded checkpoint -- one host sync
+        # per interval.  Data parallel: the loss the host sees is the tower mean (identical on every rank, so the guard trips on all
+        # of them in the same iteration) and the same small collective carries a "some rank's feeder failed" count, so that every
+        # rank leaves the loop at the SAME step instead of hanging in an all-reduce.
         late = _LateScalars(2, model.device)
-        last_batch = None
-        feeder_error = None
+        dp = _dist() if (_dist() and world > 1) else None
         flag_const = (torch.zeros(1, device=model.device), torch.ones(1, device=model.device))     # (no H2D copy inside the loop)
+
+        def agree(local_error, what):
+            """One tiny MAX all-reduce: did ANY rank fail in the block just left?  Every rank raises together (the failing one its own
+            exception), nobody is left waiting inside the next collective.  Also the barrier that keeps the other ranks out of the next
+            step's all-reduce while rank 0 writes files."""
+            if dp is not None:
+                f = flag_const[1 if local_error is not None else 0].clone()
+                dp.all_reduce(f, op=dp.ReduceOp.MAX)
+                if float(f.item()) > 0 and local_error is None:
+                    raise RuntimeError('another rank failed while {}: stopping every rank'.format(what))
+            if local_error is not None:
+                raise local_error
+
+        # the first batch, before any step is enqueued: a rank whose feeder cannot deliver it has no last good batch to keep its
+        # collectives matched with, so the ranks agree here once
+        first_error, batch = None, None
+        if step < args.wavenet_train_steps:
+            try:
+                batch = feeder.next_train_batch()
+            except RuntimeError as e:
+                first_error = e
+            agree(first_error, 'fetching the first batch')
+        last_batch = batch
+        feeder_error = None
+        newest = (step, float('nan'))                # (step, loss) of the newest loss the host has looked at
         while not coord.should_stop() and step < args.wavenet_train_steps:
             start_time = time.time()
-            if feeder_error is None:
+            if batch is None and feeder_error is None:
                 try:
                     batch = feeder.next_train_batch()
                     last_batch = batch
                 except RuntimeError as e:
-                    if _dist() is None or world == 1 or last_batch is None:
+                    if dp is None:
                         raise
                     feeder_error = e
             if feeder_error is not None:
-                # keep this step's collectives matched with the last good batch and raise the flag.  The other ranks see it one step late,
-                # i.e. after they have enqueued one MORE step: this rank stays for that step too and everybody leaves at the same read.
+                # keep the collectives matched with the last good batch and raise the flag; every rank reads the summed flag at the same
+                # late read (one step later, or in this very step when it is a writing step) and leaves there
                 batch = last_batch
             x, y, lengths, c, g = batch
             model.initialize(y, c, g, lengths, x=x)
-            loss_t = model.add_loss()
+            loss_t = model.add_loss(flags=flag_const[1 if feeder_error is not None else 0])      # data parallel: ONE 2-float all-reduce (loss mean, flag count)
             step = model.add_optimizer(step)
-            flag = flag_const[1 if feeder_error is not None else 0]
-            if _dist() and world > 1:
-                flag = flag.clone()
-                _dist().all_reduce(flag, op=_dist().ReduceOp.MAX)
-            late.push(step, torch.cat([loss_t.reshape(1).float(), flag]))
-            prev = late.pop_ready(keep=1 if step < args.wavenet_train_steps else 0)     # the previous step's (the last step: its own)
+            embed = (hparams.gin_channels > 0 and model.embedding_table is not None
+                     and (step % args.embedding_interval == 0 or step == args.wavenet_train_steps or step == 1))
+            writes = (step % args.summary_interval == 0 or step % args.checkpoint_interval == 0 or step % args.eval_interval == 0
+                      or step >= args.wavenet_train_steps or embed)              # the same decision on every rank
+            late.push(step, torch.cat([loss_t.reshape(1).float(), model.reduced_flags.reshape(1).float()]))
+            ready = late.pop_ready(keep=0 if writes else 1)
             time_window.append(time.time() - start_time)
-            for pstep, (loss, bad) in prev:
+            for pstep, (loss, bad) in ready:
                 if bad > 0:
                     if feeder_error is not None:
                         raise feeder_error
                     raise RuntimeError('the feeder of another rank failed at step {}: stopping every rank'.format(pstep))
                 loss_window.append(loss)
+                newest = (pstep, loss)
                 message = 'Step {:7d} [{:.3f} sec/step, loss={:.5f}, avg_loss={:.5f}]'.format(pstep, time_window.average, loss, loss_window.average)
                 log(message, end='\r', slack=(pstep % args.checkpoint_interval == 0))
                 if np.isnan(loss) or loss > 100:
                     log('Loss exploded to {:.5f} at step {}'.format(loss, pstep))
                     raise Exception('Loss exploded')
-            loss = loss_window._values[-1] if loss_window.count else float('nan')      # (summaries: the newest loss the host has seen)
 
-            if _dist() and world > 1 and step % args.checkpoint_interval == 0:
+            if dp is not None and step % args.checkpoint_interval == 0:
                 from wavenet_vocoder.parallel import assert_replicas_in_sync
                 assert_replicas_in_sync(model.params, what='parameters at step {}'.format(step))
 
-            if step % args.summary_interval == 0 and rank == 0:
-                log('\nWriting summary at step {}'.format(step))
-                gmax = float(model.grads.abs().max().item())
-                n_samples = int(lengths.sum().item()) * world
-                scalars.write(json.dumps({'step': step, 'wavenet_loss': loss, 'wavenet_learning_rate': model.learning_rate,
-                                          'wavenet_max_gradient_norm': gmax,
-                                          'audio_samples_per_sec': n_samples / max(time_window.average, 1e-9)}) + '\n')
-                scalars.flush()
+            block_error = None
+            try:
+                if step % args.summary_interval == 0 and rank == 0:
+                    log('\nWriting summary at step {}'.format(step))
+                    gmax = float(model.grads.abs().max().item())
+                    n_samples = int(lengths.sum().item()) * world
+                    scalars.write(json.dumps({'step': newest[0], 'wavenet_loss': newest[1], 'wavenet_learning_rate': model.learning_rate,
+                                              'wavenet_max_gradient_norm': gmax,
+                                              'audio_samples_per_sec': n_samples / max(time_window.average, 1e-9)}) + '\n')
+                    scalars.flush()
 
-            if (step % args.checkpoint_interval == 0 or step == args.wavenet_train_steps) and rank == 0:
-                save_log(model, batch, step, plot_dir, wav_dir, hparams=hparams, model_name=args.model)
-                save_checkpoint(model, save_dir, checkpoint_path)
+                if (step % args.checkpoint_interval == 0 or step == args.wavenet_train_steps) and rank == 0:
+                    save_log(model, batch, step, plot_dir, wav_dir, hparams=hparams, model_name=args.model)
+                    save_checkpoint(model, save_dir, checkpoint_path)
 
-            if step % args.eval_interval == 0 and rank == 0:
-                log('\nEvaluating at step {}'.format(step))
-                eval_step(model, feeder.next_eval_batch(), step, eval_plot_dir, eval_wav_dir, scalars, hparams=hparams, model_name=args.model)
-            if (hparams.gin_channels > 0 and model.embedding_table is not None and rank == 0
-                    and (step % args.embedding_interval == 0 or step == args.wavenet_train_steps or step == 1)):
-                log('\nSaving Model Speaker Embeddings visualization..')
-                add_embedding_stats(tensorboard_dir, ['WaveNet_model/inference/gc_embedding'], [speaker_embedding_meta], [model.embedding_table], step)
-                log('WaveNet Speaker embeddings have been updated on tensorboard!')
-            if _dist() and (step % args.checkpoint_interval == 0 or step % args.eval_interval == 0):
-                _dist().barrier()          # rank 0 wrote logs / a checkpoint / ran the eval step: the others wait HERE, not inside the next all-reduce
+                if step % args.eval_interval == 0 and rank == 0:
+                    log('\nEvaluating at step {}'.format(step))
+                    eval_step(model, feeder.next_eval_batch(), step, eval_plot_dir, eval_wav_dir, scalars, hparams=hparams, model_name=args.model)
+                if embed and rank == 0:
+                    log('\nSaving Model Speaker Embeddings visualization..')
+                    add_embedding_stats(tensorboard_dir, ['WaveNet_model/inference/gc_embedding'], [speaker_embedding_meta], [model.embedding_table], step)
+                    log('WaveNet Speaker embeddings have been updated on tensorboard!')
+            except Exception as e:
+                if dp is None:
+                    raise
+                block_error = e
+            if dp is not None and writes:
+                # rank 0 wrote logs / a checkpoint / ran the eval step: the others wait HERE, not inside the next all-reduce -- and
+                # learn here if it failed (a failing eval feeder on rank 0 used to leave them waiting at a barrier)
+                agree(block_error, 'writing logs / checkpoint / evaluating at step {}'.format(step))
+            batch = None
 
         if coord.should_stop() and step < args.wavenet_train_steps:
             raise RuntimeError('training stopped by the coordinator at step {} of {}'.format(step, args.wavenet_train_steps))
         log('Wavenet training complete after {} global steps'.format(args.wavenet_train_steps), slack=True)
         return save_dir
     except Exception as e:
-        log('Exiting due to exception: {}'.format(e), slack=True)
+        log('Exiting due to exception: {}'.format(e), slack=True, all_ranks=True)
         traceback.print_exc()
         coord.request_stop(e)
 

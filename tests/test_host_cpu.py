@@ -310,6 +310,8 @@ import sys, types, os, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/tacotron-2_amd')
 import torch.distributed as dist
 rank, fail_at = int(sys.argv[1]), int(sys.argv[2])
+explode_at = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+eval_fails = len(sys.argv) > 5 and sys.argv[5] == 'evalfail'
 dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=2)
 import hparams as H
 from wavenet_vocoder import train as T
@@ -321,8 +323,11 @@ class FakeModel:
         self.params = torch.randn(N, generator=torch.Generator().manual_seed(3 + rank)); dist.broadcast(self.params, 0)
         self.grads = torch.zeros(N); return self
     def initialize(self, y, c, g, lengths, x=None): self._x = x
-    def add_loss(self):
-        l = self._x.mean().reshape(1).clone(); dist.all_reduce(l); return l / 2
+    def add_loss(self, flags=None):
+        from wavenet_vocoder.parallel import allreduce_loss_and_flags
+        l = self._x.mean().reshape(1) * (float('nan') if (explode_at and self.global_step + 1 == explode_at and rank == 1) else 1.0)
+        vec = allreduce_loss_and_flags(l, flags)            # the product's ONE small collective: tower-mean loss + flag count
+        self.reduced_flags = vec[1:]; return vec[:1]
     def add_optimizer(self, step):
         self.grads.copy_(torch.full((N,), float(self._x.mean()))); dist.all_reduce(self.grads); self.grads /= 2
         self.params -= 0.01 * self.grads; self.global_step = step + 1; self.steps.append(self.global_step); return self.global_step
@@ -340,7 +345,10 @@ model_box = []
 T.create_model = lambda name, hp: (model_box.append(FakeModel(hp)) or model_box[-1])
 T.SyntheticFeeder = FakeFeeder
 T.save_log = lambda *a, **k: None
-T.eval_step = lambda *a, **k: 0.0
+def _eval(*a, **k):
+    if eval_fails: raise RuntimeError('eval feeder failed (injected, rank 0 only)')
+    return 0.0
+T.eval_step = _eval
 hp = H._build(); hp.parse('mi355_synthetic_data=True,wavenet_batch_size=4,max_time_steps=8,hop_size=4,upsample_scales=[2,2]')
 args = types.SimpleNamespace(base_dir=sys.argv[3], model='WaveNet', restore=False, wavenet_train_steps=7, checkpoint_interval=2, summary_interval=3,
                              eval_interval=4, embedding_interval=100, eval_max_time=0)
@@ -356,29 +364,57 @@ print('rank ok')
 '''
 
 
-@pytest.mark.parametrize('fail_at', [0, 4, 7])
+def _run_train_loop_workers(tmp_path, fail_at, extra=()):
+    port = 35500 + (os.getpid() % 2000) + fail_at + 11 * len(extra)
+    script = tmp_path / 'train_loop_worker.py'
+    script.write_text(_TRAIN_LOOP_WORKER % {'root': ROOT, 'port': port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(fail_at), str(tmp_path)] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    res = []
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and 'rank ok' in o, o[-3000:]
+        res.append(re.search(r'RESULT rank=(\d) ret=(\w+) steps=(\d+)', o).groups())
+    return res, outs
+
+
+def test_training_loop_never_checkpoints_an_exploded_step_gloo(tmp_path):
+    """ADVICE round 3 (reference train.py:307-309 raises BEFORE saver.save): rank 1's loss turns NaN at step 4 -- a checkpoint-interval
+    step.  The tower-mean loss is NaN on both ranks, the guard reads the step's OWN loss before anything is written, both ranks stop
+    after 4 steps and no wavenet_model.ckpt-4 exists (the index still names step 2)."""
+    res, outs = _run_train_loop_workers(tmp_path, 0, extra=['4'])
+    assert {int(r[2]) for r in res} == {4} and all(r[1] == 'none' for r in res), res
+    d = os.path.join(str(tmp_path), 'logs', 'wave_pretrained')
+    assert os.path.exists(os.path.join(d, 'wavenet_model.ckpt-2.pt')) and not os.path.exists(os.path.join(d, 'wavenet_model.ckpt-4.pt'))
+    assert 'ckpt-2' in open(os.path.join(d, 'checkpoint')).read()
+    assert 'Loss exploded to' in outs[0] and 'Loss exploded to' not in outs[1] and '[rank 1] Exiting due to exception' in outs[1]          # rank 0 owns the terminal (infolog.set_rank)
+
+
+def test_training_loop_eval_failure_on_rank0_stops_every_rank_gloo(tmp_path):
+    """rank 0's eval step raises at step 4 while rank 1 waits for it: the post-block agreement (one MAX all-reduce in
+    place of the barrier) tells rank 1, both leave after 4 steps."""
+    res, outs = _run_train_loop_workers(tmp_path, 0, extra=['0', 'evalfail'])
+    assert {int(r[2]) for r in res} == {4} and all(r[1] == 'none' for r in res), res
+    assert 'another rank failed' in outs[1]
+
+
+@pytest.mark.parametrize('fail_at', [0, 4, 5, 7])
 def test_training_loop_data_parallel_control_flow_gloo(tmp_path, fail_at):
     """The PRODUCT training loop (wavenet_vocoder/train.py, mirror of the reference's train.py:345) on two gloo ranks with a stand-in
     model / feeder: losses read one step late, the replica checksum guard at every checkpoint interval, rank-0-only logging behind
     barriers -- and a feeder failure on ONE rank (at batch 4; at the last batch): the failing rank keeps its collectives matched with
     its last good batch, every rank sees the flag at the same late read and leaves the loop after the SAME number of steps (nobody is
     left inside an all-reduce), and the driver returns None like the reference's does after an exception (train.py:340-343)."""
-    port = 35500 + (os.getpid() % 2000) + fail_at
-    script = tmp_path / 'train_loop_worker.py'
-    script.write_text(_TRAIN_LOOP_WORKER % {'root': ROOT, 'port': port})
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(fail_at), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
-    res = []
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0 and 'rank ok' in o, o[-3000:]
-        res.append(re.search(r'RESULT rank=(\d) ret=(\w+) steps=(\d+)', o).groups())
+    res, _ = _run_train_loop_workers(tmp_path, fail_at)
     steps = {int(r[2]) for r in res}
     assert len(steps) == 1, res                                  # both ranks ran the same number of optimiser steps
     if fail_at == 0:
         assert steps == {7} and all(r[1] == 'ok' for r in res)
         assert os.path.exists(os.path.join(str(tmp_path), 'logs', 'wave_pretrained', 'wavenet_model.ckpt-6.pt'))
     else:
-        assert steps == {min(fail_at + 1, 7)} and all(r[1] == 'none' for r in res), res     # the failing step + the one the others had already enqueued
+        # the failing step + the one the others had already enqueued -- unless the failing step is a WRITING step (4: checkpoint + eval
+        # interval, 7: the last), whose scalars are read at once
+        want = fail_at if fail_at in (4, 7) else fail_at + 1
+        assert steps == {want} and all(r[1] == 'none' for r in res), res
 
 
 def test_late_scalars_are_read_one_step_behind():
@@ -651,11 +687,18 @@ def test_feeder_thread_errors_reach_the_training_loop(tmp_path):
     coord = _Coordinator()
     fd = F.Feeder(coord, meta, str(tmp_path), hp, device=torch.device('cpu'))
     fd.start_threads()
-    got = 0
-    with pytest.raises(RuntimeError, match='feeder thread failed'):
-        for _ in range(200):
-            fd.next_train_batch(); got += 1
-    assert not coord.should_stop() and isinstance(fd.failed(), ValueError)
+    # the broken utterance lands in the train or the test split: the error belongs to THAT producer's queue (its consumer reaches it
+    # behind the good batches); the other queue keeps delivering
+    raised = []
+    for nxt, n in ((fd.next_train_batch, 200), (fd.next_eval_batch, 3)):
+        try:
+            for _ in range(n):
+                nxt()
+        except RuntimeError as e:
+            assert 'feeder thread failed' in str(e)
+            raised.append(nxt.__name__)
+    assert len(raised) == 1, raised
+    assert not coord.should_stop() and [type(e) for e in fd._errors.values()] == [ValueError]
     coord.request_stop()
 
 

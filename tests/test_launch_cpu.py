@@ -1,0 +1,80 @@
+"""CPU tests of the single-command multi-GPU launch (wavenet_vocoder/launch.py): `python bench.py --gpus N` and
+`python train.py --hparams wavenet_num_gpus=N` start their own ranks -- the reference's one-command UX (hparams.py:37,
+wavenet.py:227-239) on one process per GPU.  The rehearsal runs over gloo with a stand-in engine (bench.py --dry-run): it proves
+the launch, the rendezvous on 127.0.0.1 and the product's bucketed tower-mean walk, never a number."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'WN_SELF_LAUNCHED'):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_gpus2_starts_two_ranks_that_rendezvous():
+    """`python bench.py --gpus 2` with no launcher must not silently run one rank."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=240, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout                       # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d['dry_run'] is True and d['value'] is None and d['ms_per_step'] is None        # never mistaken for a measurement
+    assert d['n_gpus'] == 2 and d['collective'] == {'backend': 'gloo', 'world_size': 2, 'ranks_counted_by_allreduce': 2, 'self_launched': True}
+    assert d['tower_mean_correct'] and d['replicas_identical']
+    assert 'starting 2 ranks' in r.stderr
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64'], capture_output=True, text=True, timeout=240, env=_clean_env())
+    assert r.returncode != 0 and 'asked for 64 GPUs' in r.stderr and not r.stdout.strip()
+
+
+def test_bench_rejects_a_launcher_with_the_wrong_rank_count():
+    env = _clean_env(); env.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in r.stderr and not r.stdout.strip()
+
+
+def test_spawn_ranks_propagates_failure_and_stops_the_other_ranks(tmp_path):
+    from wavenet_vocoder import launch
+    script = tmp_path / 'w.py'
+    script.write_text('import os, sys, time\nr = int(os.environ["RANK"])\nassert os.environ["WORLD_SIZE"] == "3" and os.environ["MASTER_ADDR"] == "127.0.0.1"\n'
+                      'if r == 1: sys.exit(7)\ntime.sleep(60)\n')
+    import time
+    t0 = time.time()
+    assert launch.spawn_ranks([str(script)], 3) == 7
+    assert time.time() - t0 < 30                           # ranks 0 and 2 were terminated, not waited for
+
+
+def test_train_cli_self_launches_when_wavenet_num_gpus_is_set(monkeypatch):
+    spec = importlib.util.spec_from_file_location('train_cli', os.path.join(ROOT, 'tacotron-2_amd', 'train.py'))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    from wavenet_vocoder import launch
+    import types
+    calls = []
+    monkeypatch.setattr(launch, 'require_gpus', lambda n: calls.append(('need', n)))
+    monkeypatch.setattr(launch, 'spawn_ranks', lambda argv, n, **k: calls.append(('spawn', n, argv[0])) or 0)
+    for k in ('RANK', 'WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    assert cli._self_launch_if_asked(types.SimpleNamespace(hparams='wavenet_num_gpus=4,wavenet_batch_size=32')) == 0
+    assert calls == [('need', 4), ('spawn', 4, os.path.join(ROOT, 'tacotron-2_amd', 'train.py'))]
+    calls.clear()
+    assert cli._self_launch_if_asked(types.SimpleNamespace(hparams='wavenet_num_gpus=1')) is None and not calls
+    # already one of the ranks: no second launch; a rank-count mismatch is refused
+    monkeypatch.setenv('RANK', '2'); monkeypatch.setenv('WORLD_SIZE', '4')
+    assert cli._self_launch_if_asked(types.SimpleNamespace(hparams='wavenet_num_gpus=4')) is None and not calls
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    with pytest.raises(SystemExit, match='launcher started 8 ranks'):
+        cli._self_launch_if_asked(types.SimpleNamespace(hparams='wavenet_num_gpus=4'))
+    from hparams import hparams
+    hparams.parse('wavenet_num_gpus=1,wavenet_batch_size=8')
