@@ -250,7 +250,7 @@ def cpu_baseline_subprocess(workload, hard_timeout=150, fn='cpu_baseline'):
         return {'value': None, 'unit': 'audio_samples/s', 'cores': None, 'kind': 'port', 'sample': 'timed out after %d s' % hard_timeout}
 
 
-def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8)):
+def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8), modes=('pipe', 'graph')):
     """Autoregressive synthesis RTF at hp.sample_rate (BASELINE configs[3]: batch {1, 8} x 5 s from fixed mel conditioning).
     'pipe' = the persistent dataflow pipeline (steps_per_graph=0), timed on the full 5 s clip; 'graph' = the
     launch-per-layer hipGraph path, timed on 0.25 s (it is ~10x slower) for comparison."""
@@ -258,12 +258,19 @@ def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8)):
     hop = int(np.prod(hp.upsample_scales))
     out = {}
     for mode, secs, spg in (('pipe', seconds, 0), ('graph', min(seconds, 0.25), int(hp.mi355_steps_per_graph) or 16)):
+        if mode not in modes:
+            continue
         Tc = max(2, int(round(secs * hp.sample_rate / hop)))
         T = Tc * hop
-        for B in batches:
+        # the pipeline also at hparams.py's wavenet_synthesis_batch_size (20): ONE run, streams pipelined through the layer ring
+        for B in (tuple(batches) + ((int(hp.wavenet_synthesis_batch_size),) if mode == 'pipe' and int(hp.wavenet_synthesis_batch_size) not in batches else ())):
             _log('synthesis %s B=%d T=%d' % (mode, B, T))
             eng = _ext.Engine(hp, B, T, inference_only=True)       # synthesis-only context: pre-sized, ~1.5 KB of HBM per (stream x sample)
             eng.pack_weights(eng_params_flat)
+            if mode == 'pipe' and not eng.pipeline_eligible(B):   # (would silently time the ~10x slower launch-per-layer path on the full clip)
+                out['%s_B%d' % (mode, B)] = {'skipped': 'not pipeline-eligible at this batch'}
+                eng.close()
+                continue
             c = torch.rand(B, hp.cin_channels, Tc, device=device)
             samples = torch.empty(B, T, device=device)
             # sampling noise is drawn on the device (noise = None: Philox keyed by the seed); nothing is uploaded
@@ -343,6 +350,13 @@ def measure_other_workload(key, device, steps=10, warmup=3):
                            'rows_per_launch': rows, 'timing': 'in-kernel stamps (pure kernel time), live in the two-stream step'},
            'bound': 'hbm' if alg_bytes_per_sample(hp, e_act) * peak_tf * 1e12 > 6.0 * mac_per_sample(hp) * 8e12 else 'mfma'}
     eng.close()
+    if key == 'c5_stress':
+        # synthesis at this width (R = S = 512 > the LDS-resident pipeline's 384): the launch-per-layer hipGraph path, 0.1 s of audio
+        try:
+            syn = measure_synthesis(hp, flat, device, seconds=0.1, batches=(1, 8), modes=('graph',))
+            out['synthesis_graph_path'] = {k: {kk: v[kk] for kk in ('rtf_per_stream', 'us_per_step', 'deadline_us', 'path', 'seconds_of_audio_per_stream')} for k, v in syn.items()}
+        except Exception as e:
+            out['synthesis_graph_path'] = {'error': str(e)[:200]}
     del flat, grads, m, v, ema
     torch.cuda.empty_cache()
     return out

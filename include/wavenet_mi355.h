@@ -54,7 +54,9 @@ enum wn_lr_schedule { WN_LR_EXPONENTIAL = 0, WN_LR_NOAM = 1 };                  
  *   WN_COMPUTE_BF16  bf16 MFMA operands, fp32 accumulation (BASELINE configs[1]'s training dtype; the tuned path);
  *   WN_COMPUTE_F32   the reference's own arithmetic -- fp32 activations, fp32 weights, fp32 accumulation (modules.py:306-320,
  *                    wavenet.py:650-721) -- for wn_train_fwd AND wn_train_bwd (fp32 MFMA SGEMMs, ~13x slower: an accuracy /
- *                    validation mode; gradient buckets collapse to one).  Synthesis is unaffected. */
+ *                    validation mode; gradient buckets collapse to one), and for wn_synthesize: fp32 weights read from the flat
+ *                    parameter buffer, fp32 ring queues, fp32 accumulation, precise tanh / exp (modules.py:273-303,
+ *                    wavenet.py:821-886; launch-per-layer path only, far from real time; wn_synth_last_path() = 3). */
 enum wn_compute_dtype { WN_COMPUTE_BF16 = 0, WN_COMPUTE_F32 = 1 };
 
 #define WN_MAX_UPSAMPLE 8
@@ -200,13 +202,13 @@ int wn_fill_noise(wn_ctx* ctx, float* noise, int32_t B, int32_t T, uint64_t seed
  * out (a workgroup was not resident) the kernels leave early and raise a device flag.  wn_synth_check waits for the LAST
  * wn_synthesize of this context to finish and returns WN_E_HIP (+ wn_last_error) if that happened, WN_OK otherwise; the next
  * wn_synthesize on the context reports a pending failure too.  wn_synth_last_path: 0 none yet, 1 launch-per-layer hipGraph path,
- * 2 persistent pipeline. */
+ * 2 persistent pipeline, 3 fp32 launch-per-layer path (compute_dtype = WN_COMPUTE_F32). */
 int wn_synth_check(wn_ctx* ctx);
 int wn_synth_last_path(const wn_ctx* ctx);
 /* 1 if wn_synthesize(steps_per_graph <= 0) would run B streams of this model on the persistent pipeline (all of a CU's weights must
- * fit its 160 KiB of LDS: one CU per 32 gate pairs, <= 8 CUs per layer, R, S <= 384, B <= 16), 0 if it would take the
- * launch-per-layer hipGraph path.  Host helper: callers that split a large batch into groups of 8 streams only do so for the
- * pipeline (the graph path's time per step is nearly independent of B up to 32). */
+ * fit its 160 KiB of LDS next to 256 B of state per stream: one CU per 32 gate pairs, <= 8 CUs per layer, R, S <= 384, B <= 32), 0 if
+ * it would take the launch-per-layer hipGraph path.  Host helper: a caller sends the whole batch in one run when this says 1 for it
+ * (up to ~17 streams cost the wall time of one, more are paced by the head CU at ~2 us per stream and sample), else groups of 8. */
 int wn_synth_pipe_eligible(const wn_ctx* ctx, int32_t B);
 
 /* Stand-alone samplers on [B,O,T] parameters (train-time log path, wavenet.py:302-325). */

@@ -246,8 +246,10 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
         // pre-size every synthesis buffer for (max_batch, max_time): wn_synthesize never allocates on this context
         if (c->maxB > 32) { c->err = "inference_only: max_batch must be <= 32 streams"; rc = WN_E_SHAPE; }
         if (rc == WN_OK) rc = wn_noise_reserve(c, c->maxB, c->maxT);
-        // the persistent pipeline when the model fits it (up to 16 streams per run), else the launch-per-layer graph path
-        if (rc == WN_OK) rc = wn_pipe_eligible(c, std::min(c->maxB, 16)) ? wn_pipe_reserve(c, std::min(c->maxB, 16), c->maxT) : wn_synth_reserve(c);
+        // the persistent pipeline when the model fits it (all max_batch streams in one run if their LDS state fits, else groups of 8), else the launch-per-layer graph path
+        if (rc == WN_OK) rc = c->cfg.compute_dtype == WN_COMPUTE_F32 ? wn_synth_f32_reserve(c, c->maxB)
+                              : wn_pipe_eligible(c, c->maxB) ? wn_pipe_reserve(c, c->maxB, c->maxT)
+                              : wn_pipe_eligible(c, std::min(c->maxB, 8)) ? wn_pipe_reserve(c, std::min(c->maxB, 8), c->maxT) : wn_synth_reserve(c);
     }
     if (rc != WN_OK) { g_create_err = c->err; wn_destroy(c); return rc; }
     *out = c;
@@ -257,6 +259,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
 extern "C" void wn_destroy(wn_ctx* c) {
     if (!c) return;
     wn_synth_free(c);
+    wn_synth_f32_free(c);
     wn_pipe_free(c);
     wn_f32_free(c);
     auto fr = [](PackedW& w) { if (w.dev) hipFree(w.dev); if (w.dev_segs) hipFree(w.dev_segs); w.dev = nullptr; w.dev_segs = nullptr; };

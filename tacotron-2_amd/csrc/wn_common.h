@@ -178,9 +178,10 @@ struct wn_ctx {
     int64_t bucket_off[WN_MAX_BUCKETS + 2] = {}, bucket_cnt[WN_MAX_BUCKETS + 2] = {}; bool have_bwd = false;
     bool inference = false;               // cfg.inference_only: no training workspace, synthesis state pre-sized at wn_create
     float* noise_buf = nullptr; size_t noise_bytes = 0;      // device-drawn sampling noise [T][B][nps] (wn_synthesize with noise == NULL)
-    int synth_path = 0;                   // 0 none, 1 graph, 2 pipeline (wn_synth_last_path)
+    int synth_path = 0;                   // 0 none, 1 graph, 2 pipeline, 3 fp32 graph (wn_synth_last_path)
     // synthesis state (lazy)
     struct Synth* synth = nullptr;
+    void* synth32 = nullptr;              // fp32 synthesis state (wn_synth_f32.hip; cfg.compute_dtype = WN_COMPUTE_F32)
     void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)
     void* f32 = nullptr;                  // fp32-forward state (wn_f32.hip), allocated on the first forward of a cfg.compute_dtype = WN_COMPUTE_F32 context
     bool fwd_was_f32 = false;
@@ -206,6 +207,10 @@ int wn_optim_impl(wn_ctx* ctx, float* p, const float* g, float* m, float* v, flo
 int wn_synth_impl(wn_ctx* ctx, const float* c, int B, int Tc, const float* noise, uint64_t seed,
                   const void* test_inputs, void* out_samples, float* out_raw, int steps_per_graph, hipStream_t st);
 void wn_synth_free(wn_ctx* ctx);
+void wn_synth_f32_free(wn_ctx* ctx);
+int wn_synth_f32_reserve(wn_ctx* ctx, int B);
+int wn_synth_f32_impl(wn_ctx* ctx, const float* c, int B, int Tc, const float* noise, const void* test_inputs,
+                      void* out_samples, float* out_raw, int steps_per_graph, hipStream_t st);      // fp32 weights / queues / accumulation
 void wn_pipe_free(wn_ctx* ctx);
 bool wn_pipe_eligible(const wn_ctx* ctx, int B);
 int wn_pipe_reserve(wn_ctx* ctx, int B, int T);            // size every pipeline buffer for (B, T) (no-op when already large enough)

@@ -310,6 +310,8 @@ int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise
     if ((int64_t)B * T > c->NT) WN_FAIL(c, WN_E_SHAPE, "synthesis B*T = %d*%d exceeds the workspace (max_batch*max_time = %lld)", B, T, (long long)c->NT);
     if (c->gin > 0 && (!c->have_g || c->gB != B))
         WN_FAIL(c, WN_E_STATE, "global conditioning is enabled: call wn_set_global_condition with this batch (B=%d) first [wavenet.py:766-777]", B);
+    // the reference's own arithmetic (fp32 weights, queues, accumulation): its own launch-per-layer path, never the bf16 pipeline
+    if (c->cfg.compute_dtype == WN_COMPUTE_F32) return wn_synth_f32_impl(c, cin, B, Tc, noise, test_inputs, out_samples, out_raw, steps_per_graph, caller_st);
     {   // steps_per_graph <= 0 selects the persistent dataflow pipeline (wn_synth_pipe.hip) when the model fits it;
         // WN_SYNTH_MODE=graph|pipe overrides
         const char* m = getenv("WN_SYNTH_MODE");

@@ -85,7 +85,8 @@ MI355 = dict(
     mi355_grad_buckets=3,          # data-parallel training: pieces of the flat gradient that are all-reduced while the backward is still running
     mi355_synthesize_with_ema=False,   # Synthesizer.load: pack the EMA shadow weights instead of the raw ones
     mi355_compute_dtype='bf16',     # 'bf16': bf16 MFMA operands, fp32 accumulation (the tuned path); 'fp32': the reference's own fp32 arithmetic for the
-                                     # forward, loss AND backward (csrc/wn_f32.hip; ~13x slower: validation of a run against the reference's numerics)
+                                     # forward, loss AND backward (csrc/wn_f32.hip; ~13x slower: validation of a run against the reference's numerics) and
+                                     # for synthesis (csrc/wn_synth_f32.hip: fp32 weights and queues like WaveNet.incremental; far from real time)
 )
 
 

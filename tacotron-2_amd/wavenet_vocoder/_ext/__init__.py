@@ -336,7 +336,7 @@ class Engine:
 
     @property
     def synth_path(self):
-        return {0: None, 1: 'graph', 2: 'pipeline'}.get(int(self.lib.wn_synth_last_path(self.h)))
+        return {0: None, 1: 'graph', 2: 'pipeline', 3: 'graph-fp32'}.get(int(self.lib.wn_synth_last_path(self.h)))
 
     def loss(self, y_hat, y, lengths, shift, loss_out):
         B, T = int(y_hat.shape[0]), int(y_hat.shape[-1])

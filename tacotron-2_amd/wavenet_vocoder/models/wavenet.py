@@ -279,12 +279,16 @@ class WaveNet(object):
             gt = torch.as_tensor(g, device=self.device).reshape(B, -1)
 
         def run(spg_):
-            # The persistent pipeline (real time at 22.05 kHz) pipelines up to 8 streams per run through its layer ring at the wall time
-            # of one; larger batches go through it in groups of 8 (streams are independent: wavenet.py:237-239 splits them over towers).
-            # Models the pipeline does not fit (wn_synth_pipe_eligible) take the launch-per-layer graph path, whose time per step is
-            # nearly independent of the batch: the whole batch in one run.
-            piped = spg_ <= 0 and self.engine.pipeline_eligible(min(B, 8))
-            group = 8 if piped else min(B, 32)          # wn_synthesize takes at most 32 streams per run on the graph path too
+            # The persistent pipeline pipelines the streams of a run through its layer ring: up to ~17 streams at the wall time of one
+            # (35-37 us per sample: real time at 22.05 kHz), beyond that the head CU paces the ring at ~2 us per stream and sample -- still
+            # one run of 20 streams (hparams.py: wavenet_synthesis_batch_size = 20) in ~1.1x the wall time of 8, where three groups of 8
+            # took 3x.  So: the whole batch in ONE run when its per-stream LDS state fits (wn_synth_pipe_eligible), else groups of 8
+            # (streams are independent: wavenet.py:237-239 splits them over towers).  Models the pipeline does not fit take the
+            # launch-per-layer graph path, whose time per step is nearly independent of the batch: up to 32 streams per run.
+            group = min(B, 32)
+            piped = spg_ <= 0 and self.engine.pipeline_eligible(group)
+            if spg_ <= 0 and not piped and self.engine.pipeline_eligible(min(B, 8)):
+                piped, group = True, 8
             for b0 in range(0, B, group):
                 b1 = min(B, b0 + group)
                 nz = None if noise is None else noise[:, b0:b1].contiguous()

@@ -251,7 +251,7 @@ def test_pipe_global_conditioning_matches_oracle(kw):
 
 def test_pipeline_timeout_falls_back_to_the_graph_path(monkeypatch):
     """A pipeline hand-off timeout (simulated: WN_PIPE_TEST_ABORT raises the device flag of the first run, as a non-resident workgroup
-    would) is reported by synth_check even when later runs of the same batch succeeded (sticky flag: 12 streams = groups of 8 + 4),
+    would) is reported by synth_check even when later runs on the context succeeded (sticky flag: two runs of 8 + 4 streams),
     and WaveNet.incremental(check=True) re-runs the batch ONCE on the launch-per-layer path: same samples as a clean graph-path run."""
     from wavenet_vocoder import _ext
     from wavenet_vocoder.models.wavenet import WaveNet
