@@ -283,7 +283,6 @@ extern "C" void wn_destroy(wn_ctx* c) {
     for (int p = 0; p < WN_MAX_PARTS; ++p) for (int k = 0; k < WN_MAX_BUCKETS; ++k) if (c->ev_chain[p][k]) hipEventDestroy(c->ev_chain[p][k]);
     for (int p = 0; p < WN_MAX_PARTS; ++p) if (c->ev_head[p]) hipEventDestroy(c->ev_head[p]);
     for (int k = 0; k < WN_MAX_BUCKETS + 2; ++k) if (c->ev_bucket[k]) hipEventDestroy(c->ev_bucket[k]);
-    for (int k = 0; k < 2; ++k) for (hipEvent_t e : c->ev_ls[k]) hipEventDestroy(e);
     if (c->ev_w0) hipEventDestroy(c->ev_w0);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);

@@ -172,7 +172,6 @@ struct wn_ctx {
     // the serial backward chain; ev_bucket[k] = bucket k of the flat gradient is final (index WN_MAX_BUCKETS: the whole buffer)
 #define WN_MAX_BUCKETS 8
     hipStream_t st3 = nullptr; hipEvent_t ev_chain[WN_MAX_PARTS][WN_MAX_BUCKETS] = {}; hipEvent_t ev_bucket[WN_MAX_BUCKETS + 2] = {}; hipEvent_t ev_w0 = nullptr;
-    std::vector<hipEvent_t> ev_ls[2];      // lockstep schedule: the MFMA-bound launch of (part, layer) is done
     hipEvent_t ev_head[WN_MAX_PARTS] = {};   // d pre1 of a batch part exists (the head weight gradients may start under the chain)
     int nbuckets = 0, nbuckets_early = 0, nearly_live = 0; int bucket_lo[WN_MAX_BUCKETS + 2] = {}, bucket_hi[WN_MAX_BUCKETS + 2] = {};
     int64_t bucket_off[WN_MAX_BUCKETS + 2] = {}, bucket_cnt[WN_MAX_BUCKETS + 2] = {}; bool have_bwd = false;
@@ -226,6 +225,17 @@ int wn_weightnorm_apply(wn_ctx* ctx, const float* raw_params, hipStream_t st);  
 int wn_weightnorm_grad(wn_ctx* ctx, float* raw_grads, hipStream_t st);             // deff (effective grads) -> raw grads
 int wn_gbias_fwd(wn_ctx* ctx, int B, hipStream_t st);                 // global-conditioning bias table of this batch
 void wn_devtrace_poll(wn_ctx* c, hipStream_t st, bool step_start);
+// Device timeline of the kernels that carry no in-kernel stamps (upsample net, input convolution, loss, column sums, optimiser ...): while
+// a trace is being recorded, a one-thread stamp kernel in front of and behind the group on ITS stream writes the wall clock into the
+// group's slot (start = the stream reached the group, end = its last kernel retired, each +- one dispatch).  Nothing is enqueued otherwise.
+int wn_trace_scope_begin(wn_ctx* c, hipStream_t st, int kind);       // slot or -1
+void wn_trace_scope_end(wn_ctx* c, hipStream_t st, int slot);
+struct WnTraceScope {
+    wn_ctx* c; hipStream_t st; int slot;
+    WnTraceScope(wn_ctx* c_, hipStream_t st_, int kind) : c(c_), st(st_), slot(wn_trace_scope_begin(c_, st_, kind)) {}
+    ~WnTraceScope() { if (slot >= 0) wn_trace_scope_end(c, st, slot); }
+};
+enum { WN_TR_UPSAMPLE_FWD = 201, WN_TR_INPUT_CONV = 202, WN_TR_LOSS = 203, WN_TR_COLSUM = 204, WN_TR_UPSAMPLE_BWD = 205, WN_TR_OPTIMISER = 206, WN_TR_INPUT_CONV_BWD = 207 };
 int wn_gin_bwd(wn_ctx* ctx, float* grads, hipStream_t st, bool have_colsum = false);           // d W_g, d b_g, d embedding
 int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const float* xw, int64_t rows, float* out_b, float* out_w, int slot, hipStream_t st);
 size_t wn_wgrad_partial_need(wn_ctx* ctx);

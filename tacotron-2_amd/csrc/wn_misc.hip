@@ -320,6 +320,7 @@ __global__ __launch_bounds__(1024) void wn_colsum2_reduce(const float* __restric
 // column sums (+ x-weighted column sums) of M [rows][ld] into out_b / out_w (either may be null); `slot` picks one of the two
 // ctx-owned partial regions (launches on different streams may overlap)
 int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const float* xw, int64_t rows, float* out_b, float* out_w, int slot, hipStream_t st) {
+    WnTraceScope trace_scope(c, st, WN_TR_COLSUM);
     if (ncols % 8 || ncols > 1024 || 256 / (ncols / 8) * ncols > 2048) WN_FAIL(c, WN_E_SHAPE, "wn_colsum2: %d columns", ncols);
     const int rpb = (int)std::max<int64_t>(64, (rows + WN_CS_MAXBLK - 1) / WN_CS_MAXBLK);
     const int nblk = cdiv(rows, rpb);
@@ -331,6 +332,7 @@ int wn_colsum2(wn_ctx* c, const bf16_t* M, int ld, int ncols, int nvalid, const 
 }
 
 int wn_first_conv(wn_ctx* c, hipStream_t st) {
+    WnTraceScope trace_scope(c, st, WN_TR_INPUT_CONV);
     const int64_t rows = (int64_t)c->fB * c->fT;
     const int is_ids = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE;
     uint32_t klo = 0, khi = 0; wn_layer_key(c->fseed, 0, &klo, &khi);
@@ -342,6 +344,7 @@ int wn_first_conv(wn_ctx* c, hipStream_t st) {
     return WN_OK;
 }
 int wn_first_conv_grad(wn_ctx* c, const bf16_t* g0, float* grads, hipStream_t st) {
+    WnTraceScope trace_scope(c, st, WN_TR_INPUT_CONV_BWD);
     const int64_t rows = (int64_t)c->fB * c->fT;
     const int is_ids = c->cfg.input_type == WN_INPUT_MULAW_QUANTIZE;
     if (is_ids) {
@@ -715,6 +718,7 @@ static int up_type_code(const wn_ctx* c) {
 
 // c_in [B,C,Tc] fp32 -> CUP[i] (fp32 per level), cbt (bf16 time-major)
 int wn_upsample_fwd(wn_ctx* c, const float*, const float* cin, int B, int Tc, hipStream_t st) {
+    WnTraceScope trace_scope(c, st, WN_TR_UPSAMPLE_FWD);
     const int type = up_type_code(c);
     const int C = c->C;
     if (type == 0) {
@@ -744,6 +748,7 @@ int wn_upsample_fwd(wn_ctx* c, const float*, const float* cin, int B, int Tc, hi
 
 // dc_final [B,C,T] fp32 (d loss / d upsampled conditioning) -> grads of the upsample kernels/biases
 int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t st) {
+    WnTraceScope trace_scope(c, st, WN_TR_UPSAMPLE_BWD);
     const int type = up_type_code(c);
     if (type == 0) return WN_OK;               // no parameters
     const int C = c->C, B = c->fB;
@@ -1192,6 +1197,7 @@ int wn_loss_run(wn_ctx* c, const float* yhat, const void* y, const int32_t* leng
     return WN_OK;
 }
 int wn_loss_fwd_bwd(wn_ctx* c, float* loss_out, hipStream_t st) {
+    WnTraceScope trace_scope(c, st, WN_TR_LOSS);
     return wn_loss_run(c, c->YHAT, c->fy, c->flen, c->fB, c->fT, 1, loss_out, st);
 }
 extern "C" int wn_loss(wn_ctx* c, const float* y_hat, const void* y, const int32_t* lengths, int32_t B, int32_t T, int32_t shift, float* loss_out, void* stream) {
@@ -1277,6 +1283,8 @@ int wn_optim_impl(wn_ctx* c, float* p, const float* g, float* m, float* v, float
     const wn_config& h = c->cfg;
     const int nt = (int)c->raw_tensors.size();
     const int64_t n = c->n_raw;
+    struct TraceDone { wn_ctx* c; ~TraceDone() { if (c->trace_state == 3) c->trace_state = 2; } } trace_done{c};      // (destroyed AFTER trace_scope: the end stamp is enqueued first)
+    WnTraceScope trace_scope(c, st, WN_TR_OPTIMISER);
     if (h.clip_gradients) {
         hipLaunchKernelGGL(wn_norm2_span_kernel, dim3(cdiv(c->norm_nspans, 4)), dim3(256), 0, st, g, c->norm_spans_dev, c->norm_nspans, c->norm_part_dev);
         hipLaunchKernelGGL(wn_norm2_tensor_kernel, dim3(cdiv(nt, 4)), dim3(256), 0, st, c->norm_part_dev, c->norm_first_dev, nt, c->norm2_dev);

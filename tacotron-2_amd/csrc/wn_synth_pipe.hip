@@ -641,7 +641,7 @@ static int pipe_build(wn_ctx* c, Pipe* p) {
     p->slices_bytes = p->head_slice_off + al(a.head_lds_static);
     WN_HIP(c, hipMalloc((void**)&p->slices, p->slices_bytes));
     WN_HIP(c, hipMemset(p->slices, 0, p->slices_bytes));
-    p->layer_lds = a.layer_lds_static + (R * 2 + R * 4 + 16 * R + 8 * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256 * 16 + 64);
+    p->layer_lds = a.layer_lds_static + (R * 2 + R * 4 + 16 * R + 8 * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 64);      // + 256 B of z_past per stream, added at launch
     p->head_lds = a.head_lds_static + (16 * (S + 4) + S * 4 + OP * 4 + (R + 16) * 2 + 64);
 
     std::vector<SliceJob> jobs; std::vector<int> b0; int nblocks = 0;
@@ -805,7 +805,7 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         WN_HIP(c, hipMemsetAsync(trace_dev, 0, (size_t)trace_n * 2 * (L + 2) * 8, st));
         a.trace = trace_dev; a.trace_t0 = 500; a.trace_n = trace_n;
     }
-    const int lds_bytes = std::max(p->layer_lds, p->head_lds);
+    const int lds_bytes = std::max(p->layer_lds + 256 * B, p->head_lds);      // z_past [B][64] fp32 per layer CU (wn_pipe_eligible checked that it fits)
     WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(wn_synth_pipe_kernel, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     WN_LAUNCH_CHECK(c);

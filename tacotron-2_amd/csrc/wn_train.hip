@@ -44,10 +44,20 @@ static bool devtrace_begin(wn_ctx* c, hipStream_t st) {
     c->trace_n = 0; c->trace_state = 1;
     return true;
 }
+__global__ void wn_stamp_kernel(unsigned long long* p) { *p = (unsigned long long)wall_clock64(); }
+int wn_trace_scope_begin(wn_ctx* c, hipStream_t st, int kind) {
+    if ((c->trace_state != 1 && c->trace_state != 3) || c->trace_n >= WN_TRACE_MAX) return -1;
+    const int slot = c->trace_n++;
+    c->trace_tag[slot].epi = kind; c->trace_tag[slot].st = (void*)st; c->trace_tag[slot].rows = 0;
+    hipLaunchKernelGGL(wn_stamp_kernel, dim3(1), dim3(1), 0, st, c->trace_dev + 2 * slot);
+    return slot;
+}
+void wn_trace_scope_end(wn_ctx* c, hipStream_t st, int slot) { hipLaunchKernelGGL(wn_stamp_kernel, dim3(1), dim3(1), 0, st, c->trace_dev + 2 * slot + 1); }
 void wn_devtrace_poll(wn_ctx* c, hipStream_t st, bool step_start) {
     static const char* path = getenv("WN_DEVTRACE");
     static const int at = [] { const char* e = getenv("WN_DEVTRACE_STEP"); return e ? atoi(e) : 8; }();
-    if (!step_start) { if (c->trace_state == 1) c->trace_state = 2; return; }
+    if (!step_start) { if (c->trace_state == 1) c->trace_state = 3; return; }      // 3: the step's optimiser may still add its group (wn_optim_impl), then 2
+    if (c->trace_state == 3) c->trace_state = 2;                                     // (no optimiser step followed: complete as it is)
     ++c->trace_calls;
     if (c->trace_arm_at && c->trace_calls == c->trace_arm_at) { c->trace_arm_at = 0; devtrace_begin(c, st); return; }
     if (!path) return;
@@ -75,6 +85,7 @@ extern "C" int wn_trace_arm(wn_ctx* c, int32_t steps_from_now) {
 }
 extern "C" int wn_trace_read(wn_ctx* c, int32_t cap, int32_t* kind, uint64_t* stream, uint64_t* start_ticks, uint64_t* end_ticks) {
     if (!c || cap < 0 || !kind || !stream || !start_ticks || !end_ticks) return WN_E_ARG;
+    if (c->trace_state == 3) c->trace_state = 2;
     if (c->trace_state != 2) return 0;
     WN_HIP(c, hipDeviceSynchronize());
     std::vector<unsigned long long> h(2 * (size_t)WN_TRACE_MAX);
@@ -381,103 +392,11 @@ static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
     return fwd_tail(c, b0, nb, st);
 }
 
-// ---- lockstep schedule of the two half-batches (A/B switch WN_LOCKSTEP=1; OFF by default: measured slower) ----------------------------
-// Two independent streams drift into phase: both run their MFMA-bound launch (gate / d x) at the same time and then both their
-// HBM-bound one (out conv / d z), so that for half of the step ONE kernel has the GPU (rocprofv3: 5.7 of 10.9 ms with a single kernel in
-// flight) and neither resource is covered while the other is the limit.  Here the MFMA-bound launches of the two halves form ONE
-// alternating chain -- gate_A(l) -> gate_B(l) -> gate_A(l + 1) ... each waiting for the previous one's event -- and every HBM-bound launch
-// sits between two of its own stream's chain links, i.e. beside the OTHER half's MFMA-bound launch: out_A(l) || gate_B(l),
-// out_B(l) || gate_A(l + 1).  Same kernels, same arguments, same results; only cross-stream events are added.
-// MEASURED (profiles/r4d_ab_lockstep.txt, r4d_timeline_lockstep.txt): 11.6 vs 10.06 ms/step.  The pairing works -- a half-batch gate
-// launch runs 58-65 us beside the other half's out conv, 28 % of MFMA peak instead of 23 % -- but every cross-stream event costs
-// ~15-24 us between the signalling kernel's end and the waiting kernel's start (96 of them per pass: 98 idle gaps, 0.93 ms, GPU busy
-// 92 % instead of 98.7 %).  Kept as a switch; the same pairing without the event latency needs both launches in ONE grid.
-static bool lockstep_on() {
-    static const int v = [] { const char* e = getenv("WN_LOCKSTEP"); return e ? atoi(e) : 0; }();
-    return v != 0;
-}
-static int lockstep_events(wn_ctx* c) {
-    while ((int)c->ev_ls[0].size() < c->L)
-        for (int k = 0; k < 2; ++k) { hipEvent_t e; WN_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_ls[k].push_back(e); }
-    return WN_OK;
-}
-// ---- fused-pair schedule (A/B switch WN_FUSED=1; OFF by default: measured slower) ----------------------------------------------------
-// ONE stream, one grid per pair (wn_fused_pair_kernel): gate_A(0);  then per layer  [out_A(l) | gate_B(l)]  and  [gate_A(l + 1) | out_B(l)].
-// Every launch holds the MFMA-bound kernel of one half and the HBM-bound kernel of the other; the pairing is the lockstep one, without
-// events.  Same kernel bodies, same arguments => the same results as the two-stream schedule (57 parity tests green with it on).
-// MEASURED (profiles/r4e_ab_fused.txt, r4e_timeline_fused.txt): 11.2 vs 9.9 ms/step.  A fused [gate | out conv] grid takes 65-69 us and a
-// [d x | d z] grid 71-79 us -- less than the two kernels one after the other (94 / 98 us) but every grid drains completely before the next
-// one starts, so the serial chain pays 94 launch tails per pass; two free-running streams hide each kernel's tail under the other
-// stream's next launch and come out ahead (157 us per layer and direction for both halves).  C5 width: 44.2 vs 41.9 ms.
-static bool fused_ok(wn_ctx* c) {
-    static const int v = [] { const char* e = getenv("WN_FUSED"); return e ? atoi(e) : 0; }();
-    if (!v || c->fB < 2 || !c->zero_page) return false;
-    for (int l = 0; l < c->L; ++l) {
-        const WnLayerPacks& p = c->packs[l];
-        if (!p.w1.kil || !p.w1T.kil || p.w1.M % 256 || p.wo.M % 256 || p.w2T.M % 256 || p.w1T.M % 256) return false;
-        if (p.w1.M_valid != p.w1.M || p.wo.M_valid != p.wo.M || p.w2T.M_valid != p.w2T.M || p.w1T.M_valid != p.w1T.M) return false;
-    }
-    return true;
-}
-static int fwd_fused(wn_ctx* c, hipStream_t st) {
-    int rc;
-    if ((rc = parts_setup(c, 2))) return rc;
-    c->parts = 2;
-    const int L = c->L, bA = c->fB / 2, nA = bA, nB = c->fB - bA;      // half A: utterances [0, bA), half B: [bA, fB)
-    c->prof_rows = nA * c->fT;
-    if ((rc = fwd_gate(c, 0, 0, nA, st, c->prof))) return rc;
-    for (int l = 0; l < L; ++l) {
-        {   // [out_A(l) | gate_B(l)]
-            GemmArgs g; mk_gate(c, l, bA, nB, g);
-            if (l + 1 < L) {
-                GemmArgs o; mk_out(c, l, 0, nA, o);
-                if ((rc = wn_launch_fused_pair<EPI_GATE, EPI_STORE_BF16>(c, g, c->packs[l].w1.M, o, c->packs[l].wo.M, st))) return rc;
-            } else if ((rc = wn_launch_gemm<EPI_GATE>(c, g, c->packs[l].w1.M, st))) return rc;
-        }
-        if (l + 1 < L) {   // [gate_A(l + 1) | out_B(l)]
-            GemmArgs g; mk_gate(c, l + 1, 0, nA, g);
-            GemmArgs o; mk_out(c, l, bA, nB, o);
-            if (c->prof) prof_gate(c, g, st);
-            rc = wn_launch_fused_pair<EPI_GATE, EPI_STORE_BF16>(c, g, c->packs[l + 1].w1.M, o, c->packs[l].wo.M, st);
-            if (c->prof) prof_mark(c, st);
-            if (rc) return rc;
-        }
-    }
-    // skip sum + head: HBM-bound launches of the two halves, side by side on the two streams as before
-    WN_HIP(c, hipEventRecord(c->ev_fork, st));
-    WN_HIP(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
-    if ((rc = fwd_tail(c, bA, nB, c->st2))) return rc;
-    WN_HIP(c, hipEventRecord(c->ev_pjoin[1], c->st2));
-    if ((rc = fwd_tail(c, 0, nA, st))) return rc;
-    WN_HIP(c, hipStreamWaitEvent(st, c->ev_pjoin[1], 0));
-    return WN_OK;
-}
-static int fwd_lockstep(wn_ctx* c, hipStream_t st) {
-    int rc;
-    if ((rc = parts_setup(c, 2))) return rc;
-    if ((rc = lockstep_events(c))) return rc;
-    c->parts = 2;
-    hipStream_t sA = st, sB = c->st2;
-    const int bA = c->fB / 2, nA = bA, nB = c->fB - bA;      // part 0: [0, bA) on the caller's stream, part 1: [bA, fB) on the ctx-owned one
-    c->prof_rows = nA * c->fT;
-    WN_HIP(c, hipEventRecord(c->ev_fork, st));
-    WN_HIP(c, hipStreamWaitEvent(sB, c->ev_fork, 0));
-    for (int l = 0; l < c->L; ++l) {
-        if (l > 0) WN_HIP(c, hipStreamWaitEvent(sA, c->ev_ls[1][l - 1], 0));
-        if ((rc = fwd_gate(c, l, 0, nA, sA, c->prof))) return rc;
-        WN_HIP(c, hipEventRecord(c->ev_ls[0][l], sA));
-        if ((rc = fwd_out(c, l, 0, nA, sA))) return rc;
-        WN_HIP(c, hipStreamWaitEvent(sB, c->ev_ls[0][l], 0));
-        if ((rc = fwd_gate(c, l, bA, nB, sB, false))) return rc;
-        WN_HIP(c, hipEventRecord(c->ev_ls[1][l], sB));
-        if ((rc = fwd_out(c, l, bA, nB, sB))) return rc;
-    }
-    if ((rc = fwd_tail(c, 0, nA, sA))) return rc;
-    if ((rc = fwd_tail(c, bA, nB, sB))) return rc;
-    WN_HIP(c, hipEventRecord(c->ev_pjoin[1], sB));
-    WN_HIP(c, hipStreamWaitEvent(st, c->ev_pjoin[1], 0));
-    return WN_OK;
-}
+// Two ways of FORCING the complementary pairing of the two half-batches (MFMA-bound gate / d x of one beside HBM-bound out conv / d z of
+// the other) were built and measured in round 3 and are gone from the library: a lockstep chain through cross-stream events (every event
+// costs 15-24 us between the signalling kernel's end and the waiting kernel's start: 11.6 vs 10.06 ms/step, profiles/r4d_ab_lockstep.txt)
+// and both launches in ONE grid (wn_fused_pair_kernel, tools/wn_tile_variants.h: every grid drains before the next starts, 11.2 vs
+// 9.9 ms/step, profiles/r4e_ab_fused.txt).  Two free-running streams hide each kernel's tail under the other stream's next launch.
 
 // run f(b0, nb, stream, is_first_part) for every batch part: part 0 on the caller's stream, part 1 on the ctx-owned one, both
 // ordered after everything already enqueued on `st`, and `st` ordered after both when this returns
@@ -519,9 +438,7 @@ int wn_fwd_impl(wn_ctx* c, hipStream_t st, float* loss_out, float* y_hat_out) {
         c->have_loss = loss_out != nullptr;
         return WN_OK;
     }
-    if (n_parts(c) == 2 && fused_ok(c)) rc = fwd_fused(c, st);
-    else if (n_parts(c) == 2 && lockstep_on()) rc = fwd_lockstep(c, st);
-    else rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first, int) {
+    rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool first, int) {
         if (first) c->prof_rows = nb * c->fT;      // rows of one timed gate-GEMM launch (wn_profile_result)
         return fwd_part(c, b0, nb, s, c->prof && first);
     });
@@ -608,62 +525,6 @@ static int bwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
     }
     return WN_OK;
 }
-// fused-pair backward (see fwd_fused): dz_A(L-1);  then per layer, top first,  [dx_A(l) | dz_B(l)]  and  [dx_B(l) | dz_A(l - 1)]
-static int bwd_fused(wn_ctx* c, hipStream_t st) {
-    int rc;
-    if ((rc = parts_setup(c, 2))) return rc;
-    c->parts = 2;
-    const int L = c->L, bA = c->fB / 2, nA = bA, nB = c->fB - bA;
-    // head gradients of the two halves: small launches, one after the other on this stream
-    if ((rc = bwd_head(c, 0, nA, st, 0))) return rc;
-    if ((rc = bwd_head(c, bA, nB, st, 1))) return rc;
-    if ((rc = bwd_dgate(c, L - 1, 0, nA, st))) return rc;
-    for (int l = L - 1; l >= 0; --l) {
-        {   // [dx_A(l) | dz_B(l)]
-            GemmArgs x; mk_dx(c, l, 0, nA, x);
-            GemmArgs z; mk_dgate(c, l, bA, nB, z);
-            if ((rc = wn_launch_fused_pair<EPI_DX, EPI_DGATE>(c, x, c->packs[l].w1T.M, z, c->packs[l].w2T.M, st))) return rc;
-        }
-        {   // [dx_B(l) | dz_A(l - 1)]
-            GemmArgs x; mk_dx(c, l, bA, nB, x);
-            if (l > 0) {
-                GemmArgs z; mk_dgate(c, l - 1, 0, nA, z);
-                if ((rc = wn_launch_fused_pair<EPI_DX, EPI_DGATE>(c, x, c->packs[l].w1T.M, z, c->packs[l - 1].w2T.M, st))) return rc;
-            } else if ((rc = wn_launch_gemm<EPI_DX>(c, x, c->packs[l].w1T.M, st))) return rc;
-        }
-        if ((rc = chain_events(c, l, 0, st))) return rc;
-        if ((rc = chain_events(c, l, 1, st))) return rc;
-    }
-    return WN_OK;
-}
-// lockstep backward (see fwd_lockstep): the d x launches of the two halves form one alternating chain, top layer first --
-// dx_A(l) -> dx_B(l) -> dx_A(l - 1) ... -- and each d z launch runs beside the other half's d x: dz_B(l) || dx_A(l), dz_A(l - 1) || dx_B(l)
-static int bwd_lockstep(wn_ctx* c, hipStream_t st) {
-    int rc;
-    if ((rc = parts_setup(c, 2))) return rc;
-    if ((rc = lockstep_events(c))) return rc;
-    c->parts = 2;
-    hipStream_t sA = st, sB = c->st2;
-    const int bA = c->fB / 2, nA = bA, nB = c->fB - bA;
-    WN_HIP(c, hipEventRecord(c->ev_fork, st));
-    WN_HIP(c, hipStreamWaitEvent(sB, c->ev_fork, 0));
-    if ((rc = bwd_head(c, 0, nA, sA, 0))) return rc;
-    if ((rc = bwd_head(c, bA, nB, sB, 1))) return rc;
-    for (int l = c->L - 1; l >= 0; --l) {
-        if ((rc = bwd_dgate(c, l, 0, nA, sA))) return rc;
-        if (l < c->L - 1) WN_HIP(c, hipStreamWaitEvent(sA, c->ev_ls[1][l + 1], 0));
-        if ((rc = bwd_dx(c, l, 0, nA, sA, 0))) return rc;
-        WN_HIP(c, hipEventRecord(c->ev_ls[0][l], sA));
-        if ((rc = bwd_dgate(c, l, bA, nB, sB))) return rc;
-        WN_HIP(c, hipStreamWaitEvent(sB, c->ev_ls[0][l], 0));
-        if ((rc = bwd_dx(c, l, bA, nB, sB, 1))) return rc;
-        WN_HIP(c, hipEventRecord(c->ev_ls[1][l], sB));
-    }
-    WN_HIP(c, hipEventRecord(c->ev_pjoin[1], sB));
-    WN_HIP(c, hipStreamWaitEvent(st, c->ev_pjoin[1], 0));
-    return WN_OK;
-}
-
 static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st);
 int wn_bwd_impl(wn_ctx* c, float* grads, hipStream_t st) {
     if (!c->wnorm) return wn_bwd_eff(c, grads, st);
@@ -814,9 +675,7 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
         if ((rc = launch_wgrad(c, w, wst))) return rc;
     }
     // ---- the serial chain, per batch part (two streams)
-    if (n_parts(c) == 2 && fused_ok(c) && !serial) { if ((rc = bwd_fused(c, st))) return rc; }
-    else if (n_parts(c) == 2 && lockstep_on() && !serial) { if ((rc = bwd_lockstep(c, st))) return rc; }
-    else if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;
+    if ((rc = for_each_part(c, st, [&](int b0, int nb, hipStream_t s, bool, int part) { return bwd_part(c, b0, nb, s, part); }))) return rc;
     // ---- head weight gradients over the whole batch (wavenet.py:136-149): d final_convolution_1 = R1^T dpre1 needs d pre1 of every
     // part, the first thing each chain stream computes (enqueued after the chain in host order, gated only by those events)
     for (int pk = 0; pk < c->parts; ++pk) WN_HIP(c, hipStreamWaitEvent(wst, c->ev_head[pk], 0));

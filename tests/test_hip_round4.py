@@ -206,8 +206,12 @@ def test_pipe_whole_batch_in_one_run(B):
 
 
 def test_pipe_c4_at_the_benched_batch_8x110275():
-    """What bench.py's synthesis leg times -- 8 streams x 110 275 steps (5.0 s at 22.05 kHz) on the persistent pipeline -- compared with
-    the oracle stream by stream (batch forward on the shifted input, bf16-emulating like the one-stream test), flat over the 5 s."""
+    """What bench.py's synthesis leg times -- 8 streams x 110 275 steps (5.0 s at 22.05 kHz) on the persistent pipeline -- against the
+    oracle, EVERY stream, on the FINAL second of audio: by then every ring has wrapped 13 times and any drift over the 5 s would show.
+    The oracle's batch forward (bf16-emulating, like the one-stream full-length test) runs on the window [T - 22 055 - receptive field, T):
+    its outputs are exact from one receptive field in.  (All 8 streams over the full 5 s: profiles/r5a_parity_c4_b8_full.json, 9.74e-3 ..
+    9.83e-3 per stream, worst second 9.86e-3 -- 230 s of oracle time, too long for the routine suite; one stream over the full length is
+    test_c4_full_length_one_stream_vs_oracle.)"""
     from test_hip_synth import _setup
     PAPER_FULL = dict(PAPER, wavenet_dropout=0.0)
     B, Tc = 8, 401
@@ -221,21 +225,24 @@ def test_pipe_c4_at_the_benched_batch_8x110275():
     dt = time.time() - t0
     assert eng.synth_path == 'pipeline'
     raw = raw.cpu()
-    per, worst_seg = [], 0.0
+    RF = eng.receptive_field
+    sec = 22055
+    fr0 = (T - sec - RF) // cfg.hop                    # first conditioning frame of the window (hop-aligned: the upsample net is per frame)
+    w0 = fr0 * cfg.hop
+    per = []
     t1 = time.time()
     with torch.no_grad():
         for b in range(B):
-            xs = torch.cat([torch.zeros(1, 1), wav[b:b + 1, :-1]], 1).view(1, 1, T)
-            r_em = O.step(params, cfg, xs, c[b:b + 1], emulate_bf16=True)[0]
-            per.append(rel_err(raw[b], r_em))
-            worst_seg = max([worst_seg] + [rel_err(raw[b, :, a:a + 22055], r_em[:, a:a + 22055]) for a in range(0, T, 22055)])
-    rec = {'B': B, 'T': T, 'wall_s_device': dt, 'rtf_per_stream': dt / (T / 22050.0), 'rel_l2_per_stream': per, 'worst_second': worst_seg, 'oracle_seconds': time.time() - t1}
-    print('\npipe C4 at the benched batch (8 x 110 275): per stream %s; worst second of audio %.2e; device %.2f s (RTF %.2f), oracle %.0f s'
-          % (' '.join('%.2e' % e for e in per), worst_seg, dt, rec['rtf_per_stream'], rec['oracle_seconds']))
+            xs = torch.cat([torch.zeros(1, 1), wav[b:b + 1, :-1]], 1)[:, w0:].reshape(1, 1, T - w0)
+            r_em = O.step(params, cfg, xs, c[b:b + 1, :, fr0:], emulate_bf16=True)[0]
+            per.append(rel_err(raw[b, :, T - sec:], r_em[:, T - sec - w0:]))
+    rec = {'B': B, 'T': T, 'wall_s_device': dt, 'rtf_per_stream': dt / (T / 22050.0), 'rel_l2_final_second_per_stream': per, 'window_start': w0, 'oracle_seconds': time.time() - t1}
+    print('\npipe C4 at the benched batch (8 x 110 275), final second of every stream: %s; device %.2f s (RTF %.2f), oracle %.0f s'
+          % (' '.join('%.2e' % e for e in per), dt, rec['rtf_per_stream'], rec['oracle_seconds']))
     d = os.environ.get('WN_PARITY_REPORT_DIR')
     if d:
-        with open(os.path.join(d, 'parity_c4_b8_full.json'), 'w') as f:
+        with open(os.path.join(d, 'parity_c4_b8_final_second.json'), 'w') as f:
             json.dump(rec, f, indent=1)
-    assert max(per) < 2.5e-2 and worst_seg < 2.5e-2
+    assert max(per) < 2.5e-2
     exp = O.sample_from_discretized_mix_logistic(raw, nz_or['u1'].permute(1, 0, 2), nz_or['u2'].t(), cfg.log_scale_min)
     assert torch.allclose(out.cpu(), exp, atol=2e-5)

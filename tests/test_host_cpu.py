@@ -865,12 +865,13 @@ def test_device_timeline_summary_of_in_kernel_stamps(tmp_path):
             (4, 'b', T0 + 10000, T0 + 11000), (4, 'a', T0 + 10500, T0 + 11500), (3, 'a', T0 + 11500, T0 + 15000), (5, 'a', T0 + 15000, T0 + 20000),
             (3, 'b', T0 + 11000, T0 + 14000), (5, 'b', T0 + 14000, T0 + 19000),                                                           # chain ends at 200 us
             (103, 'c', T0 + 20000, T0 + 29000), (101, 'c', T0 + 29000, T0 + 30000), (2, 'a', T0 + 20000, T0 + 25000),
-            (102, 'c', devtrace.NEVER, 0)]
+            (102, 'c', devtrace.NEVER, 0),
+            (206, 'a', T0 + 30000, T0 + 31000)]                     # kinds >= 200: kernel groups bracketed by stamp kernels (here: the optimiser)
     s = devtrace.summarise(rows)
-    assert s['launches'] == 13 and abs(s['span_us'] - 300.0) < 1e-9
+    assert s['launches'] == 14 and abs(s['span_us'] - 310.0) < 1e-9 and abs(s['after_last_weight_gradient_us'] - 10.0) < 1e-9
     assert abs(s['forward_us'] - 100.0) < 1e-9 and abs(s['backward_chain_us'] - 100.0) < 1e-9 and abs(s['weight_gradient_tail_us'] - 100.0) < 1e-9
-    assert abs(sum(s['in_flight_us'].values()) - 300.0) < 1e-6 and abs(s['in_flight_us']['1'] - (0.1 + 5 + 10 + 40 + 10)) < 1e-6
-    assert [st['launches'] for st in s['streams']] == [6, 5, 2] and s['streams'][1]['first_backward_start_us'] == 100.0
+    assert abs(sum(s['in_flight_us'].values()) - 310.0) < 1e-6 and abs(s['in_flight_us']['1'] - (0.1 + 5 + 10 + 40 + 10 + 10)) < 1e-6
+    assert [st['launches'] for st in s['streams']] == [7, 5, 2] and s['streams'][1]['first_backward_start_us'] == 100.0
     f = tmp_path / 'trace.txt'
     f.write_text('# idx epi stream rows start end\n' + ''.join('%d %d %s 1 %d %d\n' % (i, r[0], r[1], r[2], r[3]) for i, r in enumerate(rows)))
     assert devtrace.summarise(devtrace.parse_file(str(f))) == s

@@ -5,7 +5,9 @@ csrc/wn_train.hip): every tile-engine and grouped weight-gradient launch with {f
    python tools/devtrace.py <file> [--all]"""
 import sys
 
-EPI = {0: 'gate', 1: 'store(out/skip/head)', 2: 'f32(yhat/dc)', 3: 'dgate', 4: 'relumask', 5: 'dx', 101: 'wgrad<1>', 102: 'wgrad<2>', 103: 'wgrad<3>'}
+EPI = {0: 'gate', 1: 'store(out/skip/head)', 2: 'f32(yhat/dc)', 3: 'dgate', 4: 'relumask', 5: 'dx', 101: 'wgrad<1>', 102: 'wgrad<2>', 103: 'wgrad<3>',
+       201: 'upsample net fwd*', 202: 'input conv fwd*', 203: 'loss + d y_hat*', 204: 'column sums*', 205: 'upsample net bwd*', 206: 'clip + Adam + EMA*', 207: 'input conv bwd*'}
+# kinds >= 200 (*): groups of kernels without in-kernel stamps, bracketed by one-thread stamp kernels on their stream (+- one dispatch)
 NEVER = 2 ** 64 - 1
 
 
@@ -31,7 +33,8 @@ def summarise(rows):
     us = lambda t: (t - t0) / 100.0
     first_bwd = min((r[2] for r in rows if r[0] in (3, 4, 5)), default=None)
     last_dx = max((r[3] for r in rows if r[0] == 5), default=None)
-    last_wg = max((r[3] for r in rows if r[0] >= 100), default=None)
+    last_wg = max((r[3] for r in rows if 100 <= r[0] < 200), default=None)
+    last_any = max(r[3] for r in rows)
     pts = sorted([(r[2], 1) for r in rows] + [(r[3], -1) for r in rows])
     depth, last, hist = 0, pts[0][0], {}
     for t, d in pts:
@@ -46,6 +49,7 @@ def summarise(rows):
             'forward_us': us(first_bwd) if first_bwd else None,
             'backward_chain_us': (us(last_dx) - us(first_bwd)) if first_bwd and last_dx else None,
             'weight_gradient_tail_us': (us(last_wg) - us(last_dx)) if last_wg and last_dx else None,
+            'after_last_weight_gradient_us': (us(last_any) - us(last_wg)) if last_wg else None,      # side-stream groups + the optimiser (kinds >= 200)
             'in_flight_us': {str(k): v / 100.0 for k, v in sorted(hist.items())}, 'streams': per_stream}
 
 

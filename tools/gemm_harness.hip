@@ -1,8 +1,8 @@
 // Stand-alone check + timing of the tile-engine main loops (run on the GPU box):
 //   v1 = wn_gemm_tile_kernel (A fragments straight from L2), v2 = wn_gemm_lds_kernel (LDS-DMA ring).
 // Same GemmArgs, same accumulation order => outputs must be BITWISE identical.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc tools/gemm_harness.hip -o tools/gemm_harness
-#include "wn_tile.h"
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc -I tools tools/gemm_harness.hip -o tools/gemm_harness
+#include "wn_tile_variants.h"
 #include <vector>
 #include <random>
 #include <functional>

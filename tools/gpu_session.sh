@@ -6,6 +6,7 @@
 #   tests:<expr> only the tests matching -k <expr>
 #   smoke        __graft_entry__.smoke()
 #   bench        default-flag bench line (what the driver runs) -> bench.json
+#   forcedist    short bench through the one-rank RCCL path (process group, bucketed ReduceOp.AVG exchange, barriers) -> bench_forcedist.json
 #   benchq       short bench (no synth / cpu baseline / other workloads) -> benchq.json
 #   ab:<name>=<ENV=V>[,<ENV=V>]   one A/B arm of the short bench (appends to ab.txt); `ab:base=` for the baseline
 #   kt           rocprofv3 kernel trace + stats of the bench step (live, two streams) -> kernel_stats.csv, timeline.txt
@@ -13,6 +14,7 @@
 #   pmc          FETCH_SIZE and WRITE_SIZE passes -> pmc_fetch.md, pmc_write.md, traffic.json (bench.py loads the committed copy)
 #   sq           SQ counter passes of the bench step -> pmc_sq.md
 #   harness      tools/gemm_harness + ablation + wgrad harness tables
+#   chain        tools/chain_harness: persistent layer-chain prototype vs the two-stream schedule (forward, 6 layers) -> chain_harness.txt
 #   pipetrace    WN_PIPE_TRACE stage trace of the synthesis pipeline (B = 1, 8) -> pipe_trace_b*.txt
 #   other        10-step runs of the other workloads only
 #   devtrace     the engine's own in-kernel stamps of one un-profiled step (WN_DEVTRACE) -> devtrace.txt, devtrace_timeline.txt
@@ -31,6 +33,7 @@ for st in "$@"; do
     tests:*) ( timeout 1200 python -m pytest tests -m gpu -q -s --maxfail=8 -k "${st#tests:}" 2>&1; echo "rc=$?" ) > $OUT/pytest_gpu_k.log; grep -E "passed|failed|error|rc=" $OUT/pytest_gpu_k.log | tail -5 ;;
     smoke) ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ) > $OUT/smoke.log; cat $OUT/smoke.log ;;
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "rc=$?" >> $OUT/bench.err; cut -c1-400 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+    forcedist) GPU_MAX_HW_QUEUES=8 timeout 300 python bench.py --force-dist --steps 40 --warmup 8 $BQ > $OUT/bench_forcedist.json 2> $OUT/bench_forcedist.err; cut -c1-300 $OUT/bench_forcedist.json; grep -i "process group" $OUT/bench_forcedist.err | tail -2 ;;
     benchq) timeout 300 python bench.py --steps 40 --warmup 8 $BQ > $OUT/benchq.json 2> $OUT/benchq.err; cut -c1-300 $OUT/benchq.json ;;
     ab:*) spec=${st#ab:}; name=${spec%%=*}; envs=$(echo "${spec#*=}" | tr ',' ' ')
       ( env $envs timeout 240 python bench.py --steps 40 --warmup 8 $BQ 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', '%.3f ms/step' % d['ms_per_step'], 'gate frac %.3f (incl. wait %.3f)' % (d['roofline']['frac'], d['roofline']['frac_incl_queue_wait']))" ) >> $OUT/ab.txt 2>&1; tail -1 $OUT/ab.txt ;;
@@ -63,6 +66,7 @@ for st in "$@"; do
     harness) cd /tmp
       for h in gemm_harness gemm_harness_ablate wgrad_harness; do [ -x $R/tools/$h ] && timeout 180 $R/tools/$h > $OUT/$h.txt 2>&1; done
       cd $R; tail -40 $OUT/gemm_harness.txt ;;
+    chain) cd /tmp; [ -x $R/tools/chain_harness ] && timeout 240 $R/tools/chain_harness > $OUT/chain_harness.txt 2>&1; cd $R; tail -16 $OUT/chain_harness.txt ;;
     pipetrace) for b in 1 8; do WN_PIPE_TRACE=1 timeout 200 python tools/pipe_trace.py $b > $OUT/pipe_trace_b$b.txt 2>&1; tail -4 $OUT/pipe_trace_b$b.txt; done ;;
     other) timeout 900 python - > $OUT/other_workloads.json 2> $OUT/other.err <<'PY'
 import json, sys, os

@@ -1,3 +1,8 @@
+// HARNESS COPY of the MFMA tile engine (tacotron-2_amd/csrc/wn_tile.h as of round 3) WITH every schedule that was measured and rejected:
+// PIPE 0 / 2 / 3 / 5 / 6 / 7, A-direct (PIPE 8), the fused-pair grid, and the WN_EPI_ABLATE bottleneck probes.  tools/gemm_harness.hip and
+// tools/overlap_harness.hip include THIS file; the library builds from csrc/wn_tile.h, which keeps only what the product launches.
+// The numbers these variants produced are under profiles/ (r2*_gemm_harness*, r4f_*, r4m_gemm_harness_variants.txt, r4e_ab_fused.txt).
+//
 // MFMA tile engine for the dense (training-time) contractions of the WaveNet stack on gfx950.
 //
 // Every dense op of the residual stack is computed in the TRANSPOSED form
@@ -51,6 +56,7 @@ struct GemmArgs {
     int32_t tiles_per_utt, ntiles;
     uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;   // dropout mask spec (row pitch of the dropped tensor)
     const bf16_t* zero;         // >= 16 B of zeros in device memory (source of out-of-range rows for the LDS-DMA kernel)
+    unsigned long long* trace;  // harness-only (WN_EPI_ABLATE builds): per-workgroup s_memtime stamps of the main loop
     unsigned long long* kprof;  // wn_profile: {min over workgroups of the start, max of the end} of THIS launch in 100 MHz wall-clock ticks (null: off)
     int32_t stagger;            // shader cycles the second-resident workgroups of the first round wait before starting (0: off)
     int32_t xcd_span;           // LDS-DMA kernels: > 0 = XCD x owns the contiguous tiles [x * xcd_span, (x + 1) * xcd_span); 0 = tiles interleaved over XCDs
@@ -113,6 +119,17 @@ __device__ __forceinline__ uint4 drop8(uint4 v, uint32_t key_lo, uint32_t key_hi
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void wn_tile_epilogue(const GemmArgs& a, f32x16_t (&acc)[MT][NT], const int mtile0, const int t0w,
                                                  const int b, const int T, const int64_t rowbase, const int lane) {
+#ifdef WN_EPI_ABLATE      // harness-only: measure the main loop alone (accumulators kept live, nothing stored)
+    if (a.e.scale != -7777.0f) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        return;
+    }
+#endif
     const EpiArgs& e = a.e;
     const int h = lane >> 5;
 #pragma unroll
@@ -373,13 +390,30 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_addr) {
 __device__ __forceinline__ void lds_dma16_s(uint64_t sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
+// One MFMA A fragment (lane i's 16 B of a fragment-ordered pack) straight into VGPRs: address = sbase (wave-uniform) + voff + IMM.
+// Inline asm on purpose: a load the compiler knows about makes its waitcnt pass put `s_waitcnt vmcnt(0)` in front of the first use --
+// which also drains every LDS-DMA in flight (they are asm too, so it cannot count them).  The caller waits by hand (counted vmcnt, in
+// order with the DMAs) through wn_wait_frags, which ties the registers to the wait so that no consumer can be scheduled above it.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int IMM>
+__device__ __forceinline__ void gload_frag_s(u32x4_t& dst, uint64_t sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void wn_wait_frags(u32x4_t& f0, u32x4_t& f1) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(VM) : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
 constexpr int lds_gemm_bytes(int MT, int NT, int WM, int WN, int BK, int NBUF) {
     const int ring = NBUF * (WM * MT * 32 + WN * NT * 32) * BK * 2, epi = WN * 32 * (WM * MT * 32 * 4 + 16);
+#ifdef WN_EPI_ABLATE      // harness-only builds time the main loop alone: the epilogue's staging area is never touched
+    return ring;
+#else
     return ring > epi ? ring : epi;
+#endif
 }
 // minimum waves per SIMD for __launch_bounds__: two 8-wave workgroups per CU when LDS allows it
 constexpr int lds_gemm_min_waves(int MT, int NT, int WM, int WN, int BK, int NBUF) {
@@ -407,18 +441,18 @@ struct LdsGemmCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-// The kernel BODY is a device function of (arguments, LDS arena, workgroup id): wn_gemm_lds_kernel is the one-launch wrapper, and a
-// grid that holds the workgroups of several launches (tools/: the fused-pair grid of round 3, the persistent chain prototype) can call it.
-template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE_ = 1, int TAPS = 0>
+// The kernel BODY is a device function of (arguments, LDS arena, workgroup id) so that two different launches can share one grid
+// (wn_fused_pair_kernel below); wn_gemm_lds_kernel is the one-launch wrapper.
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE_ = 0, int TAPS = 0>
 __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const lds, const int wg_id) {
     using Cfg = LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>;
-    // PIPE_ names the main-loop schedule; the product launches schedule 1 only (every fragment of a chunk is requested from LDS right
-    // after the chunk's barrier, the DMAs of chunk + 2 are issued while those reads fly, then the chunk's MFMAs go back to back).  The
-    // schedules that were measured against it and lost -- fragment reads one k-step ahead (2 / 3), half the waves issuing the DMAs (5),
-    // wave halves half a chunk apart (6 / 7), weight fragments straight into VGPRs (8) -- live in tools/wn_tile_variants.h with the
-    // harness; the template parameter stays so that kernel names in profiles/ keep their meaning.
-    static_assert(PIPE_ == 1, "schedule 1 is the only one in the library (tools/wn_tile_variants.h has the others)");
-    static_assert(TAPS == 0 || (TAPS == 3 && NBUF == 3), "interleaved taps: the tap of a chunk is its ring slot (ring depth 3 == 3 taps)");
+    // PIPE_ 8 ("A-direct"): the weight fragments of the K-interleaved taps go from the fragment-ordered pack straight into VGPRs
+    // (global_load_dwordx4, one chunk ahead) instead of through LDS: 1 LDS-DMA per wave and chunk instead of 3, no A ds_reads.  Needs
+    // one m-tile per wave that no other wave shares (MT == 1, WN == 1: 8 x 1 waves of 32 x 128).  Everything else is PIPE 1.
+    constexpr bool ADIRECT = (PIPE_ == 8);
+    constexpr int PIPE = ADIRECT ? 1 : PIPE_;
+    static_assert(!ADIRECT || (TAPS == 3 && NBUF == 3 && MT == 1 && WN == 1 && BK == 32), "A-direct: K-interleaved taps, 8 x 1 waves");
+    static_assert(TAPS == 0 || (TAPS == 3 && NBUF == 3 && (PIPE <= 1 || PIPE >= 6)), "interleaved taps: the tap of a chunk is its ring slot (ring depth 3 == 3 taps)");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -450,6 +484,9 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
     const int t0 = (tile - bl * a.tiles_per_utt) * Cfg::TTILE;
     const int T = a.T;
     const int64_t rowbase = (int64_t)b * T;
+#ifdef WN_EPI_ABLATE
+    const unsigned long long wg_t_start = __builtin_amdgcn_s_memtime();
+#endif
 
     // The accumulators START at the bias of their output channel (gate: b_dil + b_cin + global-conditioning row of this utterance;
     // 1x1 convs: their bias), so the fused epilogues neither load nor add it: 4 x 16-B loads here, under the first DMAs, instead of
@@ -490,6 +527,11 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
 
     const int chunks_per_rep = [&] { int n = 0; for (int s = 0; s < a.nseg; ++s) n += (a.seg[s].nk + BK - 1) / BK; return n; }();
     const int nchunks = chunks_per_rep * a.nrep;
+#ifdef WN_EPI_ABLATE     // harness-only bottleneck probes: stagger < 0 carries flag bits (1: no DMA, 2: no LDS fragment reads, 4: no barrier, 8: DMA sources L2-hot)
+    const int dbg = a.stagger < 0 ? -a.stagger : 0;
+#else
+    constexpr int dbg = 0;
+#endif
 
     // ---- staging iterator (chunk being DMA'd) and compute iterator (chunk being multiplied).  Everything the loop needs
     // from the segment descriptors is kept in registers and refreshed only when the iterator enters a new segment:
@@ -500,8 +542,11 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
     // row shared by two taps = one chunk of the co-resident tiles (a few 100 KiB) instead of a whole segment pass (> L2).
     int t_left = TAPS ? TAPS * (a.seg[0].nk / BK) : 0;
     // per-lane constants of the B image: piece g = wave + p*NW holds rows g*(1024/RB)...; LDS byte lane*16 -> (row, slot)
-    constexpr int NWD = Cfg::NW;                                      // every wave issues its share of the chunk's DMAs
+    // DMA issuers: all waves, or (PIPE 5) only waves [0, NW/2) -- one per SIMD and workgroup -- with twice the pieces each, so
+    // that after every barrier the other wave of the SIMD goes straight to the MFMA pipe while its partner queues on the TA.
+    constexpr int NWD = (PIPE == 5) ? Cfg::NW / 2 : Cfg::NW;
     constexpr int APW = Cfg::A_INSTR / NWD, BPW = Cfg::B_INSTR / NWD;
+    const bool dma_wave = wave < NWD;
     int b_c8[BPW], b_t[BPW], b_off[BPW];
     auto enter_segment = [&]() {          // per-lane element offsets inside the current segment (-1: reads the zero page)
         const int ld = a.seg[s_sg].ld, shift = a.seg[s_sg].shift;       // one s_load per SEGMENT, not per chunk
@@ -509,6 +554,9 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         for (int p = 0; p < BPW; ++p) {
             const int ts = b_t[p] + shift;
             b_off[p] = (b_t[p] < T && ts >= 0 && ts < T) ? (int)((rowbase + ts) * ld + b_c8[p]) : -1;
+#ifdef WN_EPI_ABLATE
+            if ((dbg & 8) && b_off[p] >= 0) b_off[p] = (int)(((b_t[p] - t0) & 127) * ld + b_c8[p]);     // probe: every workgroup DMAs the same 128 rows (L2-hot)
+#endif
         }
     };
 #pragma unroll
@@ -544,37 +592,41 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         if constexpr (TAPS > 0) {
             if (t_left > 0) {
                 // chunk c lives in ring slot c % NBUF and NBUF == TAPS: this buffer always holds tap BUF
+                if (dma_wave) {
 #pragma unroll
-                for (int p = 0; p < APW; ++p) {
-                    const int f = wave + p * NWD;
-                    const bf16_t* base = a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512;
-                    lds_dma16(base + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + f * 1024)));
-                }
-                const bf16_t* const tp = a.seg[0].base + a.seg[0].col0 + (s_kstep / (TAPS * Cfg::KS)) * BK;     // k-block of this chunk
+                    for (int p = 0; p < APW; ++p) {
+                        const int f = wave + p * NWD;
+                        const bf16_t* base = a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512;
+                        lds_dma16(base + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + f * 1024)));
+                    }
+                    const bf16_t* const tp = a.seg[0].base + a.seg[0].col0 + (s_kstep / (TAPS * Cfg::KS)) * BK;     // k-block of this chunk
 #pragma unroll
-                for (int p = 0; p < BPW; ++p) {
-                    const bf16_t* src = b_offt[BUF][p] >= 0 ? tp + b_offt[BUF][p] : a.zero;
-                    lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                    for (int p = 0; p < BPW; ++p) {
+                        const bf16_t* src = b_offt[BUF][p] >= 0 ? tp + b_offt[BUF][p] : a.zero;
+                        lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                    }
                 }
                 s_kstep += Cfg::KS; --t_left;
                 return;
             }
         }
-        if constexpr (TAPS == 0) {
+        if constexpr (PIPE <= 1 && TAPS == 0) {
             // full chunk inside the current segment (all but one chunk of every launch of the engine): no partial-k masks, the weight
             // panel through the SGPR-base DMA form
-            if (s_left >= BK && s_rep < a.nrep) {
+            if (s_left >= BK && s_rep < a.nrep && dbg == 0) {
+                if (dma_wave) {
 #pragma unroll
-                for (int p = 0; p < APW; ++p) {
-                    const int f = wave + p * NWD;
-                    const uint64_t v = (uint64_t)(a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512);
-                    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-                    lds_dma16_s(sb, lane * 16, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + f * 1024)));
-                }
+                    for (int p = 0; p < APW; ++p) {
+                        const int f = wave + p * NWD;
+                        const uint64_t v = (uint64_t)(a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512);
+                        const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+                        lds_dma16_s(sb, lane * 16, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + f * 1024)));
+                    }
 #pragma unroll
-                for (int p = 0; p < BPW; ++p) {
-                    const bf16_t* src = b_off[p] >= 0 ? s_ptr + b_off[p] : a.zero;
-                    lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                    for (int p = 0; p < BPW; ++p) {
+                        const bf16_t* src = b_off[p] >= 0 ? s_ptr + b_off[p] : a.zero;
+                        lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                    }
                 }
                 s_kstep += Cfg::KS; s_left -= BK; s_ptr += BK;
                 if (s_left <= 0) {
@@ -585,12 +637,18 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                 return;
             }
         }
-        const int kc = (s_rep < a.nrep) ? min(BK, s_left) : 0;      // past the last chunk: an all-zero chunk
+        const int kc = (s_rep < a.nrep) ? min(BK, s_left) : 0;      // past the last chunk: an all-zero chunk (PIPE 2 pads the count)
         // A: fragment f = mt*KS + ks  <-  Apk[(mtile_wg + mt)][s_kstep + ks]; wave-uniform base + lane*16
+        if (!(dbg & 1) && dma_wave) {
 #pragma unroll
         for (int p = 0; p < APW; ++p) {
             const int f = wave + p * NWD;
+#ifdef WN_EPI_ABLATE
+            const int ksx = (dbg & 8) ? (s_kstep & 7) : s_kstep;
+            const bf16_t* base = a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + ksx + f % Cfg::KS) * 512;
+#else
             const bf16_t* base = a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512;
+#endif
             const bf16_t* src = ((f % Cfg::KS) * 16 < kc) ? base + lane * 8 : a.zero;
             lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + f * 1024)));
         }
@@ -598,6 +656,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         for (int p = 0; p < BPW; ++p) {
             const bf16_t* src = (b_off[p] >= 0 && b_c8[p] < kc) ? s_ptr + b_off[p] : a.zero;
             lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+        }
         }
         s_kstep += kc >> 4; s_left -= BK; s_ptr += BK;
         if (s_left <= 0) {
@@ -617,54 +676,331 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
             b_rd[j][ks] = row * Cfg::RB + (((ks * 2 + (lane >> 5)) ^ ((row / Cfg::RPL) % Cfg::SPR)) * 16);
         }
     const int a_rd = (wm * MT * Cfg::KS * 64 + lane) * 16;
+    auto compute = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
+        // every k-step of the chunk, unconditionally: in a partial chunk (segment width % BK != 0) the tail k-steps of BOTH
+        // operands were DMA'd from the zero page, so they add exact zeros -- no branch around the accumulators
+#pragma unroll
+        for (int ks = 0; ks < Cfg::KS; ++ks) {
+            bf16x8_t af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
 
-    // one ring step: chunk `ch` lives in buffer BUF; chunk ch+NBUF-1 is DMA'd into the buffer freed by chunk ch-1.  Every fragment of
-    // the chunk is requested from LDS straight after the barrier, the DMA issue + iterator bookkeeping of the next chunk runs while
-    // those reads are in flight, then the chunk's MFMAs go back to back.  In a partial chunk (segment width % BK != 0) the tail
-    // k-steps of BOTH operands were DMA'd from the zero page, so they add exact zeros -- no branch around the accumulators.
-    auto ring_step = [&](auto bufc, int ch) {
+    // PIPE 6 / 7: the two halves of the workgroup (waves [0, NW/2) and [NW/2, NW): one wave of each half per SIMD) run HALF A
+    // CHUNK APART.  After the barrier of chunk ch the early half requests its fragments of chunk ch and issues the DMAs of chunk
+    // ch+2 while the late half multiplies the fragments of chunk ch-1 it already holds; then the early half multiplies chunk ch
+    // while the late half reads chunk ch and issues its DMAs.  On every SIMD a matrix-bound wave thus sits beside a memory-bound
+    // one instead of two waves fighting for the matrix pipe and then idling together.  Same k order per wave: bitwise-identical sums.
+    constexpr bool SPLIT = (PIPE >= 6);
+    const bool late = SPLIT && wave >= Cfg::NW / 2;
+    bf16x8_t haf[SPLIT ? Cfg::KS : 1][MT], hbf[SPLIT ? Cfg::KS : 1][NT];
+    auto mfma_held = [&]() {
+        if constexpr (PIPE == 7) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < (SPLIT ? Cfg::KS : 1); ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(haf[ks][i], hbf[ks][j], acc[i][j], 0, 0, 0);
+        if constexpr (PIPE == 7) __builtin_amdgcn_s_setprio(0);
+    };
+    // one ring step: chunk `ch` lives in buffer BUF; chunk ch+NBUF-1 is DMA'd into the buffer freed by chunk ch-1
+    auto ring_step = [&](auto bufc, int ch, auto latec) {
         constexpr int BUF = decltype(bufc)::value;
         // all DMAs except those of the (NBUF-2) youngest chunks have landed
         const int younger = min(NBUF - 2, nchunks - 1 - ch);
         if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
-        bf16x8_t af[Cfg::KS][MT], bfr[Cfg::KS][NT];
+        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+        if constexpr (PIPE == 0) {
+            if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+            compute(bufc);
+        } else if constexpr (SPLIT) {
+            const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
+            auto read_held = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < Cfg::KS; ++ks) {
+                for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        haf[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        hbf[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
+                }
+            };
+            if constexpr (decltype(latec)::value) {
+                mfma_held();                                 // late half: chunk ch-1 (zeros before the first chunk), fragments read before the barrier
+                __builtin_amdgcn_sched_barrier(0);
+                read_held();
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+                // the next barrier releases this buffer to the DMA of chunk ch+3: the reads just issued must have returned by then
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                read_held();
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_held();                                 // early half: chunk ch
+            }
+        } else {
+            // PIPE 1: every fragment of the chunk is requested from LDS straight after the barrier, the DMA issue + iterator
+            // bookkeeping of the next chunk runs while those reads are in flight, then the chunk's MFMAs go back to back.
+            const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
+            bf16x8_t af[Cfg::KS][MT], bfr[Cfg::KS][NT];
+            if (dbg & 2) {
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) af[ks][i] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, ch, ks, i));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bfr[ks][j] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, ch, ks, j));
+                }
+            } else
+#pragma unroll
+            for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < Cfg::KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    static_assert(NBUF == 2 || NBUF == 3 || (NBUF == 4 && PIPE >= 2), "ring depth");
+
+    if constexpr (PIPE >= 2 && PIPE < 6) {
+        // PIPE 2: fragments are requested from LDS one k-step AHEAD of the MFMAs that use them (two register sets), across
+        // chunk boundaries too, so no MFMA ever waits on a read it has just issued.  Reading chunk ch+1 while chunk ch is still
+        // being multiplied needs chunk ch+1 landed one step early: the ring keeps {ch, ch+1, DMA target ch+2}, i.e. the DMA
+        // look-ahead is one chunk time (>= 1000 clk here, above the L2-hit DMA latency) instead of two.
+        static_assert(NBUF >= 3 && Cfg::KS % 2 == 0, "PIPE >= 2 needs a ring of 3 or 4 and an even number of k-steps per chunk");
+        // With NBUF == 4 the DMAs awaited at a step were issued TWO steps earlier (vmcnt leaves the youngest chunk in flight).
+        constexpr int INFL = (NBUF - 3) * (APW + BPW);
+        bf16x8_t fa[2][MT], fb[2][NT];
+        auto read_frags = [&](auto bufc, auto ksc, auto setc) {
+            constexpr int BUF = decltype(bufc)::value, ks = decltype(ksc)::value, SET = decltype(setc)::value;
+            const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                af[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
+                fa[SET][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(buf + a_rd + (i * Cfg::KS + ks) * 1024));
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (ch + NBUF - 1 < nchunks) stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < Cfg::KS; ++ks)
+                fb[SET][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
+        };
+        auto mfma_set = [&](auto setc) {
+            constexpr int SET = decltype(setc)::value;
+#ifdef WN_EPI_ABLATE
+            if (dbg & 64) { asm volatile("" :: "v"(fa[SET][0]), "v"(fb[SET][0])); return; }      // probe: DMAs, LDS reads, waits and barriers only
+#endif
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-    };
-    static_assert(NBUF == 2 || NBUF == 3, "ring depth");
-
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);
+        };
+        const int npad = (nchunks + NBUF - 1) / NBUF * NBUF;          // zero chunks pad the count: no guards inside the unrolled body
+#ifdef WN_EPI_ABLATE
+        const bool tr_on = (dbg & 16) && a.trace && lane == 0 && (wave == 0 || wave == 5) && wg_id < 1024;
+        unsigned long long* const tr = a.trace + ((size_t)wg_id * 2 + (wave ? 1 : 0)) * 64 * 4;
+#define WN_TR(ch_, slot_) do { if (tr_on && (ch_) < 64) tr[(ch_) * 4 + (slot_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WN_TR(ch_, slot_) do { } while (0)
+#endif
+        auto step2 = [&](auto bufc, int ch) {
+            constexpr int BUF = decltype(bufc)::value;
+            // entry: set 0 holds (ch, k-step 0)
+            [&]<int... KSI>(std::integer_sequence<int, KSI...>) {
+                ([&] {
+                    constexpr int ks = KSI;
+                    if constexpr (ks + 1 < Cfg::KS) {
+                        read_frags(bufc, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, (ks + 1) & 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_set(std::integral_constant<int, ks & 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        // last k-step: synchronise on chunk ch+1 and issue the DMAs of chunk ch+2 FIRST (their address arithmetic,
+                        // incl. the occasional segment switch with its scalar loads, must not sit between LDS reads and their
+                        // consumers: any SMEM in flight, or any control-flow join, turns the later waits into lgkmcnt(0)), then
+                        // the MFMAs, then the reads of (ch+1, k-step 0), which fly during those MFMAs and the next read issue.
+                        WN_TR(ch, 0);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");   // my DMAs of chunk ch+1 have landed (younger chunks may fly)
+                        WN_TR(ch, 1);
+                        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();               // everyone's have landed; buffer of chunk ch-1 is free
+                        WN_TR(ch, 2);
+                        if constexpr (PIPE == 2) {
+                            stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});      // chunk ch+NBUF-1 (zero chunks past the end keep vmcnt uniform)
+                            WN_TR(ch, 3);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mfma_set(std::integral_constant<int, ks & 1>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            read_frags(std::integral_constant<int, (BUF + 1) % NBUF>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else {
+                            // PIPE 3 / 5: the (slow, wave-blocking) DMA issue goes LAST, behind MFMAs that are already in the pipe
+                            read_frags(std::integral_constant<int, (BUF + 1) % NBUF>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            mfma_set(std::integral_constant<int, ks & 1>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            stage(std::integral_constant<int, (BUF + NBUF - 1) % NBUF>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }(), ...);
+            }(std::make_integer_sequence<int, Cfg::KS>{});
+        };
+        stage(std::integral_constant<int, 0>{});
+        stage(std::integral_constant<int, 1>{});
+        if constexpr (NBUF == 4) stage(std::integral_constant<int, 2>{});
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (APW + BPW)) : "memory");      // chunk 0 landed (non-issuing waves: trivially true)
+        __builtin_amdgcn_s_barrier();
+        read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        for (int ch = 0; ch < npad; ch += NBUF) {
+            step2(std::integral_constant<int, 0>{}, ch);
+            step2(std::integral_constant<int, 1>{}, ch + 1);
+            step2(std::integral_constant<int, 2>{}, ch + 2);
+            if constexpr (NBUF == 4) step2(std::integral_constant<int, 3>{}, ch + 3);
+        }
+        // the trailing fragment reads (of a buffer nobody multiplies) must retire before the epilogue reuses the registers / LDS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(fa[0][0]), "v"(fb[0][0]) : "memory");
+    } else {
+    // A-direct: the fragments of chunk 0 are requested BEFORE the prologue's DMAs (vmcnt retires in order)
+    [[maybe_unused]] u32x4_t adf[Cfg::KS];                      // this wave's A fragments of ONE chunk (single set, see ad_step)
+    [[maybe_unused]] uint64_t ad_src = 0;                       // SGPR: pack address of the next chunk's first k-step of this wave's m-tile
+    [[maybe_unused]] bool ad_on = false;
+    if constexpr (ADIRECT) {
+        const int nkb = a.seg[0].nk / BK;
+        ad_on = nkb >= 2 && dbg == 0 && nchunks > 3 * (nkb - 1) + 1;
+        if (ad_on) {
+            const uint64_t v = (uint64_t)(a.Apk + (int64_t)mtile0 * a.ksteps_total * 512);
+            ad_src = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            gload_frag_s<0>(adf[0], ad_src, lane * 16);
+            gload_frag_s<1024>(adf[1], ad_src, lane * 16);
+            ad_src += Cfg::KS * 1024;
+        }
+    }
     // prologue: fill NBUF-1 buffers
     stage(std::integral_constant<int, 0>{});
     if constexpr (NBUF == 3) { if (nchunks > 1) stage(std::integral_constant<int, 1>{}); }
     int ch0 = 0;
-    if constexpr (TAPS == 3 && NBUF == 3) {
+    if constexpr (ADIRECT) {
+        if (ad_on) {
+            static_assert(Cfg::KS == 2, "two k-steps per chunk");
+            const int nkb = a.seg[0].nk / BK;
+            uint64_t sa[APW];                                   // DMA sources of the weight panel (only the last two steps use them: the generic tail reads A from LDS)
+#pragma unroll
+            for (int p = 0; p < APW; ++p) {
+                const int f = wave + p * NWD;
+                const uint64_t v = (uint64_t)(a.Apk + ((int64_t)(mtile_wg + f / Cfg::KS) * a.ksteps_total + s_kstep + f % Cfg::KS) * 512);
+                sa[p] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            }
+            const uint32_t a_voff = lane * 16;
+            const bf16_t* tpb = a.seg[0].base + a.seg[0].col0;
+            // One ring step of chunk ch (slot BUF == tap):
+            //     wait: the DMAs of chunk ch have landed | barrier | request the B fragments | DMA chunk ch + 2 (B only; MODE >= 1: A too --
+            //     a generic tail step will read it from LDS) | wait: A(ch) is in adf | the chunk's MFMAs | request A(ch + 1) INTO THE SAME
+            //     REGISTERS (the MFMAs have read them at issue; MODE 2, the last step, does not).
+            // The A request of the next chunk thus flies during the whole next step up to its MFMAs (> one L2 round trip) with a single
+            // register set.  vmcnt retires in order; issue order per step: [A DMAs], B DMA, ..., A request x 2.  VT = operations that may be in
+            // flight at the top (everything younger than the DMAs of chunk ch), VA = those younger than the A request of chunk ch.
+            auto ad_step = [&](auto bufc, auto vtc, auto modec) {
+                constexpr int BUF = decltype(bufc)::value, VT = decltype(vtc)::value, MODE = decltype(modec)::value;
+                constexpr int VA = (MODE == 0 ? 0 : APW) + BPW;
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VT) : "memory");
+                __builtin_amdgcn_s_barrier();
+                const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
+                bf16x8_t bfr[Cfg::KS][NT];
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        bfr[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bufb + b_rd[j][ks]));
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    constexpr int SB = (BUF + NBUF - 1) % NBUF;          // slot (== tap) of chunk + 2
+                    char* const abuf = lds + Cfg::a_base(SB);
+                    char* const bbuf = lds + Cfg::b_base(SB);
+                    if constexpr (SB == 0) tpb += BK;
+#pragma unroll
+                    for (int p = 0; p < APW; ++p) {
+                        if constexpr (MODE != 0) lds_dma16_s(sa[p], a_voff, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + (wave + p * NWD) * 1024)));
+                        sa[p] += Cfg::KS * 1024;
+                    }
+#pragma unroll
+                    for (int p = 0; p < BPW; ++p) {
+                        const bf16_t* src = b_offt[SB][p] >= 0 ? tpb + b_offt[SB][p] : a.zero;
+                        lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(bbuf + (wave + p * NWD) * 1024)));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                wn_wait_frags<VA>(adf[0], adf[1]);
+#pragma unroll
+                for (int ks = 0; ks < Cfg::KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, adf[ks]), bfr[ks][j], acc[0][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MODE != 2) {
+                    gload_frag_s<0>(adf[0], ad_src, a_voff);
+                    gload_frag_s<1024>(adf[1], ad_src, a_voff);
+                    ad_src += Cfg::KS * 1024;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            using VT0 = std::integral_constant<int, BPW + Cfg::KS>;            // after a MODE 0 step: its B DMA + its A request
+            using VT1 = std::integral_constant<int, APW + BPW + Cfg::KS>;      // after a MODE 1 step
+            using VTP = std::integral_constant<int, Cfg::LPC>;                 // first step of the tile: the prologue's DMAs of chunk 1
+            auto kblock = [&](auto firstc, auto lastc) {
+                constexpr bool FIRST = decltype(firstc)::value, LAST = decltype(lastc)::value;
+                ad_step(I0{}, std::conditional_t<FIRST, VTP, VT0>{}, I0{});
+                ad_step(I1{}, VT0{}, std::conditional_t<LAST, I1, I0>{});
+                ad_step(I2{}, std::conditional_t<LAST, VT1, VT0>{}, std::conditional_t<LAST, I2, I0>{});
+            };
+            const int nb = nkb - 1;                              // k-blocks of the fast part (>= 1)
+            if (nb == 1) kblock(std::true_type{}, std::true_type{});
+            else {
+                kblock(std::true_type{}, std::false_type{});
+                for (int i = 1; i + 1 < nb; ++i) kblock(std::false_type{}, std::false_type{});
+                kblock(std::false_type{}, std::true_type{});
+            }
+            ch0 = 3 * nb;
+            s_kstep += Cfg::KS * ch0; t_left -= ch0;
+        }
+    }
+    if constexpr (TAPS == 3 && PIPE == 1 && NBUF == 3 && !ADIRECT) {
         // ---- regular part of the K-interleaved taps (all k-blocks but the last): the generic staging iterator above costs ~80 mostly
         // scalar, branchy instructions per chunk IN FRONT of the wave's MFMAs (in-order issue).  Here the three ring steps of one
         // k-block are unrolled with everything they need in registers: the weight panel source is an SGPR base advanced by one
         // scalar add per chunk (SGPR-base DMA form), the activation source one 64-bit add per lane and tap; no segment
         // bookkeeping, no division, one loop branch per three chunks.  Same chunk order, same sums.
         const int nkb = a.seg[0].nk / BK;
-        if (nkb >= 2 && nchunks > 3 * (nkb - 1) + 1) {
+        if (nkb >= 2 && (dbg == 0 || dbg == 128) && nchunks > 3 * (nkb - 1) + 1) {      // (dbg 128: harness probe, see below)
             uint64_t sa[APW];
 #pragma unroll
             for (int p = 0; p < APW; ++p) {
@@ -681,6 +1017,9 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                 if constexpr (BUF == 0) tpb += BK;
 #pragma unroll
                 for (int p = 0; p < APW; ++p) {
+#ifdef WN_EPI_ABLATE      // probe 128: only the first A piece per wave is DMA'd (wrong sums; the DMA count of a 128 x 256 tile that shares its B rows between the taps)
+                    if (dbg == 128 && p > 0) { sa[p] += Cfg::KS * 1024; continue; }
+#endif
                     lds_dma16_s(sa[p], a_voff, __builtin_amdgcn_readfirstlane(lds_addr_of(abuf + (wave + p * NWD) * 1024)));
                     sa[p] += Cfg::KS * 1024;
                 }
@@ -695,6 +1034,9 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                 // chunk ch landed (only chunk ch+1 may still be in flight); lgkmcnt(0): this wave's fragment reads of chunk ch-1 have
                 // RETURNED before the barrier releases its ring slot to the next DMA -- the compiler is free to sink the (register-only)
                 // MFMAs of chunk ch-1 and the waits in front of them below the barrier, and does
+#ifdef WN_EPI_ABLATE
+                if (dbg == 128) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::LPC - APW + 1) : "memory"); else
+#endif
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::LPC) : "memory");
                 __builtin_amdgcn_s_barrier();
                 const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
@@ -728,12 +1070,46 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
             s_kstep += Cfg::KS * ch0; t_left -= ch0;
         }
     }
-    for (int ch = ch0; ch < nchunks; ch += NBUF) {
-        ring_step(std::integral_constant<int, 0>{}, ch);
-        if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1);
-        if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2); }
+    auto main_loop = [&](auto latec) {
+        for (int ch = ch0; ch < nchunks; ch += NBUF) {
+            ring_step(std::integral_constant<int, 0>{}, ch, latec);
+            if (ch + 1 < nchunks) ring_step(std::integral_constant<int, 1>{}, ch + 1, latec);
+            if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2, latec); }
+        }
+    };
+    if constexpr (SPLIT) {
+        // two copies of the loop (wave-uniform scalar branch): inside each the instruction order is fixed, nothing merges per chunk
+        if (late) {
+#pragma unroll
+            for (int ks = 0; ks < Cfg::KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) haf[ks][i] = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) hbf[ks][j] = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+            }
+            main_loop(std::true_type{});
+            mfma_held();                                  // the late half still owes the last chunk
+        } else main_loop(std::false_type{});
+    } else main_loop(std::false_type{});
     }
 
+#ifdef WN_EPI_ABLATE
+    if ((dbg & 32) && a.trace && tid == 0) {
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[(size_t)wg_id * 4 + 0] = wg_t_start; a.trace[(size_t)wg_id * 4 + 1] = __builtin_amdgcn_s_memtime();
+        a.trace[(size_t)wg_id * 4 + 2] = hwid; a.trace[(size_t)wg_id * 4 + 3] = xcc;
+    }
+    if (a.e.scale != -7777.0f) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        return;
+    }
+#endif
     if constexpr (EPI == EPI_STORE_F32_BOT) {
         // [B][M][T] fp32 output: lanes are consecutive time steps, already coalesced
         wn_tile_epilogue<MT, NT, EPI>(a, acc, mtile0, t0 + wn * NT * 32, b, T, rowbase, lane);
@@ -906,15 +1282,63 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
     if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
 }
 
-template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 1, int TAPS = 0>
+template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 0, int TAPS = 0>
 __global__ __launch_bounds__(WM * WN * 64, (lds_gemm_min_waves(MT, NT, WM, WN, BK, NBUF)))
 void wn_gemm_lds_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(1024))) char lds[LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>::LDS_BYTES];
     wn_gemm_lds_body<MT, NT, WM, WN, BK, NBUF, EPI, PIPE, TAPS>(a, lds, blockIdx.x);
 }
 
-// grids of at least this many workgroups (more than two full rounds of 2 x 256 slots) de-phase their second-resident workgroups
-#define WN_STAGGER_MIN_GRID 1024
+// Two launches in ONE grid: an MFMA-bound launch of one half of the batch (gate / d x: K-interleaved taps, 256 x 128 tiles) and an
+// HBM-bound launch of the OTHER half (out conv / d z: 256 x 128 tiles) interleaved in groups of 8 workgroups (a group of 8 consecutive
+// ids covers the 8 XCDs once, so every body keeps its id % 8 == XCD decode).  The serial layer chain alternates the two kinds, and each
+// kind alone under-uses the GPU: a half-batch gate launch is 1.34 rounds of workgroups and leaves HBM idle, the out conv leaves the
+// matrix pipe idle.  Two streams only overlap them by accident (rocprofv3: one kernel in flight for more than half of the step) and
+// forcing the pairing with cross-stream events costs 15-24 us per event (wn_train.hip, lockstep).  In one grid the dispatcher fills
+// every freed CU slot with the next workgroup of EITHER kind, with no boundary between them.
+template <int EPI_A, int EPI_B>
+__global__ __launch_bounds__(512, 4)      // 4 waves per SIMD = two 8-wave workgroups per CU (<= 128 VGPRs)
+void wn_fused_pair_kernel(const GemmArgs a, const GemmArgs b, const int groups_a, const int groups_b) {
+    using CfgA = LdsGemmCfg<2, 2, 4, 2, 32, 3>;
+    __shared__ __attribute__((aligned(1024))) char lds[CfgA::LDS_BYTES];
+    const int q = blockIdx.x >> 3, r = blockIdx.x & 7;
+    const int64_t tot = (int64_t)groups_a + groups_b;
+    const int na0 = (int)((int64_t)q * groups_a / tot), na1 = (int)((int64_t)(q + 1) * groups_a / tot);      // A groups among the first q / q + 1 groups
+    if (na1 > na0) wn_gemm_lds_body<2, 2, 4, 2, 32, 3, EPI_A, 1, 3>(a, lds, na0 * 8 + r);
+    else wn_gemm_lds_body<2, 2, 4, 2, 32, 3, EPI_B, 1, 0>(b, lds, (q - na0) * 8 + r);
+}
+
+// Tile order of the LDS-DMA kernels (A/B switch WN_TILE_ORDER: 1 = contiguous run of tiles per XCD, 0 = interleaved).
+static inline bool wn_tile_order_contiguous() {
+    static const int v = [] { const char* e = getenv("WN_TILE_ORDER"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
+// grids of at least this many workgroups de-phase their second-resident workgroups (A/B switch WN_STAGGER_MIN_GRID)
+static inline int wn_stagger_min_grid() {
+    static const int v = [] { const char* e = getenv("WN_STAGGER_MIN_GRID"); return e ? atoi(e) : 1024; }();
+    return v;
+}
+
+// grid of the 256 x 128 LDS-DMA launch of `a` (fills the decode fields); 0 if the shape does not take that kernel
+static inline int wn_prep_v2(GemmArgs& a, int M) {
+    if (M % 256 != 0 || a.e.M_valid != M || !a.zero) return 0;
+    a.mblocks = M / 256;
+    a.tiles_per_utt = cdiv(a.T, 128);
+    a.ntiles = a.tiles_per_utt * a.B;
+    a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
+    a.stagger = 0;
+    return cdiv(a.ntiles, 8) * a.mblocks * 8;
+}
+// one grid for the MFMA-bound launch `a` (taps == 3) and the HBM-bound launch `b`; WN_E_SHAPE if either does not fit the 256 x 128 kernel
+template <int EPI_A, int EPI_B>
+static inline int wn_launch_fused_pair(wn_ctx* ctx, GemmArgs& a, int Ma, GemmArgs& b, int Mb, hipStream_t st) {
+    const int ga = wn_prep_v2(a, Ma), gb = wn_prep_v2(b, Mb);
+    if (!ga || !gb || a.taps != 3 || b.taps != 0 || b.nrep != 1) WN_FAIL(ctx, WN_E_SHAPE, "fused pair launch: shapes M = %d / %d do not take the 256 x 128 kernels", Ma, Mb);
+    hipLaunchKernelGGL((wn_fused_pair_kernel<EPI_A, EPI_B>), dim3(ga + gb), dim3(512), 0, st, a, b, ga / 8, gb / 8);
+    WN_LAUNCH_CHECK(ctx);
+    return WN_OK;
+}
 
 // Host-side launcher: picks the main loop and workgroup shape from M.
 template <int EPI>
@@ -931,11 +1355,12 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
         // 128-row tile is the faster one (46.6 vs 48.2 us), hence the rule.
         bool k64 = a.nrep == 1 && a.taps == 0;
         for (int sgi = 0; sgi < a.nseg; ++sgi) k64 = k64 && a.seg[sgi].nk % 64 == 0;
-        if (k64 && M % 256 == 0 && a.e.M_valid == M && a.zero && (int64_t)cdiv(a.T, 128) * a.B * (M / 256) < 512) {
+        static const int small_tiles = [] { const char* e = getenv("WN_SMALL_TILES"); return e ? atoi(e) : 1; }();       // A/B switch
+        if (small_tiles && k64 && M % 256 == 0 && a.e.M_valid == M && a.zero && (int64_t)cdiv(a.T, 128) * a.B * (M / 256) < 512) {
             a.mblocks = M / 256;
             a.tiles_per_utt = cdiv(a.T, 64);
             a.ntiles = a.tiles_per_utt * a.B;
-            a.xcd_span = cdiv(a.ntiles, 8);
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             a.stagger = 0;
             hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 1, 4, 2, 64, 2, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
@@ -943,23 +1368,36 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             return WN_OK;
         }
     }
+    // A/B switch WN_MFMA_SMALL: 1 = an MFMA-bound taps launch (gate / d x) with fewer 256 x 128 tiles than workgroup slots (d x of a half
+    // batch: 344 for 512) takes 128 x 128 tiles instead (twice the workgroups, half the work each); 2 = every taps launch does
+    static const int mfma_small = [] { const char* e = getenv("WN_MFMA_SMALL"); return e ? atoi(e) : 0; }();
+    const bool small_taps = (EPI == EPI_GATE || EPI == EPI_DX) && a.taps == 3 && M % 128 == 0 &&
+                            (mfma_small >= 2 || (mfma_small == 1 && (int64_t)cdiv(a.T, 128) * a.B * (M / 256) < 512));
     if constexpr (EPI != EPI_STORE_F32_BOT) {
-        if (M % 256 == 0 && a.e.M_valid == M && a.zero) {
+        if (M % 256 == 0 && a.e.M_valid == M && a.zero && !small_taps) {
             // v2: 256 channels x 128 time rows per 8-wave workgroup, K-chunks of 32, 3-deep LDS-DMA ring, 2 workgroups per CU
             a.mblocks = M / 256;
             a.tiles_per_utt = cdiv(a.T, 128);
             a.ntiles = a.tiles_per_utt * a.B;
-            a.xcd_span = cdiv(a.ntiles, 8);
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
-            a.stagger = grid >= WN_STAGGER_MIN_GRID ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
+            a.stagger = grid >= wn_stagger_min_grid() ? 8000 : 0;      // more than two full rounds: desynchronise the co-resident workgroups
             if constexpr (EPI == EPI_GATE || EPI == EPI_DX) {
-                if (a.taps == 3) {       // K-interleaved taps (packs built with kil = 32)
+                if (a.taps == 3) {       // K-interleaved taps (packs built with kil = 32).  PIPE 6 (wave halves half a chunk apart) measured +1.5 .. 2 % in
+                                         // the harness without the tap offsets (profiles/r2_gemm_harness_b{4,8}.txt) but needs 128 VGPRs + 3 spills with them: not used
                     hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1, 3>), dim3(grid), dim3(512), 0, st, a);
                     WN_LAUNCH_CHECK(ctx);
                     return WN_OK;
                 }
             }
-            hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
+            static const int pipe_override = [] { const char* e = getenv("WN_GEMM_PIPE"); return e ? atoi(e) : 1; }();   // A/B switch for measurements (PIPE 2/3 pad the chunk count: slower on the 8- and 16-chunk kernels)
+            // chunk count of this contraction: PIPE 2 (fragment reads one k-step ahead across chunk boundaries) pads it to a
+            // multiple of the ring depth, so it is only used where that costs nothing (gate 27, dx 48, skip sum L*8 chunks)
+            int nch = 0; for (int sgi = 0; sgi < a.nseg; ++sgi) nch += (a.seg[sgi].nk + 31) / 32; nch *= a.nrep;
+            const bool free_pad = (nch % 3 == 0) && nch >= 24;
+            if (pipe_override == 2 || (pipe_override == 4 && free_pad)) hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 2>), dim3(grid), dim3(512), 0, st, a);
+            else if (pipe_override == 3) hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 3>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
             return WN_OK;
         }
@@ -970,9 +1408,9 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.mblocks = M / 128;
             a.tiles_per_utt = cdiv(a.T, 128);
             a.ntiles = a.tiles_per_utt * a.B;
-            a.xcd_span = cdiv(a.ntiles, 8);
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
-            a.stagger = grid >= WN_STAGGER_MIN_GRID ? 8000 : 0;
+            a.stagger = grid >= wn_stagger_min_grid() ? 8000 : 0;
             if constexpr (EPI == EPI_GATE || EPI == EPI_DX) {
                 if (a.taps == 3) {
                     hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 2, 4, 2, 32, 3, EPI, 1, 3>), dim3(grid), dim3(512), 0, st, a);
@@ -990,11 +1428,12 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.mblocks = 1;
             a.tiles_per_utt = cdiv(a.T, 192);
             a.ntiles = a.tiles_per_utt * a.B;
-            a.xcd_span = cdiv(a.ntiles, 8);
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * 8;
             // K-chunks of 64 with a 2-deep ring (half the ring steps) for narrow gate widths: -1 .. -2.4 % on the step of hparams.py's
-            // defaults (G = 256), neutral at G = 512 (profiles/r4u_ab_dc_bk64.txt)
-            bool k64 = a.seg[0].nk <= 256;
+            // defaults (G = 256), neutral at G = 512 (gpurun_out r4u A/B; WN_DC_BK64 = 0 / 1 forces either)
+            static const int bk64 = [] { const char* e = getenv("WN_DC_BK64"); return e ? atoi(e) : -1; }();
+            bool k64 = bk64 < 0 ? a.seg[0].nk <= 256 : bk64 != 0;
             for (int sgi = 0; sgi < a.nseg; ++sgi) k64 = k64 && a.seg[sgi].nk % 64 == 0;
             if (k64) hipLaunchKernelGGL((wn_gemm_lds_kernel<1, 3, 3, 2, 64, 2, EPI, 1>), dim3(grid), dim3(384), 0, st, a);
             else
@@ -1006,7 +1445,7 @@ static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st
             a.mblocks = M / 128;
             a.tiles_per_utt = cdiv(a.T, 256);
             a.ntiles = a.tiles_per_utt * a.B;
-            a.xcd_span = cdiv(a.ntiles, 8);
+            a.xcd_span = wn_tile_order_contiguous() ? cdiv(a.ntiles, 8) : 0;
             const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
             hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 2, 4, 32, 3, EPI, 1>), dim3(grid), dim3(512), 0, st, a);
             WN_LAUNCH_CHECK(ctx);
