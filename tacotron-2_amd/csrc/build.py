@@ -61,6 +61,38 @@ def build(force=False, verbose=True):
     return LIB
 
 
+SAN_LIB = os.path.join(HERE, 'libwavenet_mi355_san.so')
+SAN_FLAGS = ['-O1', '-g', '-fno-omit-frame-pointer', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-fno-gpu-sanitize']
+
+
+def build_sanitized(verbose=True):
+    """ASAN + UBSAN variant of the library's HOST side for the CPU ABI tests (tests/test_host_cpu.py runs them under it in a child
+    process with the sanitizer runtime preloaded): wn_api.hip -- every C-ABI entry point, the configuration validation, the parameter
+    table and workspace planning -- is rebuilt with -fsanitize=address,undefined (device code untouched: -fno-gpu-sanitize) and linked
+    with the regular objects of the other translation units.  libwavenet_mi355_san.so; never loaded by the product."""
+    build(verbose=verbose)
+    src, obj = os.path.join(HERE, 'wn_api.hip'), os.path.join(HERE, 'wn_api.san.o')
+    newest = max([_mtime(src)] + [_mtime(os.path.join(HERE, h)) for h in HEADERS] + [_mtime(__file__)])
+    if _mtime(obj) <= newest:
+        flags = [f for f in FLAGS if f != '-O3'] + SAN_FLAGS
+        r = subprocess.run(['hipcc'] + flags + ['-c', src, '-o', obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc (sanitized) failed for wn_api.hip:\n%s\n%s' % (r.stdout, r.stderr))
+    others = [os.path.join(HERE, s.replace('.hip', '.o')) for s in SOURCES if s != 'wn_api.hip']
+    if _mtime(SAN_LIB) < max(_mtime(o) for o in others + [obj]):
+        r = subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-fsanitize=address,undefined', '-shared-libsan', '-o', SAN_LIB, obj] + others, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link (sanitized) failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return SAN_LIB
+
+
+def sanitizer_runtime():
+    """Path of clang's shared ASAN runtime (to LD_PRELOAD into the python that loads libwavenet_mi355_san.so)."""
+    r = subprocess.run(['/opt/rocm/lib/llvm/bin/clang', '-print-file-name=libclang_rt.asan-x86_64.so'], capture_output=True, text=True)
+    p = r.stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    print(build_sanitized() if '--sanitize' in sys.argv else build(force='--force' in sys.argv))
     print('build mode: ' + ', '.join('%s %s' % kv for kv in sorted(LAST_BUILD.items())))

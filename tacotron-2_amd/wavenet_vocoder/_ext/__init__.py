@@ -12,6 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'csrc', 'libwavenet_mi355.so'))
+if os.environ.get('WN_MI355_TEST_LIB'):      # test hook: the ASAN / UBSAN build of the host side (csrc/build.py --sanitize), never the product
+    LIB_PATH = os.environ['WN_MI355_TEST_LIB']
 
 WN_ABI_VERSION = 4
 WN_MAX_UPSAMPLE = 8

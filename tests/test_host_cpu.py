@@ -629,6 +629,29 @@ def test_c_abi_rejects_bad_configurations_before_touching_the_gpu():
     assert ei.value.code == SHAPE and 'WN_E_SHAPE' in str(ei.value)
 
 
+def test_c_abi_host_side_under_address_and_ub_sanitizers():
+    """SURVEY section 5 (sanitizer variant): the C-ABI validation tests above, re-run in a child interpreter against the ASAN + UBSAN
+    build of the library's host side (csrc/build.py --sanitize: wn_api.hip -- entry points, configuration validation, parameter table,
+    workspace planning -- instrumented; device code untouched) with the sanitizer runtime preloaded.  Any heap overflow, use after free
+    or undefined behaviour on those paths aborts the child."""
+    sys.path.insert(0, os.path.join(ROOT, 'tacotron-2_amd', 'csrc'))
+    import build as B
+    rt = B.sanitizer_runtime()
+    if rt is None:
+        pytest.skip('clang ASAN runtime not found in this image')
+    lib = B.build_sanitized(verbose=False)
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS='detect_leaks=0:verify_asan_link_order=0:abort_on_error=1',
+               UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1', WN_MI355_TEST_LIB=lib)
+    probe = ('import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from wavenet_vocoder import _ext; _ext.load_library(); '
+             'm = open("/proc/self/maps").read(); print("SAN_LIB", "libwavenet_mi355_san.so" in m, "libclang_rt.asan" in m)' % (ROOT, os.path.join(ROOT, 'tacotron-2_amd')))
+    r = subprocess.run([sys.executable, '-c', probe], capture_output=True, text=True, timeout=300, env=env)
+    assert 'SAN_LIB True True' in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_host_cpu.py'), '-x', '-q', '-p', 'no:cacheprovider',
+                        '-k', 'c_abi_rejects or exports_every_declared or fails_loudly_without_gpu or dropout_mask_mirror'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and '4 passed' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_bench_cpu_synthesis_baseline_leg():
     """bench.py's CPU synthesis baseline: the oracle incremental loop in the reference's queue formulation and with ring
     buffers, on a bounded sample, reporting samples/s and the extrapolated real-time factor."""

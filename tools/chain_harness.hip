@@ -2,6 +2,14 @@
 // >= 15 % faster than the production schedule (two free-running streams, one half batch each, one launch per GEMM) on the same layers,
 // or it is dropped and written up.
 //
+// RESULT (MI355X, round 4; profiles/r5i_chain_harness_fenced.txt, r5j_chain_harness_unfenced.txt): bit-identical outputs, and
+//     (A) production 124 - 143 us per layer | (B) one stream 137 - 160 | (C) persistent chain 337 (agent-scope fences) / 190 - 200 (no fences:
+//     `chain_harness 1`, legal only while every dependency stays inside one XCD)  =>  C is +40 .. +155 % SLOWER than A.  KILLED.
+// Why: an agent-scope release / acquire per tile is an L2 write-back + invalidate on gfx950 (the weights are re-fetched after every
+// invalidate); both bodies in one kernel at the 128-VGPR limit of two workgroups per CU spill 40 VGPRs into the main loops (a scratch
+// reload makes hipcc drain vmcnt, i.e. the LDS-DMA ring); and what the chain removes -- launch tails -- the two free-running streams
+// already hide under each other's next launch (B vs A is only +5 .. 13 %).
+//
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc tools/chain_harness.hip -o tools/chain_harness
 //
 // Workload: NL gated residual layers of the paper model (R = 256, G = 512, 80 conditioning channels, dropout 0.05), B = 8 x T = 11 000,
@@ -22,6 +30,7 @@
 #include <vector>
 #include <random>
 #include <algorithm>
+#include <unistd.h>
 std::string g_create_err;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 static std::mt19937 rng(7);
@@ -43,67 +52,77 @@ struct ChainArgs {
     int32_t dil[MAXL];
     int32_t* abort_flag;
     unsigned long long* t_first; unsigned long long* t_last;
+    int32_t flags;               // debug: 1 no fences, 2 no body
+    int32_t n_per_xcd;           // resident workgroups per XCD (grid / 8): the ticket stride of a workgroup
+    const int32_t* always;       // a word that satisfies every wait (idle poll lanes)
+    int32_t* dummy;              // [64][16] sink of the idle lanes' atomics
 };
 
 __device__ __forceinline__ int ld_acq(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Control flow inside the task loop is kept WAVE-UNIFORM on purpose: with `if (tid == 0)` regions (ticket atomics, flag polls, the
+// release) hipcc's structuriser treats the loop as divergent and moves the tail of an iteration out of the inner loop for the lanes
+// that took the branch -- wave 0 then executes more s_barriers than waves 1..7 and every workgroup deadlocks in its first task
+// (measured: gpurun_out r5f-r5h).  So: static round-robin tickets (workgroup i of an XCD takes tickets i, i + n, ...: still only EARLIER
+// tickets are ever waited for), polls by all 64 lanes of wave 0 with a ballot as the loop condition, and per-lane atomics whose idle
+// lanes hit a dummy line.
 __global__ __launch_bounds__(512, 4) void chain_kernel(const ChainArgs ca) {
     using Cfg = LdsGemmCfg<2, 2, 4, 2, 32, 3>;
     __shared__ __attribute__((aligned(1024))) char lds[Cfg::LDS_BYTES];
-    __shared__ int s_ticket;
-    const int tid = threadIdx.x;
+    __shared__ int s_first;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int xcd; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd)); xcd &= 7;
-    if (tid == 0) atomicMin(ca.t_first, (unsigned long long)wall_clock64());
+    // my index among the workgroups of this XCD (once, before the loop), and how many there are (the host launches 8 * n_per_xcd)
+    if (tid == 0) { s_first = atomicAdd(ca.ticket + xcd * 32, 1); atomicMin(ca.t_first, (unsigned long long)wall_clock64()); }
+    __syncthreads();
+    const int my = __builtin_amdgcn_readfirstlane(s_first);
     const int total = ca.per_xcd_prefix[2 * ca.nl];
-    for (;;) {
-        if (tid == 0) s_ticket = atomicAdd(ca.ticket + xcd * 32, 1);
-        __syncthreads();
-        const int k = __builtin_amdgcn_readfirstlane(s_ticket);
-        __syncthreads();
-        if (k >= total) break;
-        int li = 0;
+    int li = 0;
+    for (int k = my; k < total; k += ca.n_per_xcd) {
         while (k >= ca.per_xcd_prefix[li + 1]) ++li;
         const int q = k - ca.per_xcd_prefix[li];
         const GemmArgs& a = ca.args[li];
-        const int mblocks = a.mblocks;
-        const int tile = xcd * a.xcd_span + q / mblocks;
+        const int tile = xcd * a.xcd_span + q / a.mblocks;
         const bool is_gate = (li & 1) == 0;
         const int l = li >> 1;
-        if (tile < ca.tiles) {
-            // ---- wait for the producers of exactly the rows this tile reads
-            if (tid < 64) {
-                const int32_t* flag = nullptr; int need = 0;
-                if (is_gate) {
-                    if (l > 0 && tid < 6) {
-                        const int bl = tile / ca.tiles_per_utt, tt = tile - bl * ca.tiles_per_utt;
-                        const int r0 = tt * 128 - (2 - (tid >> 1)) * ca.dil[l] + (tid & 1) * 127;        // first / last row of tap tid >> 1
-                        if (r0 >= 0) { flag = ca.done + (size_t)(2 * (l - 1) + 1) * ca.tiles + bl * ca.tiles_per_utt + min(r0 >> 7, ca.tiles_per_utt - 1); need = 1; }
-                    }
-                } else if (tid == 0) { flag = ca.done + (size_t)li * ca.tiles - ca.tiles + tile; need = 2; }      // gate(l) is launch li - 1
-                if (flag) {
-                    int spins = 0;
-                    while (ld_acq(flag) < need) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spins > 20000000) { *ca.abort_flag = 1 + li; break; }
-                        if ((spins & 1023) == 0 && ld_acq(ca.abort_flag)) break;
-                    }
-                }
+        if (tile >= ca.tiles) continue;                                   // (wave-uniform: padding of the last span)
+        if (wave == 0) {
+            // ---- wait for the producers of exactly the rows this tile reads: lanes 0..5 = first / last row of the three taps (gate),
+            // lane 0 = both M-blocks of the gate tile (out conv); the other lanes watch a word that is always satisfied
+            const int32_t* flag = ca.always; int need = 1;
+            const int bl = tile / ca.tiles_per_utt, tt = tile - bl * ca.tiles_per_utt;
+            const int r0 = tt * 128 - (2 - (lane >> 1)) * ca.dil[l] + (lane & 1) * 127;
+            const bool gate_dep = is_gate && l > 0 && lane < 6 && r0 >= 0;
+            const bool out_dep = !is_gate && lane == 0;
+            if (gate_dep) flag = ca.done + (size_t)(2 * (l - 1) + 1) * ca.tiles + bl * ca.tiles_per_utt + min(r0 >> 7, ca.tiles_per_utt - 1);
+            if (out_dep) { flag = ca.done + (size_t)(li - 1) * ca.tiles + tile; need = 2; }
+            int spins = 0;
+            for (;;) {
+                const bool ok = ld_acq(flag) >= need;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;         // wave-uniform exit
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > 200000) { __hip_atomic_store(ca.abort_flag, 1 + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                   // agent scope: this workgroup's loads see the producers' stores
+        }
+        __syncthreads();
+        if (!(ca.flags & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // agent scope: this workgroup's loads see the producers' stores
+        if (!(ca.flags & 2)) {
             if (is_gate) wn_gemm_lds_body<2, 2, 4, 2, 32, 3, EPI_GATE, 1, 3>(a, lds, q * 8 + xcd);
             else wn_gemm_lds_body<2, 2, 4, 2, 32, 3, EPI_STORE_BF16, 1, 0>(a, lds, q * 8 + xcd);
-            __syncthreads();                                              // every wave's stores are issued and acknowledged (vmcnt(0))
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                // agent scope: L2 write-back towards the other XCDs
-                __hip_atomic_fetch_add(ca.done + (size_t)li * ca.tiles + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        }
+        __syncthreads();                                                  // every wave's stores are issued and acknowledged (vmcnt(0))
+        if (wave == 0) {
+            if (!(ca.flags & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // agent scope: L2 write-back towards the other XCDs
+            int32_t* dst = lane == 0 ? ca.done + (size_t)li * ca.tiles + tile : ca.dummy + lane * 16;      // one atomic per lane, 63 of them on dummy lines
+            __hip_atomic_fetch_add(dst, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid == 0) atomicMax(ca.t_last, (unsigned long long)wall_clock64());
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int B = 8, T = 11000, R = 256, G = 512, GH = 256, C = 80;
     const int NL = 6; const int dil[NL] = {1, 8, 128, 512, 1024, 2048};
     const int64_t NT = (int64_t)B * T;
@@ -160,7 +179,8 @@ int main(int argc, char** argv) {
     // ---- persistent chain state
     ChainArgs ca; memset(&ca, 0, sizeof ca);
     std::vector<GemmArgs> hargs(2 * NL);
-    ca.nl = NL; ca.per_xcd_prefix[0] = 0;
+    ca.nl = NL; ca.per_xcd_prefix[0] = 0; ca.flags = argc > 1 ? atoi(argv[1]) : 0;
+    printf("debug flags %d\n", ca.flags);
     for (int l = 0; l < NL; ++l) {
         hargs[2 * l] = mk_gate(l, 0, B); int g0 = prep(hargs[2 * l], G, 128); hargs[2 * l].stagger = 0;
         hargs[2 * l + 1] = mk_out(l, 0, B); int g1 = prep(hargs[2 * l + 1], R, 128); hargs[2 * l + 1].stagger = 0;
@@ -170,12 +190,13 @@ int main(int argc, char** argv) {
     }
     ca.tiles = hargs[0].ntiles; ca.tiles_per_utt = hargs[0].tiles_per_utt;
     CK(hipMalloc(&ca.args, sizeof(GemmArgs) * 2 * NL)); CK(hipMemcpy(ca.args, hargs.data(), sizeof(GemmArgs) * 2 * NL, hipMemcpyHostToDevice));
-    const size_t state_ints = 8 * 32 + (size_t)2 * NL * ca.tiles + 32;
+    const size_t state_ints = 8 * 32 + (size_t)2 * NL * ca.tiles + 32 + 64 * 16;
     int32_t* state; CK(hipMalloc(&state, state_ints * 4 + 64));
-    ca.ticket = state; ca.done = state + 8 * 32; ca.abort_flag = state + 8 * 32 + (size_t)2 * NL * ca.tiles;
+    ca.ticket = state; ca.done = state + 8 * 32; ca.abort_flag = state + 8 * 32 + (size_t)2 * NL * ca.tiles; ca.dummy = ca.abort_flag + 32;
+    int32_t* always_dev; CK(hipMalloc(&always_dev, 64)); { int32_t big = 1 << 30; CK(hipMemcpy(always_dev, &big, 4, hipMemcpyHostToDevice)); } ca.always = always_dev;
     unsigned long long* stamps; CK(hipMalloc(&stamps, 16)); ca.t_first = stamps; ca.t_last = stamps + 1;
     int nres = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nres, chain_kernel, 512, 0));
-    const int grid_c = 256 * std::max(1, nres);
+    const int grid_c = 256 * std::max(1, nres); ca.n_per_xcd = grid_c / 8;
     printf("persistent chain: %d layers, %d tiles, %d tickets per XCD, %d workgroups resident per CU -> grid %d\n", NL, ca.tiles, ca.per_xcd_prefix[2 * NL], nres, grid_c);
     auto run_C = [&]() {
         CK(hipMemsetAsync(state, 0, state_ints * 4, s0));
@@ -186,14 +207,20 @@ int main(int argc, char** argv) {
     std::vector<bf16_t> ref((size_t)NT * R), got((size_t)NT * R);
     auto top = [&](std::vector<bf16_t>& v) { CK(hipDeviceSynchronize()); CK(hipMemcpy(v.data(), X + (size_t)NL * NT * R, (size_t)NT * R * 2, hipMemcpyDeviceToHost)); };
     auto clear_top = [&]() { for (int l = 1; l <= NL; ++l) { CK(hipMemset(X + (size_t)l * NT * R, 0, (size_t)NT * R * 2)); CK(hipMemset(XD + (size_t)l * NT * R, 0, (size_t)NT * R * 2)); } };
-    run_B(); top(ref);
+    printf("single stream ...\n"); run_B(); top(ref); printf("  done\n");
     auto compare = [&](const char* name) {
         top(got); size_t bad = 0; double md = 0;
         for (size_t i = 0; i < ref.size(); ++i) { if (ref[i] != got[i]) { ++bad; md = std::max(md, (double)fabsf(bf2f(ref[i]) - bf2f(got[i]))); } }
         printf("  %-28s top-layer output vs single stream: %zu of %zu elements differ (max |diff| %.3g)\n", name, bad, ref.size(), md);
     };
     clear_top(); run_A(); compare("two streams (production)");
-    clear_top(); run_C(); compare("persistent chain");
+    printf("persistent chain ...\n"); clear_top(); run_C();
+    {   // watchdog: a hung persistent kernel is reported instead of waited for
+        int waited = 0;
+        while (hipStreamQuery(s0) == hipErrorNotReady && waited < 100) { usleep(100000); ++waited; }
+        if (hipStreamQuery(s0) == hipErrorNotReady) { printf("  HUNG after 10 s\n"); fflush(stdout); _exit(3); }
+    }
+    compare("persistent chain");
     { int ab = 0; CK(hipMemcpy(&ab, ca.abort_flag, 4, hipMemcpyDeviceToHost)); if (ab) printf("  !! persistent chain: a dependency wait timed out (launch %d)\n", ab - 1); }
 
     const int REPS = 5;

@@ -1,6 +1,10 @@
 // Does running the two half-batches of the (serial) layer chain on two streams overlap the MFMA/power-bound gate GEMM of one
 // half with the HBM-bound out conv of the other?   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc -I tools tools/overlap_harness.hip -o tools/overlap_harness
+#ifdef USE_PRODUCTION_TILE
+#include "wn_tile.h"
+#else
 #include "wn_tile_variants.h"
+#endif
 #include <vector>
 #include <random>
 std::string g_create_err;
