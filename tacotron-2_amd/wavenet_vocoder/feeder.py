@@ -79,6 +79,7 @@ class Feeder(object):
         self._eval_q = queue.Queue(maxsize=1)
         self._threads = []
         self._errors = {}
+        self._pin_pool, self._pin_lock = {}, threading.Lock()
 
     # ------------------------------------------------------------------ threads
     def start_threads(self, session=None):
@@ -110,13 +111,34 @@ class Feeder(object):
             self._errors[id(q)] = e
             self._put(q, _FeederError(e))
 
-    @staticmethod
-    def _pin(batch):
+    def _pin(self, batch):
         """numpy batch -> page-locked host tensors (in the producer thread, off the step's critical path): the H2D copies of
-        next_*_batch are then truly asynchronous (``non_blocking`` from pageable memory is a synchronous staged copy)."""
+        next_*_batch are then truly asynchronous (``non_blocking`` from pageable memory is a synchronous staged copy).  The pinned
+        buffers come from a small per-shape ring: ``tensor.pin_memory()`` allocates page-locked memory on every call (a driver call of
+        ~1 ms per tensor: four per batch made the PRODUCER the bottleneck of a 10 ms step, bench.py ``with_feeder``)."""
         if not torch.cuda.is_available():
             return batch
-        return tuple(None if b is None else torch.from_numpy(b).pin_memory() for b in batch)
+        return tuple(None if b is None else self._pinned_copy(b) for b in batch)
+
+    _PIN_RING = 14      # >= queue depth (8) + the batch being built + the two the consumer keeps referenced while their copies fly + slack
+
+    def _pinned_copy(self, arr):
+        src = torch.from_numpy(arr)
+        key = (arr.dtype.str, arr.shape)
+        with self._pin_lock:                        # (the train and the eval producer share the pool)
+            ring = self._pin_pool.get(key)
+            if ring is None:
+                if len(self._pin_pool) >= 64:       # many distinct padded lengths (real data): drop the oldest shape's ring
+                    self._pin_pool.pop(next(iter(self._pin_pool)))
+                ring = self._pin_pool[key] = {'bufs': [], 'next': 0}
+            if len(ring['bufs']) < self._PIN_RING:
+                buf = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                ring['bufs'].append(buf)
+            else:
+                buf = ring['bufs'][ring['next'] % self._PIN_RING]
+            ring['next'] += 1
+        buf.copy_(src)
+        return buf
 
     def _put(self, q, item):
         """Blocking put that gives up when the coordinator stops (returns True then)."""
