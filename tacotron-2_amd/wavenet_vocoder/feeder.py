@@ -80,9 +80,17 @@ class Feeder(object):
         self._threads = []
         self._errors = {}
         self._pin_pool, self._pin_lock = {}, threading.Lock()
+        self._len_cache = {}
+        self._ahead, self._copy_stream = None, None
 
     # ------------------------------------------------------------------ threads
     def start_threads(self, session=None):
+        # The producers are Python threads: while one holds the GIL in pure-Python code the training loop waits for the interpreter's
+        # switch interval (5 ms by default -- half a training step) before it can enqueue the next kernels.  0.5 ms keeps the hand-off
+        # latency far below the ~9 ms of device work the loop is ahead by (bench.py with_feeder: 10.6 -> see profiles/).
+        import sys
+        if sys.getswitchinterval() > 5e-4:
+            sys.setswitchinterval(5e-4)
         for target in (self._enqueue_next_train_group, self._enqueue_next_test_group):
             t = threading.Thread(name='background', target=target, daemon=True)
             t.start()
@@ -120,7 +128,7 @@ class Feeder(object):
             return batch
         return tuple(None if b is None else self._pinned_copy(b) for b in batch)
 
-    _PIN_RING = 14      # >= queue depth (8) + the batch being built + the two the consumer keeps referenced while their copies fly + slack
+    _PIN_RING = 16      # >= queue depth (8) + the batch being built + the three the consumer keeps referenced while their copies fly + slack
 
     def _pinned_copy(self, arr):
         src = torch.from_numpy(arr)
@@ -170,7 +178,46 @@ class Feeder(object):
             return item
 
     def next_train_batch(self):
-        return self._to_device(self._get(self._train_q))
+        """The next training batch as device tensors.  On a GPU the batch AFTER this one is already on its way: its H2D copies run on a
+        copy stream while the current step computes (issued on the compute stream they cost the step ~0.1 ms of serialised SDMA launches
+        at its very start), and the compute stream only waits for an event that has normally fired long ago.  A producer error met while
+        prefetching is raised when THAT batch is asked for, so batches and errors keep their order."""
+        dev = self._device or torch.device('cuda', torch.cuda.current_device())
+        if dev.type != 'cuda':
+            return self._to_device(self._get(self._train_q))
+        if self._ahead is None:
+            self._ahead = self._start_copy(self._get(self._train_q), dev)
+        if isinstance(self._ahead, BaseException):
+            err, self._ahead = self._ahead, None
+            raise err
+        tensors, ev = self._ahead
+        self._ahead = None
+        try:                                   # start the following batch if the producer already has it (never block for it here)
+            item = self._train_q.get_nowait()
+            if isinstance(item, _FeederError):
+                self._ahead = RuntimeError('feeder thread failed: {!r}'.format(item.error))
+                self._ahead.__cause__ = item.error
+            else:
+                self._ahead = self._start_copy(item, dev)
+        except queue.Empty:
+            pass
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(ev)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cur)            # allocated on the copy stream, used on the compute stream
+        return tensors
+
+    def _start_copy(self, batch, dev):
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        host = tuple(None if b is None else (b if torch.is_tensor(b) else torch.from_numpy(b)) for b in batch)
+        self._inflight = (getattr(self, '_inflight', ()) + (host,))[-3:]      # pinned sources outlive their copies
+        with torch.cuda.stream(self._copy_stream):
+            tensors = tuple(None if b is None else b.to(dev, non_blocking=True) for b in host)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        return tensors, ev
 
     def next_eval_batch(self):
         return self._to_device(self._get(self._eval_q))
@@ -217,7 +264,15 @@ class Feeder(object):
             if self._test_offset >= len(meta_list):
                 self._test_offset = 0
             meta = meta_list[self._test_offset]; self._test_offset += 1
-        return meta, int(np.load(self._resolve(meta[0]), mmap_mode='r').shape[0])
+        return meta, self._length_of(meta[0])
+
+    def _length_of(self, audio_path):
+        """Samples of an utterance from its .npy header, read once per file (the bucketing of every 64-batch group needs 512 lengths:
+        an mmap open per utterance and step was ~0.5 ms of GIL-holding work per step in the producer thread)."""
+        n = self._len_cache.get(audio_path)
+        if n is None:
+            n = self._len_cache[audio_path] = int(np.load(self._resolve(audio_path), mmap_mode='r').shape[0])
+        return n
 
     def _load_example(self, meta):
         hp = self._hparams
