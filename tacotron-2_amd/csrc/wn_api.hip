@@ -148,7 +148,7 @@ static int alloc_workspace(wn_ctx* c) {
         sz((size_t)c->uppart_floats * 4);
     }
     sz(NT * 4); sz(NT * c->C * 4);          // XIN, CIN
-    sz((size_t)2 * 1024 * 2 * 1024 * 4);    // wn_colsum2 partials (2 regions)
+    sz((size_t)WN_CS_SLOTS * WN_CS_MAXBLK * 2 * 1024 * 4);    // wn_colsum2 partials (WN_CS_SLOTS regions)
     sz(256);                               // scalars
     sz(256);                               // zero page
     c->ws_bytes = total;
@@ -172,7 +172,7 @@ static int alloc_workspace(wn_ctx* c) {
     c->DCUP[0] = (float*)bump(p, NT * c->C * 4); c->DCUP[1] = (float*)bump(p, NT * c->C * 4);
     c->UPPART = (float*)bump(p, (size_t)c->uppart_floats * 4);
     c->XIN = (void*)bump(p, NT * 4); c->CIN = (float*)bump(p, NT * c->C * 4);
-    c->cs_part = (float*)bump(p, (size_t)2 * 1024 * 2 * 1024 * 4);
+    c->cs_part = (float*)bump(p, (size_t)WN_CS_SLOTS * WN_CS_MAXBLK * 2 * 1024 * 4);      // exactly what wn_colsum2 addresses (was twice that: ADVICE round 3)
     c->scal = (float*)bump(p, 256);
     c->zero_page = (bf16_t*)bump(p, 256);
     if (hipMemset(c->zero_page, 0, 256) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");

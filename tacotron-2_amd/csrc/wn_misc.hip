@@ -261,7 +261,6 @@ __global__ void wn_first_conv_bwd_ids(const int32_t* __restrict__ ids, const bf1
 // Two stages in a fixed order, no atomics (bit-reproducible): part[blk][0][c], part[blk][1][c], then wn_colsum2_reduce.
 // (Round 2's input-conv gradient walked 128 rows per block one 2-byte load at a time and finished with float atomics: 77 us alone,
 // 0.5 ms beside the weight-gradient kernels.  This one reads 16 B per lane: scalar-input d W / d b and the head-bias column sums.)
-#define WN_CS_MAXBLK 512
 __global__ __launch_bounds__(256) void wn_colsum2_kernel(const bf16_t* __restrict__ M, int ld, int ncols, const float* __restrict__ xw,
                                                          int64_t rows, int rows_per_block, float* __restrict__ part) {
     __shared__ float red[2][2048];                   // [b | w][row lane][ncols]   (row lanes * ncols <= 2048)
