@@ -315,8 +315,34 @@ extern "C" int wn_tensor_info(const wn_ctx* c, int i, char* name, int32_t* shape
 extern "C" int64_t wn_workspace_bytes(const wn_ctx* c) { return c ? (int64_t)(c->ws_bytes + c->wg_partial_bytes) : (int64_t)WN_E_ARG; }
 extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, 0, 1, 3>"; }
 
+// rocTX ranges around the host side of the drop-in entry points (tracing): `rocprofv3 --marker-trace --kernel-trace` then
+// shows which call enqueued which kernels.  The marker library is looked up at run time (dlopen of libroctx64.so / the SDK's
+// librocprofiler-sdk-roctx.so; no link dependency) and only when WN_ROCTX=1: otherwise a range costs one predictable branch.
+#include <dlfcn.h>
+struct WnRoctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    WnRoctx() {
+        const char* e = getenv("WN_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "/opt/rocm/lib/libroctx64.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+static WnRoctx& wn_roctx() { static WnRoctx r; return r; }
+struct WnRange {
+    bool on;
+    explicit WnRange(const char* name) : on(wn_roctx().push != nullptr) { if (on) wn_roctx().push(name); }
+    ~WnRange() { if (on) wn_roctx().pop(); }
+};
+
 extern "C" int wn_pack_weights(wn_ctx* c, const float* params, void* stream) {
     if (!c || !params) return WN_E_ARG;
+    WnRange range("wn_pack_weights");
     return wn_launch_pack(c, params, (hipStream_t)stream);
 }
 
@@ -354,6 +380,7 @@ static int check_fwd_args(wn_ctx* c, const void* x, const float* cc, const void*
 extern "C" int wn_train_fwd(wn_ctx* c, const void* x, const float* cc, const void* y, const int32_t* lengths,
                             int32_t B, int32_t T, int32_t Tc, uint64_t seed, float* loss_out, float* y_hat_out, void* stream) {
     if (!c) return WN_E_ARG;
+    WnRange range("wn_train_fwd");
     if (c->inference) WN_FAIL(c, WN_E_STATE, "wn_train_fwd on an inference-only context (cfg.inference_only = 1)");
     int rc = check_fwd_args(c, x, cc, y, lengths, B, T, Tc);
     if (rc) return rc;
@@ -369,12 +396,14 @@ extern "C" int wn_train_fwd(wn_ctx* c, const void* x, const float* cc, const voi
 
 extern "C" int wn_train_bwd(wn_ctx* c, float* grads, void* stream) {
     if (!c || !grads) return WN_E_ARG;
+    WnRange range("wn_train_bwd");
     if (!c->have_fwd) WN_FAIL(c, WN_E_STATE, "wn_train_bwd called without a preceding successful wn_train_fwd");
     return wn_bwd_impl(c, grads, (hipStream_t)stream);
 }
 
 extern "C" int wn_optim_step(wn_ctx* c, float* p, const float* g, float* m, float* v, float* ema, float lr, int64_t step, void* stream) {
     if (!c || !p || !g || !m || !v || !ema) return WN_E_ARG;
+    WnRange range("wn_optim_step");
     if (c->inference) WN_FAIL(c, WN_E_STATE, "wn_optim_step on an inference-only context (cfg.inference_only = 1)");
     return wn_optim_impl(c, p, g, m, v, ema, lr, step, (hipStream_t)stream);
 }
@@ -389,6 +418,7 @@ extern "C" int wn_get_upsampled_features(wn_ctx* c, float* out, void* stream) {
 extern "C" int wn_synthesize(wn_ctx* c, const float* cc, int32_t B, int32_t Tc, const float* noise, uint64_t seed,
                              const void* test_inputs, void* out_samples, float* out_raw, int32_t steps_per_graph, void* stream) {
     if (!c || !cc || !out_samples) return WN_E_ARG;
+    WnRange range("wn_synthesize");
     if (!c->packed) WN_FAIL(c, WN_E_STATE, "wn_pack_weights must be called before wn_synthesize");
     if (B <= 0 || B > 32) WN_FAIL(c, WN_E_SHAPE, "synthesis batch %d outside (0, 32]", B);
     if (Tc <= 0) WN_FAIL(c, WN_E_SHAPE, "Tc must be positive");

@@ -10,6 +10,7 @@
 #   benchq       short bench (no synth / cpu baseline / other workloads) -> benchq.json
 #   ab:<name>=<ENV=V>[,<ENV=V>]   one A/B arm of the short bench (appends to ab.txt); `ab:base=` for the baseline
 #   kt           rocprofv3 kernel trace + stats of the bench step (live, two streams) -> kernel_stats.csv, timeline.txt
+#   roctx        WN_ROCTX=1: rocTX ranges of the C-ABI entry points in a rocprofv3 marker + kernel trace -> roctx_marker_stats.csv
 #   serial       the same with every kernel alone on one stream (exclusive kernel times) -> serial_kernel_stats.csv
 #   pmc          FETCH_SIZE and WRITE_SIZE passes -> pmc_fetch.md, pmc_write.md, traffic.json (bench.py loads the committed copy)
 #   sq           SQ counter passes of the bench step -> pmc_sq.md
@@ -41,6 +42,10 @@ for st in "$@"; do
       f=$(find $OUT/kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv
       f=$(find $OUT/kt -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python tools/timeline.py $f 1 --detail > $OUT/timeline.txt 2>&1
       rm -rf $OUT/kt; head -14 $OUT/timeline.txt ;;
+    roctx) cd /tmp; WN_ROCTX=1 timeout 400 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $OUT/roctx -o c2 -- python $R/bench.py --steps 5 --warmup 2 $BQ --no-feeder > $OUT/roctx.log 2>&1; cd $R
+      f=$(find $OUT/roctx -name '*marker_api_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/roctx_marker_stats.csv
+      f=$(find $OUT/roctx -name '*marker_api_trace.csv' | head -1); [ -n "$f" ] && head -60 $f > $OUT/roctx_marker_trace_head.csv
+      rm -rf $OUT/roctx; cat $OUT/roctx_marker_stats.csv 2>/dev/null | cut -c1-160 ;;
     ktw:*) w=${st#ktw:}; cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktw -o w -- python $R/bench.py --workload $w --steps 10 --warmup 5 $BQ > $OUT/ktw_$w.log 2>&1; cd $R
       f=$(find $OUT/ktw -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_$w.csv
       rm -rf $OUT/ktw; tail -2 $OUT/ktw_$w.log | cut -c1-200; head -16 $OUT/kernel_stats_$w.csv | cut -c1-160 ;;
