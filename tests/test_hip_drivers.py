@@ -89,3 +89,49 @@ def test_train_checkpoint_restore_synthesize(tmp_path, gin):
     from scipy.io import wavfile
     sr, data = wavfile.read(wavs[0])
     assert sr == hp.sample_rate and len(data) == 6 * 16 and np.abs(data).max() > 0
+
+
+def test_feeder_prefetch_keeps_batches_and_errors_in_order(tmp_path):
+    """The GPU path of Feeder.next_train_batch copies the NEXT batch to the device on a copy stream while the current step runs
+    (round 4).  Same batches, in the same order, as the plain path of a second feeder over the same files (CPU tensors); device
+    tensors equal their pinned sources; and a broken utterance still surfaces as 'feeder thread failed' on the call that would have
+    returned its batch -- after every good batch before it, not one call early."""
+    import hparams as H
+    from wavenet_vocoder import feeder as F
+    from wavenet_vocoder.train import _Coordinator
+    root = str(tmp_path)
+    meta = os.path.join(root, _dataset(root, n=24))
+    hp = H._build()
+    hp.parse('hop_size=16,num_mels=16,cin_channels=16,upsample_scales=[4,4],max_time_steps=512,wavenet_batch_size=4,wavenet_test_batches=1')
+    co = [_Coordinator(), _Coordinator()]
+    fd_gpu = F.Feeder(co[0], meta, root, hp)
+    fd_cpu = F.Feeder(co[1], meta, root, hp, device=torch.device('cpu'))
+    fd_gpu.start_threads(); fd_cpu.start_threads()
+    try:
+        for _ in range(70):                       # more than one 64-batch group: the order rng advances identically in both
+            a, b = fd_gpu.next_train_batch(), fd_cpu.next_train_batch()
+            torch.cuda.synchronize()
+            for ta, tb in zip(a, b):
+                assert (ta is None) == (tb is None)
+                if ta is not None:
+                    assert ta.is_cuda and torch.equal(ta.cpu(), tb)
+    finally:
+        for c in co:
+            c.request_stop()
+    # a broken utterance: every batch the plain path delivers before the error is delivered by the prefetching path too
+    bad = os.path.join(root, F.Feeder(None, meta, root, hp, device=torch.device('cpu'))._train_meta[3][0])      # an utterance of the TRAIN split
+    np.save(bad, np.load(bad)[:-2])               # audio / mel length mismatch
+    counts = []
+    for dev in (None, torch.device('cpu')):
+        c = _Coordinator()
+        fd = F.Feeder(c, meta, root, hp, device=dev)
+        fd.start_threads()
+        n = 0
+        try:
+            with pytest.raises(RuntimeError, match='feeder thread failed'):
+                for _ in range(300):
+                    fd.next_train_batch(); n += 1
+        finally:
+            c.request_stop()
+        counts.append(n)
+    assert counts[0] == counts[1] and counts[0] < 300, counts
