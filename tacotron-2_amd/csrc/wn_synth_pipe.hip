@@ -603,7 +603,7 @@ bool wn_pipe_eligible(const wn_ctx* c, int B) {
     const int R = c->R, S = c->S, C = c->C, GH = c->GH, L = c->L;
     if (GH % 32 || R % 8 || S % 8 || C % 8 || R > 512) return false;
     const int P = GH / 32;
-    if (P > 8 || L > 32 || B > 32 || R > 384 || S > 384 || c->OP > 256) return false;      // (B: 256 B of LDS per stream, checked below; the head CU serves ~2 us per stream and step, so > 17 streams pace the ring)
+    if (P > 8 || L > 32 || B > 32 || R > 384 || S > 384 || c->OP > 256) return false;      // (B: 256 B of LDS per stream, checked below; beyond 8 streams a run costs + 4.2 us per stream and sample)
     const int spx = (L + 7) / 8;
     if (spx * P + 1 > 30) return false;                 // 32 CUs per XCD, keep slack
     const int64_t layer_static = 64LL * R * 2 + 64LL * (2 * R + C) * 2 + 32LL * R * 2 + 32LL * S * 2 + 256 + R * 4;
