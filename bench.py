@@ -201,11 +201,11 @@ def cpu_full_batch(hp, B=None, T=None):
     """The oracle on the WHOLE bench batch (not the bounded sample of cpu_baseline): forward + loss + autograd backward utterance by
     utterance (the masked-mean loss of the batch is the length-weighted mean of the per-utterance losses, so the gradients add up),
     then ONE clip + TF-Adam + EMA update -- the full training step on all host cores.  Run only on request (--cpu-full-batch): about a
-    minute on the GPU box's 256 cores, far more on a small host."""
+    minute with 64 threads (the bounded sample's rate: 2.4 k samples/s), far more on a small host; the caller bounds it (600 s)."""
     from collections import OrderedDict
     from oracle import wavenet_oracle as O
     B, T = B or 8, T or 11000
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)      # (256 intra-op threads on these layer-sized convolutions are slower than 64: the first run with all cores did not finish in 13 min)
     torch.set_num_threads(cores)
     cfg = O.OracleConfig.from_hparams(hp)
     T = T // cfg.hop * cfg.hop
@@ -530,7 +530,7 @@ def main():
     ap.add_argument('--no-synth', action='store_true')
     ap.add_argument('--no-other-workloads', action='store_true', help='skip the 10-step runs of c5_stress / default_hparams appended under other_workloads')
     ap.add_argument('--no-feeder', action='store_true', help='skip the untimed block of steps fed through the on-disk feeder (feeder -> pinned -> H2D)')
-    ap.add_argument('--cpu-full-batch', action='store_true', help='also RUN the oracle (forward + autograd backward) on the whole bench batch on the host cores (~1 min on the GPU box)')
+    ap.add_argument('--cpu-full-batch', action='store_true', help='also RUN the oracle training step on the whole bench batch on the host cores (64 threads; bounded at 600 s)')
     ap.add_argument('--no-exclusive', action='store_true', help='skip the untimed single-stream pass (keeps a rocprofv3 trace to the timed configuration)')
     ap.add_argument('--sustained', type=int, default=100, help='steps per block of the untimed-by-contract sustained measurement (3 blocks after the timed region; 0 = off)')
     ap.add_argument('--emulate-allreduce-gbps', type=float, default=0.0,
@@ -853,7 +853,7 @@ def main():
             res['cpu_baseline'] = cpu_baseline_subprocess(args.workload)
             if args.cpu_full_batch:          # measured here or absent: never a number quoted from a file
                 _log('cpu baseline on the full batch (oracle, ~1 min on 256 cores) ...')
-                res['cpu_baseline']['full_batch'] = cpu_baseline_subprocess(args.workload, hard_timeout=900, fn='cpu_full_batch')
+                res['cpu_baseline']['full_batch'] = cpu_baseline_subprocess(args.workload, hard_timeout=600, fn='cpu_full_batch')
             if not args.no_synth:
                 _log('cpu baseline, synthesis (oracle incremental loop) ...')
                 try:
