@@ -38,6 +38,7 @@ __device__ __forceinline__ void f32s_matvec(float* smem, const int K, Fill fill,
 #pragma unroll
         for (int s = 0; s < F32S_NS; ++s) acc[c][s] = 0.0f;
     const int kq = (K + 3) / 4, k0 = wave * kq, k1 = min(K, k0 + kq);
+#pragma unroll 8                                     // eight weight loads in flight per lane (same order of the additions)
     for (int k = k0; k < k1; ++k) {
         float w[NCOL];
 #pragma unroll

@@ -898,3 +898,43 @@ def test_device_timeline_summary_of_in_kernel_stamps(tmp_path):
     f = tmp_path / 'trace.txt'
     f.write_text('# idx epi stream rows start end\n' + ''.join('%d %d %s 1 %d %d\n' % (i, r[0], r[1], r[2], r[3]) for i, r in enumerate(rows)))
     assert devtrace.summarise(devtrace.parse_file(str(f))) == s
+
+
+def test_synthesis_driver_work_list_and_index_file(tmp_path, monkeypatch):
+    """wavenet_vocoder/synthesize.py (reference synthesize.py:14-82) with a stand-in Synthesizer: mel files in sorted order, chunks of
+    wavenet_synthesis_batch_size, speaker ids from --speaker_id; Tacotron-2 mode reads text|mel|speaker rows of the evaluation map.txt;
+    the index rows keep ALL their columns (the reference's format strings drop the last one)."""
+    import types
+    import hparams as H
+    from wavenet_vocoder import synthesize as S
+    d = tmp_path / 'mels'; d.mkdir()
+    for i in (2, 0, 1, 3, 4):
+        np.save(str(d / ('mel-%d.npy' % i)), np.zeros((3, 80), np.float32))
+    (d / 'notes.txt').write_text('not a mel')
+    calls = []
+
+    class FakeSynth:
+        def load(self, ckpt, hp):
+            self.ckpt = ckpt
+
+        def synthesize(self, mels, speakers, names, wav_dir, plot_dir):
+            calls.append((len(mels), speakers, names))
+            return [os.path.join(wav_dir, 'wavenet-audio-%s.wav' % n) for n in names]
+    monkeypatch.setattr(S, 'Synthesizer', FakeSynth)
+    hp = H._build(); hp.parse('wavenet_synthesis_batch_size=2')
+    out = str(tmp_path / 'out')
+    S.run_synthesis(types.SimpleNamespace(model='WaveNet', mels_dir=str(d), speaker_id='0,1, 2,0,1'), 'ckpt', out, hp)
+    assert [c[0] for c in calls] == [2, 2, 1] and calls[0][1] == ['0', '1'] and calls[2][2] == ['mel-4']
+    rows = [l.split('|') for l in open(os.path.join(out, 'wavs', 'map.txt')).read().strip().split('\n')]
+    assert len(rows) == 5 and all(len(r) == 3 for r in rows)
+    assert rows[0] == [str(d / 'mel-0.npy'), os.path.join(out, 'wavs', 'wavenet-audio-mel-0.wav'), '0'] and rows[4][2] == '1'
+    assert os.path.isdir(os.path.join(out, 'plots'))
+    # Tacotron-2 mode: the evaluation map.txt, no global conditioning
+    calls.clear()
+    (d / 'map.txt').write_text('hello world|%s|<no_g>\nsecond|%s|<no_g>\n' % (d / 'mel-1.npy', d / 'mel-3.npy'))
+    S.run_synthesis(types.SimpleNamespace(model='Tacotron-2', mels_dir=str(d), speaker_id=None), 'ckpt', out, hp)
+    assert calls == [(2, None, ['mel-1', 'mel-3'])]
+    rows = [l.split('|') for l in open(os.path.join(out, 'wavs', 'map.txt')).read().strip().split('\n')]
+    assert rows[0][0] == 'hello world' and rows[1][3] == '<no_g>' and all(len(r) == 4 for r in rows)
+    with pytest.raises(RuntimeError, match='Failed to load checkpoint'):
+        S.wavenet_synthesize(types.SimpleNamespace(model='WaveNet', mels_dir=str(d), speaker_id=None, output_dir='o/'), hp, str(tmp_path / 'nowhere'))
