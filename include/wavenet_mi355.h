@@ -208,8 +208,8 @@ int wn_synth_last_path(const wn_ctx* ctx);
 /* 1 if wn_synthesize(steps_per_graph <= 0) would run B streams of this model on the persistent pipeline (all of a CU's weights must
  * fit its 160 KiB of LDS next to 256 B of state per stream: one CU per 32 gate pairs, <= 8 CUs per layer, R, S <= 384, B <= 32), 0 if
  * it would take the launch-per-layer hipGraph path.  Host helper: a caller sends the whole batch in one run when this says 1 for it
- * (8 streams cost the wall time of one -- 34 - 37 us per sample --, every further stream adds ~4.2 us per sample: real time at
- * 22.05 kHz up to 10 streams per run, profiles/r5p_pipe_batch_scaling.txt), else groups of 8. */
+ * (10 streams cost the wall time of one -- 34 - 37 us per sample --, every further stream adds ~3.6 us per sample: real time at
+ * 22.05 kHz up to 12 streams per run, profiles/r5u_pipe_batch_scaling.txt), else groups of 8. */
 int wn_synth_pipe_eligible(const wn_ctx* ctx, int32_t B);
 
 /* Stand-alone samplers on [B,O,T] parameters (train-time log path, wavenet.py:302-325). */

@@ -58,6 +58,9 @@ __device__ __forceinline__ void st_g16_local(u32x4* p, u32x4 v) { asm volatile("
 __device__ __forceinline__ u32x4 ld_g16(const u32x4* p) {
     u32x4 v; asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v;
 }
+// the same load WITHOUT the wait: the caller waits by hand (pf_wait) before touching the register
+__device__ __forceinline__ void ld_g16_nowait(u32x4& v, const u32x4* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void pf_wait(u32x4& a, u32x4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) :: "memory"); }
 __device__ __forceinline__ void ld2_g16(const u32x4* p0, const u32x4* p1, u32x4& v0, u32x4& v1) {
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
@@ -218,6 +221,54 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
             lds_barrier();
         };
         for (int s = 0; s < B; ++s) precompute(s, 0, false);
+        // Inside the sample loop the pre-multiplication is split (round 4): its ring reads -- rows written >= d samples ago, HBM latency
+        // once the streams' queues exceed L2 -- are REQUESTED by wave 3 right after this CU published its x partial and CONSUMED after the
+        // skip chain, so their latency lies under the skip matvec and the wait for the previous layer's running sum instead of in front of
+        // the matvec.  Wave 3 on purpose: vmcnt retires in order per WAVE, and waves 0 / 1 poll the skip granules in between (a poll
+        // behind an older outstanding load would wait for it: the skip chain is the second latency-critical chain of the ring).
+        const int KR = 2 * R / 8;                                            // 16-B chunks of the two past taps
+        u32x4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0};
+        auto pre_issue = [&](int s, int tn, bool tap1_is_cur) {
+            if (wave != 3) return;
+            const bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = lane + 64 * q, k = i * 8;
+                u32x4& dst = q ? pf1 : pf0;
+                dst = (u32x4){0, 0, 0, 0};
+                if (i < KR) {
+                    const bool tap0 = k < R;
+                    const int tau = tn - (tap0 ? 2 * d : d);
+                    if (tau >= 0 && (tap0 || !tap1_is_cur)) ld_g16_nowait(dst, reinterpret_cast<const u32x4*>(ringb + (int64_t)(tau & mask) * R + (tap0 ? k : k - R)));
+                }
+            }
+        };
+        auto pre_finish = [&](int s, int tn, bool tap1_is_cur) {
+            float gb = 0.0f;
+            if (a.gbias && tid < 64) gb = a.gbias[((int64_t)l * B + s) * a.G + (tid < 32 ? 32 * j + tid : a.GH + 32 * j + (tid - 32))];
+            if (wave == 3) {
+                pf_wait(pf0, pf1);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int i = lane + 64 * q, k = i * 8;
+                    if (i < KR) {
+                        uint4 v = __builtin_bit_cast(uint4, q ? pf1 : pf0);
+                        if (k >= R && tap1_is_cur && tn - d >= 0) v = *reinterpret_cast<const uint4*>(xcur_b + (k - R));
+                        *reinterpret_cast<uint4*>(vec + k) = v;
+                    }
+                }
+            }
+            for (int i = KR + tid; i < KP; i += PIPE_THREADS)                // the conditioning chunks
+                *reinterpret_cast<uint4*>(vec + i * 8) = *reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (i * 8 - 2 * R));
+            lds_barrier();
+            {
+                const int per = (KP + 3) / 4, kc0 = wave * per, kc1 = min(KP, kc0 + per);
+                zpart[wave * 64 + lane] = mv_rows(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
+            }
+            lds_barrier();
+            if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + (a.gbias ? gb : zb[tid]);
+            lds_barrier();
+        };
 
         // ---- fast path (R == 256): the critical-path weights live in REGISTERS for the whole utterance.
         //   z rows: wave w owns gate pairs 8w..8w+7; lane = (pair = lane>>3, k8 = lane&7: a 32-channel eighth of K) holds BOTH rows
@@ -349,6 +400,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 }
                 lds_barrier();
                 if (a.trace && (!fast || top) && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
+                if (t + 1 < T) pre_issue(s, t + 1, d == 1);          // wave 3: ring reads of this stream's NEXT sample, consumed in step 5
                 // ---- 4. skip chain: running sum of CU (l-1, j) + W_skip[:, mine] u_mine  -> CU (l+1, j) / head (wavenet.py:833-836)
                 {
                     // own contribution first (the running sum of CU (l-1, j) is published ~1 us after its x partial: no point in
@@ -383,7 +435,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
                     for (int i = tid; i < R / 8; i += PIPE_THREADS)
                         *reinterpret_cast<uint4*>(ringb + (int64_t)(t & mask) * R + i * 8) = *reinterpret_cast<const uint4*>(xcur_b + i * 8);
-                    if (t + 1 < T) precompute(s, t + 1, d == 1);      // ring rows are read past this CU's L1 (sc1): slots are recycled
+                    if (t + 1 < T) pre_finish(s, t + 1, d == 1);      // ring rows are read past this CU's L1 (sc1): slots are recycled
                 }
                 if (pipe_aborted(abortf)) return;
             }
@@ -603,7 +655,7 @@ bool wn_pipe_eligible(const wn_ctx* c, int B) {
     const int R = c->R, S = c->S, C = c->C, GH = c->GH, L = c->L;
     if (GH % 32 || R % 8 || S % 8 || C % 8 || R > 512) return false;
     const int P = GH / 32;
-    if (P > 8 || L > 32 || B > 32 || R > 384 || S > 384 || c->OP > 256) return false;      // (B: 256 B of LDS per stream, checked below; beyond 8 streams a run costs + 4.2 us per stream and sample)
+    if (P > 8 || L > 32 || B > 32 || R > 384 || S > 384 || c->OP > 256) return false;      // (B: 256 B of LDS per stream, checked below; beyond 10 streams a run costs + 3.6 us per stream and sample)
     const int spx = (L + 7) / 8;
     if (spx * P + 1 > 30) return false;                 // 32 CUs per XCD, keep slack
     const int64_t layer_static = 64LL * R * 2 + 64LL * (2 * R + C) * 2 + 32LL * R * 2 + 32LL * S * 2 + 256 + R * 4;

@@ -279,9 +279,9 @@ class WaveNet(object):
             gt = torch.as_tensor(g, device=self.device).reshape(B, -1)
 
         def run(spg_):
-            # The persistent pipeline pipelines the streams of a run through its layer ring: 8 streams at the wall time of one (34 - 37 us
-            # per sample: real time at 22.05 kHz), every further stream + 4.2 us per sample (profiles/r5p_pipe_batch_scaling.txt) -- one run
-            # of 20 streams (hparams.py: wavenet_synthesis_batch_size = 20) takes 2.3x the wall time of 8 where three groups of 8 took 3x.
+            # The persistent pipeline pipelines the streams of a run through its layer ring: 10 streams at the wall time of one (34 - 37 us
+            # per sample: real time at 22.05 kHz), every further stream + 3.6 us per sample (profiles/r5u_pipe_batch_scaling.txt) -- one run
+            # of 20 streams (hparams.py: wavenet_synthesis_batch_size = 20) takes 2.0x the wall time of 8 where three groups of 8 took 3x.
             # So: the whole batch in ONE run when its per-stream LDS state fits (wn_synth_pipe_eligible), else groups of 8 (streams are
             # independent: wavenet.py:237-239 splits them over towers).  Models the pipeline does not fit take the launch-per-layer graph
             # path, whose time per step is nearly independent of the batch: up to 32 streams per run.
