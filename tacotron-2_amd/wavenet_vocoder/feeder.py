@@ -32,6 +32,10 @@ def _interp(feats, in_range):
     return (feats - in_range[0]) / (in_range[1] - in_range[0])
 
 
+def _new_pinned(shape, dtype):
+    return torch.empty(shape, dtype=dtype, pin_memory=True)
+
+
 def _ranks():
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         return torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -109,7 +113,7 @@ class Feeder(object):
         try:
             while not self._should_stop():
                 for batch in self._iter_group(train=train):
-                    if self._put(q, self._pin(self._prepare_batch(batch))):
+                    if self._put(q, self._pin(self._prepare_batch(batch), train)):
                         return
         except BaseException as e:          # noqa: BLE001 -- forwarded, not swallowed
             # The error belongs to THIS queue: its consumer reaches it behind the good batches (blocking put; gives up only when the
@@ -119,28 +123,28 @@ class Feeder(object):
             self._errors[id(q)] = e
             self._put(q, _FeederError(e))
 
-    def _pin(self, batch):
+    def _pin(self, batch, train=True):
         """numpy batch -> page-locked host tensors (in the producer thread, off the step's critical path): the H2D copies of
         next_*_batch are then truly asynchronous (``non_blocking`` from pageable memory is a synchronous staged copy).  The pinned
         buffers come from a small per-shape ring: ``tensor.pin_memory()`` allocates page-locked memory on every call (a driver call of
         ~1 ms per tensor: four per batch made the PRODUCER the bottleneck of a 10 ms step, bench.py ``with_feeder``)."""
         if not torch.cuda.is_available():
             return batch
-        return tuple(None if b is None else self._pinned_copy(b) for b in batch)
+        return tuple(None if b is None else self._pinned_copy(b, train) for b in batch)
 
     _PIN_RING = 16      # >= queue depth (8) + the batch being built + the three the consumer keeps referenced while their copies fly + slack
 
-    def _pinned_copy(self, arr):
+    def _pinned_copy(self, arr, train=True):
         src = torch.from_numpy(arr)
-        key = (arr.dtype.str, arr.shape)
-        with self._pin_lock:                        # (the train and the eval producer share the pool)
+        key = (bool(train), arr.dtype.str, arr.shape)   # one ring per producer: a burst of same-shaped eval batches must not lap the train queue's buffers
+        with self._pin_lock:
             ring = self._pin_pool.get(key)
             if ring is None:
                 if len(self._pin_pool) >= 64:       # many distinct padded lengths (real data): drop the oldest shape's ring
                     self._pin_pool.pop(next(iter(self._pin_pool)))
                 ring = self._pin_pool[key] = {'bufs': [], 'next': 0}
             if len(ring['bufs']) < self._PIN_RING:
-                buf = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                buf = _new_pinned(src.shape, src.dtype)
                 ring['bufs'].append(buf)
             else:
                 buf = ring['bufs'][ring['next'] % self._PIN_RING]

@@ -693,6 +693,25 @@ def test_feeder_ranks_take_disjoint_slices_of_the_same_batches(tmp_path, monkeyp
         F.Feeder(None, meta, str(tmp_path), hp, device=torch.device('cpu'))
 
 
+def test_feeder_pinned_rings_are_per_producer(tmp_path, monkeypatch):
+    """The page-locked staging buffers are a ring per (producer, shape).  The train queue keeps up to 8 batches + the one being built + the
+    consumer's two alive; a burst of same-shaped eval batches (eval queue depth 1, but one batch per eval step) must not lap them."""
+    import hparams as H
+    from wavenet_vocoder import feeder as F
+    hp = H._build()
+    hp.parse('hop_size=16,num_mels=16,cin_channels=16,upsample_scales=[4,4],max_time_steps=500,wavenet_batch_size=4,wavenet_test_batches=1')
+    fd = F.Feeder(None, _write_dataset(str(tmp_path)), str(tmp_path), hp, device=torch.device('cpu'))
+    monkeypatch.setattr(F, '_new_pinned', lambda shape, dtype: torch.empty(shape, dtype=dtype))
+    live = [fd._pinned_copy(np.full((4, 7), float(i), np.float32), True) for i in range(12)]          # the train side's live set
+    for i in range(40):                                                                                 # an eval phase of the same shape
+        fd._pinned_copy(np.full((4, 7), -1.0 - i, np.float32), False)
+    for i, t in enumerate(live):
+        assert torch.equal(t, torch.full((4, 7), float(i))), i
+    # the ring itself wraps after _PIN_RING buffers of one producer (bounded page-locked memory)
+    again = [fd._pinned_copy(np.full((4, 7), 100.0 + i, np.float32), True) for i in range(fd._PIN_RING)]
+    assert again[4].data_ptr() == live[0].data_ptr() and len({t.data_ptr() for t in live + again}) == fd._PIN_RING
+
+
 def test_feeder_thread_errors_reach_the_training_loop(tmp_path):
     """A failure inside a background feeder thread (here: a mel file of the wrong length) is re-raised by next_train_batch -- AFTER the
     batches that were already queued -- instead of leaving the training loop blocked on an empty queue.  The producer must NOT stop the
