@@ -228,7 +228,11 @@ int wn_synth_f32_reserve(wn_ctx* c, int B) {
     const int L = c->L, R = c->R;
     if (s->capB < B) {
         if (c->inference && s->capB > 0) WN_FAIL(c, WN_E_SHAPE, "fp32 synthesis: %d streams exceed the %d this inference-only context was sized for", B, s->capB);
-        if (s->capB > 0) { (void)hipDeviceSynchronize(); for (float*& p : s->ring) { if (p) hipFree(p); p = nullptr; } }
+        if (s->capB > 0) {
+            (void)hipDeviceSynchronize();
+            for (float*& p : s->ring) { if (p) hipFree(p); p = nullptr; }
+            for (float** p : {&s->ucur, &s->skip_acc, &s->h2, &s->yraw}) { if (*p) hipFree(*p); *p = nullptr; }
+        }
         if (s->gexec) { hipGraphExecDestroy(s->gexec); s->gexec = nullptr; }
         s->ring.assign(L, nullptr); s->mask.assign(L, 0);
         for (int l = 0; l < L; ++l) {
@@ -236,12 +240,13 @@ int wn_synth_f32_reserve(wn_ctx* c, int B) {
             s->mask[l] = slots - 1;
             WN_HIP(c, hipMalloc((void**)&s->ring[l], (size_t)slots * B * R * 4));
         }
+        // per-step scratch, one row per stream, sized with the queues (wn_synthesize admits at most 32 streams)
+        WN_HIP(c, hipMalloc((void**)&s->ucur, (size_t)B * c->GH * 4));
+        WN_HIP(c, hipMalloc((void**)&s->skip_acc, (size_t)B * c->S * 4));
+        WN_HIP(c, hipMalloc((void**)&s->h2, (size_t)B * c->S * 4));
+        WN_HIP(c, hipMalloc((void**)&s->yraw, (size_t)B * c->OP * 4));
         s->capB = B;
     }
-    auto need = [&](float** p, size_t floats) -> int { if (!*p) WN_HIP(c, hipMalloc((void**)p, floats * 4)); return WN_OK; };
-    int rc;
-    if ((rc = need(&s->ucur, 32 * (size_t)c->GH)) || (rc = need(&s->skip_acc, 32 * (size_t)c->S)) || (rc = need(&s->h2, 32 * (size_t)c->S)) ||
-        (rc = need(&s->yraw, 32 * (size_t)c->OP))) return rc;
     if (!s->t_dev) WN_HIP(c, hipMalloc((void**)&s->t_dev, 4));
     if (!s->priv) WN_HIP(c, hipStreamCreateWithFlags(&s->priv, hipStreamNonBlocking));
     if (!s->ev0) WN_HIP(c, hipEventCreateWithFlags(&s->ev0, hipEventDisableTiming));

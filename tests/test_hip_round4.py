@@ -91,6 +91,26 @@ def test_fp32_synthesis_matches_fp32_oracle(kw):
     assert e < TOL_F32 and e_f < TOL_F32
 
 
+def test_fp32_synthesis_context_grows_with_the_batch():
+    """5 streams first (small queues and scratch), then the ABI's maximum of 32 on the same context (queues, per-step scratch and the
+    captured graph are rebuilt) -- against the fp32 oracle; the first 5 streams of the wide run equal the narrow run bit for bit
+    (streams are independent)."""
+    B, Tc = 32, 3
+    hp, cfg, eng, params, wav, c, T = _setup32(B, Tc)
+    nz_dev, nz_or = _noise(cfg, T, B)
+    out5 = torch.empty(5, T, device='cuda'); raw5 = torch.empty(5, cfg.out_channels, T, device='cuda')
+    eng.synthesize(c[:5].contiguous().cuda(), nz_dev[:, :5].contiguous().cuda(), out5, raw5, wav[:5].contiguous().cuda(), steps_per_graph=4)
+    out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, cfg.out_channels, T, device='cuda')
+    eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, wav.contiguous().cuda(), steps_per_graph=4)
+    torch.cuda.synchronize()
+    assert eng.synth_path == 'graph-fp32'
+    _, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=wav.unsqueeze(-1), formulation='reference')
+    e = rel_err(raw.cpu(), r_or)
+    print('\nfp32 synthesis, 32 streams after 5 on one context: teacher-forced raw rel err %.2e' % e)
+    assert e < TOL_F32
+    assert torch.equal(raw[:5], raw5) and torch.equal(out[:5], out5)
+
+
 GOLD_INC = [p for p in GOLD if 'inc_tf_raw' in np.load(p).files]
 
 
