@@ -261,6 +261,9 @@ int wn_set_batch_parts(wn_ctx* ctx, int32_t parts);
  * (wn_layer_key / wn_drop_quad): out[i] = 1 if element first + i of the [rows][R] layer input is kept, else 0.  No context, no GPU:
  * pins the numpy mirror the parity tests hand to the oracle. */
 int wn_test_dropout_mask(uint64_t seed, int32_t layer, float p, int64_t first, int64_t n, uint8_t* out);
+/* which launches of this context take the 8-phase kernel (csrc/wn_tile8p.h; WN_GEMM8P in the environment of wn_create -- an A/B switch,
+ * default 0): bit 0 = the gate GEMM, bit 1 = d x.  A model that does not fit the kernel reports 0 whatever the switch says. */
+int wn_test_gemm8p_mask(const wn_ctx* ctx);
 #endif /* WN_NO_TEST_HOOKS */
 
 #ifdef __cplusplus

@@ -104,7 +104,7 @@ static int alloc_workspace_inference(wn_ctx* c) {
     }
     sz(NT * c->C * 2);
     for (int i = 0; i <= c->cfg.n_upsample; ++i) sz(lvl[i] * c->C * 4);
-    sz(256); sz(256);
+    sz(256); sz(WN_ZERO_PAGE_BYTES);
     c->ws_bytes = total;
     hipError_t e = hipMalloc((void**)&c->ws, total);
     if (e != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMalloc(%zu bytes inference workspace) failed: %s", total, hipGetErrorString(e));
@@ -112,10 +112,10 @@ static int alloc_workspace_inference(wn_ctx* c) {
     c->cbt = (bf16_t*)bump(p, NT * c->C * 2);
     for (int i = 0; i <= c->cfg.n_upsample; ++i) c->CUP[i] = (float*)bump(p, lvl[i] * c->C * 4);
     c->scal = (float*)bump(p, 256);
-    c->zero_page = (bf16_t*)bump(p, 256);
+    c->zero_page = (bf16_t*)bump(p, WN_ZERO_PAGE_BYTES);
     c->X = c->XD = c->TS = c->U = c->R1 = c->H2 = c->DY = c->DPRE1 = c->DSKIP = c->DZ = c->GXall = c->GX0 = c->GX1 = nullptr;
     c->YHAT = c->DC = c->DCUP[0] = c->DCUP[1] = c->CIN = c->UPPART = nullptr; c->XIN = nullptr;
-    if (hipMemset(c->zero_page, 0, 256) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
+    if (hipMemset(c->zero_page, 0, WN_ZERO_PAGE_BYTES) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
     return WN_OK;
 }
 
@@ -150,7 +150,7 @@ static int alloc_workspace(wn_ctx* c) {
     sz(NT * 4); sz(NT * c->C * 4);          // XIN, CIN
     sz((size_t)WN_CS_SLOTS * WN_CS_MAXBLK * 2 * 1024 * 4);    // wn_colsum2 partials (WN_CS_SLOTS regions)
     sz(256);                               // scalars
-    sz(256);                               // zero page
+    sz(WN_ZERO_PAGE_BYTES);                // zero page
     c->ws_bytes = total;
     hipError_t e = hipMalloc((void**)&c->ws, total);
     if (e != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMalloc(%zu bytes workspace) failed: %s", total, hipGetErrorString(e));
@@ -174,8 +174,8 @@ static int alloc_workspace(wn_ctx* c) {
     c->XIN = (void*)bump(p, NT * 4); c->CIN = (float*)bump(p, NT * c->C * 4);
     c->cs_part = (float*)bump(p, (size_t)WN_CS_SLOTS * WN_CS_MAXBLK * 2 * 1024 * 4);      // exactly what wn_colsum2 addresses (was twice that: ADVICE round 3)
     c->scal = (float*)bump(p, 256);
-    c->zero_page = (bf16_t*)bump(p, 256);
-    if (hipMemset(c->zero_page, 0, 256) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
+    c->zero_page = (bf16_t*)bump(p, WN_ZERO_PAGE_BYTES);
+    if (hipMemset(c->zero_page, 0, WN_ZERO_PAGE_BYTES) != hipSuccess) WN_FAIL(c, WN_E_HIP, "hipMemset(zero page) failed");
     return WN_OK;
 }
 
@@ -220,6 +220,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     c->lbias = cfg->use_bias != 0;
     c->wnorm = cfg->weight_normalization != 0;
     c->inference = cfg->inference_only != 0;
+    { const char* e8 = getenv("WN_GEMM8P"); c->gemm8p = e8 ? atoi(e8) : 0; }      // bit 0: gate, bit 1: d x on the 8-phase kernel (wn_tile8p.h; measured: not faster on any shipped workload)
     c->gin = cfg->gin_channels > 0 ? cfg->gin_channels : 0;
     c->OP = (int)align_up(c->O, 32); c->CP = (int)align_up(c->C, 32);
     const int per = c->L / cfg->stacks;
@@ -439,6 +440,11 @@ extern "C" int wn_fill_noise(wn_ctx* c, float* noise, int32_t B, int32_t T, uint
 }
 extern "C" int wn_synth_check(wn_ctx* c) { if (!c) return WN_E_ARG; return wn_pipe_check(c, true); }
 extern "C" int wn_synth_last_path(const wn_ctx* c) { return c ? c->synth_path : WN_E_ARG; }
+extern "C" int wn_test_gemm8p_mask(const wn_ctx* c) {
+    if (!c) return WN_E_ARG;
+    if (c->packs.empty()) return 0;
+    return (c->packs[0].w1.kil == 64 ? 1 : 0) | (c->packs[0].w1T.kil == 64 ? 2 : 0);
+}
 extern "C" int wn_synth_pipe_eligible(const wn_ctx* c, int32_t B) {
     if (!c || B <= 0) return WN_E_ARG;
     const char* m = getenv("WN_SYNTH_MODE");

@@ -88,7 +88,8 @@ struct PackedW {          // one fragment-ordered bf16 matrix
     int32_t M_valid = 0;
     int32_t gate_interleave = 0;      // row permutation (see wn_pack.hip)
     int32_t GH = 0;
-    int32_t kil = 0;                  // > 0: the three dilated taps are interleaved along K in blocks of `kil` channels
+    int32_t kil = 0;                  // > 0: the three dilated taps are interleaved along K in blocks of `kil` channels (32: wn_gemm_lds_kernel's TAPS
+                                      //      staging; 64: the K-tiles of wn_gemm8p_kernel)
                                       //      [tap0 blk0 | tap1 blk0 | tap2 blk0 | tap0 blk1 | ...] (tile engine: taps of one k-block back to back => L2 reuse)
     std::vector<PackSeg> segs;
     PackSeg* dev_segs = nullptr;
@@ -149,7 +150,10 @@ struct wn_ctx {
     void* XIN; float* CIN;                // ctx-owned copies of the step's x and c (pointers are borrowed per call)
     float* wg_partial = nullptr; size_t wg_partial_bytes = 0;   // split-K partial tiles of the grouped wgrad (wn_wgrad.h)
     bf16_t* GXall = nullptr;              // [L+1][NT][R] gradient wrt every layer input (kept for the grouped W_out wgrad)
-    bf16_t* zero_page = nullptr;          // 256 B of zeros: DMA source for out-of-range rows (wn_gemm_lds_kernel)
+#define WN_ZERO_PAGE_BYTES 4096
+    bf16_t* zero_page = nullptr;          // zeros: DMA source for out-of-range rows / k-steps (wn_gemm_lds_kernel: 16 B per lane from one address;
+                                          // wn_gemm8p_kernel's SGPR-base form: base + 16 * lane, i.e. 1 KiB)
+    int gemm8p = 0;                       // WN_GEMM8P at wn_create, bit 0: gate, bit 1: d x on the 8-phase kernel (wn_tile8p.h) where the model fits it; default 0: the 256 x 128 LDS-DMA ring kernel
     float* scal;                          // device scalars: [0]=loss sum [1]=denominator [2]=1/denominator [3]=count
     // state of the last forward
     int fB = 0, fT = 0, fTc = 0; uint64_t fseed = 0; bool have_fwd = false; bool have_loss = false;

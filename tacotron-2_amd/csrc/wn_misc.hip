@@ -87,7 +87,9 @@ int wn_build_packs(wn_ctx* c) {
         // stages (tap0, tap1, tap2) of one k-block back to back, so the rows two taps have in common are re-read while still in L2.
         init_pack(c, p.w1, G, 3 * R + C, 1);
         p.w1.kil = (G % 128 == 0 && R % 32 == 0) ? 32 : 0;
-        if (p.w1.kil) { for (int kb = 0; kb < R / 32; ++kb) for (int j = 0; j < 3; ++j) p.w1.segs.push_back({o.dil_k + ((int64_t)j * R + kb * 32) * G, (kb * 3 + j) * 32, 32, G, 1, 1.0f}); }
+        // the 8-phase kernel (wn_tile8p.h: 256-row M blocks, 64-channel K-tiles, 32-bit byte offsets inside the staged tensors)
+        if ((c->gemm8p & 1) && G % 256 == 0 && R % 64 == 0 && C % 16 == 0 && c->NT * std::max(R, C) * 2 < ((int64_t)1 << 31)) p.w1.kil = 64;
+        if (p.w1.kil) { const int kl = p.w1.kil; for (int kb = 0; kb < R / kl; ++kb) for (int j = 0; j < 3; ++j) p.w1.segs.push_back({o.dil_k + ((int64_t)j * R + kb * kl) * G, (kb * 3 + j) * kl, kl, G, 1, 1.0f}); }
         else for (int j = 0; j < 3; ++j) p.w1.segs.push_back({o.dil_k + (int64_t)j * R * G, j * R, R, G, 1, 1.0f});
         p.w1.segs.push_back({o.cin_k, 3 * R, C, G, 1, 1.0f});
         if ((rc = finish_pack(c, p.w1))) return rc;
@@ -107,7 +109,8 @@ int wn_build_packs(wn_ctx* c) {
         // W1T (dx): rows = r, K = [tap0 G | tap1 G | tap2 G];  W[r][j*G+g] = dil[j][r][g]
         init_pack(c, p.w1T, R, 3 * G, 0);
         p.w1T.kil = (R % 128 == 0 && G % 32 == 0) ? 32 : 0;
-        if (p.w1T.kil) { for (int kb = 0; kb < G / 32; ++kb) for (int j = 0; j < 3; ++j) p.w1T.segs.push_back({o.dil_k + (int64_t)j * R * G + kb * 32, (kb * 3 + j) * 32, 32, 1, G, 1.0f}); }
+        if ((c->gemm8p & 2) && R % 256 == 0 && G % 64 == 0 && c->NT * G * 2 < ((int64_t)1 << 31)) p.w1T.kil = 64;
+        if (p.w1T.kil) { const int kl = p.w1T.kil; for (int kb = 0; kb < G / kl; ++kb) for (int j = 0; j < 3; ++j) p.w1T.segs.push_back({o.dil_k + (int64_t)j * R * G + kb * kl, (kb * 3 + j) * kl, kl, 1, G, 1.0f}); }
         else for (int j = 0; j < 3; ++j) p.w1T.segs.push_back({o.dil_k + (int64_t)j * R * G, j * G, G, 1, G, 1.0f});
         if ((rc = finish_pack(c, p.w1T))) return rc;
     }

@@ -54,6 +54,7 @@ struct GemmArgs {
     unsigned long long* kprof;  // wn_profile: {min over workgroups of the start, max of the end} of THIS launch in 100 MHz wall-clock ticks (null: off)
     int32_t stagger;            // shader cycles the second-resident workgroups of the first round wait before starting (0: off)
     int32_t xcd_span;           // LDS-DMA kernels: > 0 = XCD x owns the contiguous tiles [x * xcd_span, (x + 1) * xcd_span); 0 = tiles interleaved over XCDs
+    int32_t kil;                // block size of the K-interleaved pack (32: this header's TAPS kernels; 64: wn_gemm8p_kernel, wn_tile8p.h)
     int32_t taps;               // 3: seg[0..2] are the dilated taps of ONE tensor (same base / ld / nk), staged interleaved in BK-channel blocks
                                 //    (tap0, tap1, tap2 of block 0, then of block 1, ...: the K order of a `kil` pack); 0: segments one after the other
     EpiArgs e;
@@ -919,6 +920,7 @@ void wn_gemm_lds_kernel(const GemmArgs a) {
 // Host-side launcher: picks the main loop and workgroup shape from M.
 template <int EPI>
 static inline int wn_launch_gemm(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st) {
+    if (a.taps != 0 && a.kil != 32) WN_FAIL(ctx, WN_E_STATE, "wn_launch_gemm: K-interleaved pack with %d-channel blocks (this header stages 32)", a.kil);
     if (EPI == EPI_GATE && M % 64 != 0) WN_FAIL(ctx, WN_E_SHAPE, "gate GEMM needs gate_channels %% 64 == 0 (got M=%d)", M);
     if (ctx->trace_state == 1 && ctx->trace_n < WN_TRACE_MAX) {      // WN_DEVTRACE: this launch's own stamp slot (takes the slot of wn_profile for this step)
         a.kprof = ctx->trace_dev + 2 * ctx->trace_n;

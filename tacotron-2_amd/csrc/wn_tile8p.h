@@ -45,7 +45,8 @@ __device__ __forceinline__ uint64_t p8_sgpr64(uint64_t v) {
 }
 
 // ABL (harness only): 1 = main loop alone (the accumulators are kept live, nothing is stored)
-template <int EPI, int ABL>
+// SCHED: 0 = LDS-DMAs in the load section of a phase (the guide's template); 1 = between the MFMAs of its matrix block
+template <int EPI, int ABL, int SCHED>
 __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,33 +157,27 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
     };
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-    auto stageB = [&](auto bufc, auto hc) __attribute__((always_inline)) {
+    auto stageB1 = [&](auto bufc, auto hc, const int p) __attribute__((always_inline)) {          // piece p (0 / 1) of half-tile B-h<H>
         constexpr int BUF = decltype(bufc)::value, H = decltype(hc)::value;
-        if (it_fast) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-                lds_dma16_s(p8_sgpr64(it_src + (uint64_t)((H * 2 + p) * it_rs)), it_off, lds_base + p8::b_off(BUF, H) + (wave + 8 * p) * 1024);
-        } else {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const char* src = ((it_okb >> (H * 2 + p)) & 1u) ? (const char*)(it_src + (uint64_t)((H * 2 + p) * it_rs)) + it_off : zero;
-                lds_dma16(src, lds_base + p8::b_off(BUF, H) + (wave + 8 * p) * 1024);
-            }
+        const uint64_t sb = it_src + (uint64_t)((H * 2 + p) * it_rs);
+        if (it_fast) lds_dma16_s(p8_sgpr64(sb), it_off, lds_base + p8::b_off(BUF, H) + (wave + 8 * p) * 1024);
+        else {
+            const char* src = ((it_okb >> (H * 2 + p)) & 1u) ? (const char*)sb + it_off : zero;
+            lds_dma16(src, lds_base + p8::b_off(BUF, H) + (wave + 8 * p) * 1024);
         }
     };
+    auto stageB = [&](auto bufc, auto hc) __attribute__((always_inline)) { stageB1(bufc, hc, 0); stageB1(bufc, hc, 1); };
     // A: fragment f = wave + 8p of a half-tile = (m-tile f / 4 of the half, k-step f % 4); the pack is fragment ordered, one fragment = 1 KiB
     const uint64_t mrow = (uint64_t)a.ksteps_total * 1024;                        // bytes between consecutive 32-row m-tiles of the pack
     const uint64_t abase_w = (uint64_t)a.Apk + ((uint64_t)(mblk * 8 + (wave >> 2)) * a.ksteps_total + (wave & 3)) * 1024;
     const uint32_t a_voff = lane * 16;
-    auto stageA = [&](auto bufc, auto hc, const int kt) __attribute__((always_inline)) {
+    auto stageA1 = [&](auto bufc, auto hc, const int kt, const int p) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value, H = decltype(hc)::value;
         const bool ok = kt * 4 + (wave & 3) < a.ksteps_total;                     // k-steps past the end of the pack come from the zero page
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const uint64_t sb = ok ? abase_w + (uint64_t)kt * 4096 + (uint64_t)(H * 4 + 2 * p) * mrow : (uint64_t)zero;
-            lds_dma16_s(p8_sgpr64(sb), a_voff, lds_base + p8::a_off(BUF, H) + (wave + 8 * p) * 1024);
-        }
+        const uint64_t sb = ok ? abase_w + (uint64_t)kt * 4096 + (uint64_t)(H * 4 + 2 * p) * mrow : (uint64_t)zero;
+        lds_dma16_s(p8_sgpr64(sb), a_voff, lds_base + p8::a_off(BUF, H) + (wave + 8 * p) * 1024);
     };
+    auto stageA = [&](auto bufc, auto hc, const int kt) __attribute__((always_inline)) { stageA1(bufc, hc, kt, 0); stageA1(bufc, hc, kt, 1); };
 
     // fragment read offsets (loop invariant)
     const int rrow = wn * 32 + (lane & 31);
@@ -191,7 +186,9 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
     for (int ks = 0; ks < 4; ++ks) b_rd[ks] = rrow * 128 + (((ks * 2 + h5) ^ ((rrow >> 1) & 7)) * 16);
     const int a_rd = p8::A_REGION + wm * 8192 + lane * 16;
 
-    auto mma = [&](f32x16_t (&c2)[2], const bf16x8_t (&A)[2][4], const bf16x8_t (&Bv)[4], const int nks) __attribute__((always_inline)) {
+    // the MFMA block of a phase; f0 / f1 run between its MFMA pairs (SCHED 1: the phase's two LDS-DMAs and the iterator's scalar bookkeeping
+    // ride in the issue slots the matrix pipe leaves free, instead of lengthening the load section the OTHER wave row's MFMA block waits for)
+    auto mma = [&](f32x16_t (&c2)[2], const bf16x8_t (&A)[2][4], const bf16x8_t (&Bv)[4], const int nks, auto f0, auto f1) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -200,10 +197,13 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) c2[ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ii][ks], Bv[ks], c2[ii], 0, 0, 0);
             }
+            if (ks == 0) { __builtin_amdgcn_sched_barrier(0); f0(); __builtin_amdgcn_sched_barrier(0); }
+            if (ks == 2) { __builtin_amdgcn_sched_barrier(0); f1(); __builtin_amdgcn_sched_barrier(0); }
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto nofill = []() __attribute__((always_inline)) {};
 
     // one K-tile = four phases.  TAIL 0: steady state; 1: second-to-last K-tile (nothing left to stage for kt + 2); 2: last K-tile
     auto ktile = [&](auto bufc, auto tailc, const int kt) __attribute__((always_inline)) {
@@ -221,20 +221,22 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) A0[ii][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(lds + a_rd + (p8::a_off(BUF, 0) - p8::A_REGION) + (ii * 4 + ks) * 1024));
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TAIL < 2) stageA(IO{}, I1{}, kt + 1);
+        if constexpr (TAIL < 2 && SCHED == 0) stageA(IO{}, I1{}, kt + 1);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");          // the four B-h0 reads (issued first) have returned: B-h0 may be re-staged in phase 2
+        if constexpr (SCHED == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");          // the four B-h0 reads (issued first) have returned: B-h0 may be re-staged in phase 2
         __builtin_amdgcn_s_barrier();
-        mma(acc[0][0], A0, B0, nks);
+        if constexpr (TAIL < 2 && SCHED == 1) mma(acc[0][0], A0, B0, nks, [&]() __attribute__((always_inline)) { stageA1(IO{}, I1{}, kt + 1, 0); }, [&]() __attribute__((always_inline)) { stageA1(IO{}, I1{}, kt + 1, 1); });
+        else mma(acc[0][0], A0, B0, nks, nofill, nofill);
         __builtin_amdgcn_s_barrier();
         // ---- phase 2
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) B1[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(lds + b_rd[ks] + p8::b_off(BUF, 1)));
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TAIL == 0) { b_next(); stageB(IB{}, I0{}); }
+        if constexpr (TAIL == 0 && SCHED == 0) { b_next(); stageB(IB{}, I0{}); }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        mma(acc[0][1], A0, B1, nks);
+        if constexpr (TAIL == 0 && SCHED == 1) mma(acc[0][1], A0, B1, nks, [&]() __attribute__((always_inline)) { b_next(); stageB1(IB{}, I0{}, 0); }, [&]() __attribute__((always_inline)) { stageB1(IB{}, I0{}, 1); });
+        else mma(acc[0][1], A0, B1, nks, nofill, nofill);
         __builtin_amdgcn_s_barrier();
         // ---- phase 3
 #pragma unroll
@@ -242,17 +244,21 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) A1[ii][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(lds + a_rd + (p8::a_off(BUF, 1) - p8::A_REGION) + (ii * 4 + ks) * 1024));
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TAIL == 0) stageA(IB{}, I0{}, kt + 2);
+        if constexpr (TAIL == 0 && SCHED == 0) stageA(IB{}, I0{}, kt + 2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        mma(acc[1][1], A1, B1, nks);
+        if constexpr (TAIL == 0 && SCHED == 1) mma(acc[1][1], A1, B1, nks, [&]() __attribute__((always_inline)) { stageA1(IB{}, I0{}, kt + 2, 0); }, [&]() __attribute__((always_inline)) { stageA1(IB{}, I0{}, kt + 2, 1); });
+        else mma(acc[1][1], A1, B1, nks, nofill, nofill);
         __builtin_amdgcn_s_barrier();
         // ---- phase 4: K-tile kt + 1 has landed once only the three youngest half-tiles (those of kt + 2) are in flight
-        if constexpr (TAIL == 0) { stageB(IB{}, I1{}); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        // (SCHED 1: this phase's own DMAs are issued in its MFMA block, after the wait: only the pieces of phases 2 and 3 are younger)
+        if constexpr (TAIL == 0 && SCHED == 0) { stageB(IB{}, I1{}); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else if constexpr (TAIL == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if constexpr (TAIL == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        mma(acc[1][0], A1, B0, nks);
+        if constexpr (TAIL == 0 && SCHED == 1) mma(acc[1][0], A1, B0, nks, [&]() __attribute__((always_inline)) { stageB1(IB{}, I1{}, 0); }, [&]() __attribute__((always_inline)) { stageB1(IB{}, I1{}, 1); });
+        else mma(acc[1][0], A1, B0, nks, nofill, nofill);
         __builtin_amdgcn_s_barrier();
     };
 
@@ -429,10 +435,10 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
     if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
 }
 
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void wn_gemm8p_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(1024))) char lds[p8::LDS_BYTES];
-    wn_gemm8p_body<EPI, ABL>(a, lds);
+    wn_gemm8p_body<EPI, ABL, SCHED>(a, lds);
 }
 
 // Does this launch fit the 8-phase kernel?  (K-interleaved taps in 64-channel blocks + at most sequential tail segments with shift 0;
@@ -450,6 +456,12 @@ static inline bool wn_gemm8p_fits(const GemmArgs& a, int M, int64_t rows_total) 
 }
 template <int EPI>
 static inline int wn_launch_gemm8p(wn_ctx* ctx, GemmArgs& a, int M, hipStream_t st) {
+    if (a.kil != 64 || !wn_gemm8p_fits(a, M, (int64_t)(a.b0 + a.B) * a.T))
+        WN_FAIL(ctx, WN_E_STATE, "wn_launch_gemm8p: launch does not fit the 8-phase kernel (M = %d, kil = %d, taps = %d, nseg = %d)", M, a.kil, a.taps, a.nseg);
+    if (ctx->trace_state == 1 && ctx->trace_n < WN_TRACE_MAX) {      // WN_DEVTRACE: this launch's own stamp slot (as wn_launch_gemm)
+        a.kprof = ctx->trace_dev + 2 * ctx->trace_n;
+        ctx->trace_tag[ctx->trace_n].epi = EPI; ctx->trace_tag[ctx->trace_n].st = (void*)st; ctx->trace_tag[ctx->trace_n].rows = a.B * a.T; ++ctx->trace_n;
+    }
     a.mblocks = M / 256;
     a.tiles_per_utt = cdiv(a.T, 256);
     a.ntiles = a.tiles_per_utt * a.B;

@@ -1,6 +1,6 @@
 // Training step of the WaveNet stack: forward (wavenet.py:650-721), loss (476-495) and the hand-written
 // backward (replaces tf.gradients / optimizer.compute_gradients, wavenet.py:557).
-#include "wn_tile.h"
+#include "wn_tile8p.h"
 #include "wn_wgrad.h"
 
 int wn_first_conv(wn_ctx* c, hipStream_t st);
@@ -321,7 +321,7 @@ static void mk_gate(wn_ctx* c, int l, int b0, int nb, GemmArgs& a) {
     a.seg[1] = seg(XDl, R, 0, R, -d, 0);
     a.seg[2] = seg(XDl, R, 0, R, 0, 0);
     a.seg[3] = seg(c->cbt, C, 0, C, 0, 0);
-    a.taps = c->packs[l].w1.kil ? 3 : 0;
+    a.taps = c->packs[l].w1.kil ? 3 : 0; a.kil = c->packs[l].w1.kil;
     if (c->gin > 0) { a.e.bias = c->gbias + (size_t)l * c->fB * G; a.e.bias_bstride = G; }      // + W_g^T g + b_g per utterance
     else a.e.bias = c->b1sum + (size_t)l * G;
     a.e.out0 = c->TS + (size_t)l * NT * GH; a.e.ld_out0 = GH;      // sigmoid half only (tanh = u / sigmoid in the backward)
@@ -348,7 +348,7 @@ static void prof_gate(wn_ctx* c, GemmArgs& a, hipStream_t st) {
 static int fwd_gate(wn_ctx* c, int l, int b0, int nb, hipStream_t st, bool prof) {
     GemmArgs a; mk_gate(c, l, b0, nb, a);
     if (prof) prof_gate(c, a, st);
-    int rc = wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st);
+    int rc = a.kil == 64 ? wn_launch_gemm8p<EPI_GATE>(c, a, c->packs[l].w1.M, st) : wn_launch_gemm<EPI_GATE>(c, a, c->packs[l].w1.M, st);
     if (prof) prof_mark(c, st);
     return rc;
 }
@@ -493,7 +493,7 @@ static void mk_dx(wn_ctx* c, int l, int b0, int nb, GemmArgs& a) {
     a.seg[0] = seg(DZl, G, 0, G, 2 * d, 0);
     a.seg[1] = seg(DZl, G, 0, G, d, 0);
     a.seg[2] = seg(DZl, G, 0, G, 0, 0);
-    a.taps = c->packs[l].w1T.kil ? 3 : 0;
+    a.taps = c->packs[l].w1T.kil ? 3 : 0; a.kil = c->packs[l].w1T.kil;
     set_dropout(c, l, a.key_lo, a.key_hi, a.thresh16, a.keep_scale, a.drop_ld);
     if (!(c->cfg.dropout > 0.0f)) a.thresh16 = 0;
     a.e.in0 = top ? nullptr : c->GXall + (size_t)(l + 1) * NT * R; a.e.ld_in0 = R;
@@ -512,7 +512,7 @@ static int chain_events(wn_ctx* c, int l, int part, hipStream_t st) {
 }
 static int bwd_dx(wn_ctx* c, int l, int b0, int nb, hipStream_t st, int part) {
     GemmArgs a; mk_dx(c, l, b0, nb, a);
-    int rc = wn_launch_gemm<EPI_DX>(c, a, c->packs[l].w1T.M, st);
+    int rc = a.kil == 64 ? wn_launch_gemm8p<EPI_DX>(c, a, c->packs[l].w1T.M, st) : wn_launch_gemm<EPI_DX>(c, a, c->packs[l].w1T.M, st);
     if (rc) return rc;
     return chain_events(c, l, part, st);
 }

@@ -242,6 +242,23 @@ def test_c2_bench_geometry_b8():
     _assert_case(r)
 
 
+def test_c2_geometry_on_the_8phase_kernel(monkeypatch):
+    """WN_GEMM8P=3 at wn_create routes gate and d x to the 8-phase kernel (csrc/wn_tile8p.h: 256 x 256 tiles, K-interleaved packs in 64-channel
+    blocks, one workgroup per CU) -- an alternative main loop that is not the default (it ties the 256 x 128 ring kernel on the step,
+    DESIGN 3.1); same tolerances as the default engine: layer-local activations at d = 1 / 1024 / 2048 (taps 8 tiles away, the zero
+    page at the utterance start, the 11000 % 256 tail tile, the ragged second utterance), y_hat, all 204 gradient tensors."""
+    monkeypatch.setenv('WN_GEMM8P', '3')
+    r = _case(PAPER, 2, 11000, [11000, 9377], [0, 10, 11, 12, 22, 23], report='c2_b2_gemm8p')
+    assert r['eng'].lib.wn_test_gemm8p_mask(r['eng'].h) == 3          # both launches really took the 8-phase kernel
+    _assert_case(r)
+    r['eng'].close()
+    monkeypatch.delenv('WN_GEMM8P')
+    from wavenet_vocoder import _ext
+    e0 = _ext.Engine(make_hp(**PAPER), 2, 11000)
+    assert e0.lib.wn_test_gemm8p_mask(e0.h) == 0                      # and the default engine does not
+    e0.close()
+
+
 def test_c2_4stack_geometry():
     """paper_hparams.py's own 4-stack variant (dilations 1..32, four cycles), single-stream order (batch_parts = 1)."""
     r = _case(dict(PAPER, stacks=4), 2, 11000, [11000, 11000], [0, 5, 6, 23], report='c2_4stack_b2', batch_parts=1)

@@ -83,11 +83,11 @@ template <int EPI> static void launch_prod(GemmArgs a, int M, hipStream_t st) {
     a.stagger = grid >= WN_STAGGER_MIN_GRID ? 8000 : 0;
     hipLaunchKernelGGL((wn_gemm_lds_kernel<2, 2, 4, 2, 32, 3, EPI, 1, 3>), dim3(grid), dim3(512), 0, st, a);
 }
-template <int EPI, int ABL = 0> static void launch_8p(GemmArgs a, int M, hipStream_t st) {
+template <int EPI, int ABL = 0, int SCHED = 1> static void launch_8p(GemmArgs a, int M, hipStream_t st) {
     a.mblocks = M / 256; a.tiles_per_utt = cdiv(a.T, 256); a.ntiles = a.tiles_per_utt * a.B;
     a.xcd_span = cdiv(a.ntiles, 8); a.taps = 3; a.stagger = 0;
     const int grid = cdiv(a.ntiles, 8) * a.mblocks * 8;
-    hipLaunchKernelGGL((wn_gemm8p_kernel<EPI, ABL>), dim3(grid), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((wn_gemm8p_kernel<EPI, ABL, SCHED>), dim3(grid), dim3(512), 0, st, a);
 }
 
 int main(int argc, char** argv) {
@@ -135,6 +135,12 @@ int main(int argc, char** argv) {
         printf("gate   8p vs production: sigmoid %zu of %zu differ (max |d| %.4g, %zu beyond 2 ulp) | u %zu differ (max |d| %.4g, %zu beyond 2 ulp)  %s\n",
                cs.ndiff, cs.n, cs.maxabs, cs.nbad, cu.ndiff, cu.maxabs, cu.nbad, (cs.nbad + cu.nbad) ? "FAIL" : "ok");
         fails += (cs.nbad + cu.nbad) != 0;
+        {   // both schedules add the same products in the same order: bitwise equal
+            CK(hipMemset(TS3, 0xff, NT_ * GH * 2)); CK(hipMemset(U3, 0xff, NT_ * GH * 2));
+            launch_8p<EPI_GATE, 0, 0>(a3, M, 0); CK(hipDeviceSynchronize());
+            const bool ok = same_bits(TS2, TS3, NT_ * GH) && same_bits(U2, U3, NT_ * GH);
+            printf("gate   8p schedule 0 vs schedule 1: %s\n", ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+        }
         for (int rep = 0; rep < 4; ++rep) {        // race screen: the kernel must reproduce its own bits, also beside another copy of itself
             CK(hipMemset(TS3, 0xff, NT_ * GH * 2)); CK(hipMemset(U3, 0xff, NT_ * GH * 2));
             launch_8p<EPI_GATE>(a3, M, 0); if (rep & 1) launch_8p<EPI_GATE>(a3, M, 0);
@@ -144,10 +150,12 @@ int main(int argc, char** argv) {
         }
         for (int rnd = 0; rnd < rounds; ++rnd) {
             const float tp = time_ms([&] { launch_prod<EPI_GATE>(a1, M, 0); });
-            const float t8 = time_ms([&] { launch_8p<EPI_GATE>(a2, M, 0); });
-            const float tm = time_ms([&] { launch_8p<EPI_GATE, 1>(a2, M, 0); });
-            printf("gate   production %7.1f us %6.1f TF | 8-phase %7.1f us %6.1f TF | 8-phase main loop only %7.1f us %6.1f TF\n",
-                   tp * 1e3, fl / tp / 1e9, t8 * 1e3, fl / t8 / 1e9, tm * 1e3, fl / tm / 1e9);
+            const float t8 = time_ms([&] { launch_8p<EPI_GATE, 0, 1>(a2, M, 0); });
+            const float tm = time_ms([&] { launch_8p<EPI_GATE, 1, 1>(a2, M, 0); });
+            const float t80 = time_ms([&] { launch_8p<EPI_GATE, 0, 0>(a2, M, 0); });
+            const float tm0 = time_ms([&] { launch_8p<EPI_GATE, 1, 0>(a2, M, 0); });
+            printf("gate   production %7.1f us %6.1f TF | 8-phase DMA-in-MFMA-block %7.1f us %6.1f TF, main loop only %7.1f us %6.1f TF | DMA-in-load-section %7.1f us %6.1f TF, main loop only %7.1f us %6.1f TF\n",
+                   tp * 1e3, fl / tp / 1e9, t8 * 1e3, fl / t8 / 1e9, tm * 1e3, fl / tm / 1e9, t80 * 1e3, fl / t80 / 1e9, tm0 * 1e3, fl / tm0 / 1e9);
         }
         if (B >= 2) {       // what the step launches: half batches on two streams
             hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
@@ -176,6 +184,12 @@ int main(int argc, char** argv) {
         Cmp c = compare_bf16(O1, O2, NT_ * R);
         printf("dx     8p vs production: %zu of %zu differ (max |d| %.4g, %zu beyond 2 ulp)  %s\n", c.ndiff, c.n, c.maxabs, c.nbad, c.nbad ? "FAIL" : "ok");
         fails += c.nbad != 0;
+        {
+            CK(hipMemset(O3, 0xff, NT_ * R * 2));
+            launch_8p<EPI_DX, 0, 0>(a3, M, 0); CK(hipDeviceSynchronize());
+            const bool ok = same_bits(O2, O3, NT_ * R);
+            printf("dx     8p schedule 0 vs schedule 1: %s\n", ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+        }
         for (int rep = 0; rep < 4; ++rep) {
             CK(hipMemset(O3, 0xff, NT_ * R * 2));
             launch_8p<EPI_DX>(a3, M, 0); if (rep & 1) launch_8p<EPI_DX>(a3, M, 0);
@@ -184,10 +198,12 @@ int main(int argc, char** argv) {
         }
         for (int rnd = 0; rnd < rounds; ++rnd) {
             const float tp = time_ms([&] { launch_prod<EPI_DX>(a1, M, 0); });
-            const float t8 = time_ms([&] { launch_8p<EPI_DX>(a2, M, 0); });
-            const float tm = time_ms([&] { launch_8p<EPI_DX, 1>(a2, M, 0); });
-            printf("dx     production %7.1f us %6.1f TF | 8-phase %7.1f us %6.1f TF | 8-phase main loop only %7.1f us %6.1f TF\n",
-                   tp * 1e3, fl / tp / 1e9, t8 * 1e3, fl / t8 / 1e9, tm * 1e3, fl / tm / 1e9);
+            const float t8 = time_ms([&] { launch_8p<EPI_DX, 0, 1>(a2, M, 0); });
+            const float tm = time_ms([&] { launch_8p<EPI_DX, 1, 1>(a2, M, 0); });
+            const float t80 = time_ms([&] { launch_8p<EPI_DX, 0, 0>(a2, M, 0); });
+            const float tm0 = time_ms([&] { launch_8p<EPI_DX, 1, 0>(a2, M, 0); });
+            printf("dx     production %7.1f us %6.1f TF | 8-phase DMA-in-MFMA-block %7.1f us %6.1f TF, main loop only %7.1f us %6.1f TF | DMA-in-load-section %7.1f us %6.1f TF, main loop only %7.1f us %6.1f TF\n",
+                   tp * 1e3, fl / tp / 1e9, t8 * 1e3, fl / t8 / 1e9, tm * 1e3, fl / tm / 1e9, t80 * 1e3, fl / t80 / 1e9, tm0 * 1e3, fl / tm0 / 1e9);
         }
     }
     printf("gemm8p harness %s (%d failing checks)\n", fails ? "FAILED" : "passed", fails);
