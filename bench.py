@@ -488,7 +488,8 @@ def dry_run(args):
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
-    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    from wavenet_vocoder import launch as _launch
+    _launch.init_process_group(backend='gloo', rank=rank, world_size=world)
     ones = torch.ones(1)
     dist.all_reduce(ones)
     eng = _DryEngine(1000)
@@ -580,10 +581,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
+        from wavenet_vocoder import launch as _launch
         if world > 1:
-            dist.init_process_group(backend='nccl', device_id=device)
+            _launch.init_process_group(backend='nccl', device_id=device)
         else:
-            dist.init_process_group(backend='nccl', device_id=device, rank=0, world_size=1)
+            _launch.init_process_group(backend='nccl', device_id=device, rank=0, world_size=1)
     collective = None
     if use_dist:
         # count the ranks with a real collective: the number RCCL actually connected, not the number the environment promised

@@ -247,10 +247,15 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
         // pre-size every synthesis buffer for (max_batch, max_time): wn_synthesize never allocates on this context
         if (c->maxB > 32) { c->err = "inference_only: max_batch must be <= 32 streams"; rc = WN_E_SHAPE; }
         if (rc == WN_OK) rc = wn_noise_reserve(c, c->maxB, c->maxT);
-        // the persistent pipeline when the model fits it (all max_batch streams in one run if their LDS state fits, else groups of 8), else the launch-per-layer graph path
-        if (rc == WN_OK) rc = c->cfg.compute_dtype == WN_COMPUTE_F32 ? wn_synth_f32_reserve(c, c->maxB)
-                              : wn_pipe_eligible(c, c->maxB) ? wn_pipe_reserve(c, c->maxB, c->maxT)
-                              : wn_pipe_eligible(c, std::min(c->maxB, 8)) ? wn_pipe_reserve(c, std::min(c->maxB, 8), c->maxT) : wn_synth_reserve(c);
+        // the persistent pipeline when the model fits it, pre-sized for the LARGEST eligible run of <= max_batch streams (it was
+        // sized for max_batch or else 8, so a batch between 8 and a non-eligible max_batch was eligible by wn_synth_pipe_eligible and then
+        // failed to grow); else the launch-per-layer graph path
+        if (rc == WN_OK) {
+            int pb = c->maxB;
+            while (pb > 0 && !wn_pipe_eligible(c, pb)) --pb;
+            c->pipe_cap = pb;
+            rc = c->cfg.compute_dtype == WN_COMPUTE_F32 ? wn_synth_f32_reserve(c, c->maxB) : pb > 0 ? wn_pipe_reserve(c, pb, c->maxT) : wn_synth_reserve(c);
+        }
     }
     if (rc != WN_OK) { g_create_err = c->err; wn_destroy(c); return rc; }
     *out = c;
@@ -449,6 +454,7 @@ extern "C" int wn_synth_pipe_eligible(const wn_ctx* c, int32_t B) {
     if (!c || B <= 0) return WN_E_ARG;
     const char* m = getenv("WN_SYNTH_MODE");
     if (m && strcmp(m, "graph") == 0) return 0;
+    if (c->inference && c->pipe_cap > 0 && B > c->pipe_cap) return 0;      // an inference-only context never grows its pipeline: larger batches go in groups
     return wn_pipe_eligible(c, B) ? 1 : 0;
 }
 

@@ -188,6 +188,7 @@ struct wn_ctx {
     struct Synth* synth = nullptr;
     void* synth32 = nullptr;              // fp32 synthesis state (wn_synth_f32.hip; cfg.compute_dtype = WN_COMPUTE_F32)
     void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)
+    int pipe_cap = 0;                     // inference-only contexts: streams of ONE pipeline run the pre-sized buffers hold (0: pipeline not used / not limited)
     void* f32 = nullptr;                  // fp32-forward state (wn_f32.hip), allocated on the first forward of a cfg.compute_dtype = WN_COMPUTE_F32 context
     bool fwd_was_f32 = false;
     float* dy32_next = nullptr;           // the next wn_loss_run also writes d y_hat in fp32 here ([rows][ldDY]; fp32 training mode)

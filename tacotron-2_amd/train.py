@@ -55,7 +55,8 @@ def _init_distributed():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        from wavenet_vocoder import launch as _launch
+        _launch.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     return world
 
 

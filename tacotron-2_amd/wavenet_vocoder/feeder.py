@@ -130,27 +130,33 @@ class Feeder(object):
         ~1 ms per tensor: four per batch made the PRODUCER the bottleneck of a 10 ms step, bench.py ``with_feeder``)."""
         if not torch.cuda.is_available():
             return batch
-        return tuple(None if b is None else self._pinned_copy(b, train) for b in batch)
+        return self._pinned_batch(batch, train)
 
-    _PIN_RING = 16      # >= queue depth (8) + the batch being built + the three the consumer keeps referenced while their copies fly + slack
+    _PIN_RING = 16      # slots per ring >= queue depth (8) + the batch being built + the three the consumer keeps referenced while their copies fly + slack
 
-    def _pinned_copy(self, arr, train=True):
-        src = torch.from_numpy(arr)
-        key = (bool(train), arr.dtype.str, arr.shape)   # one ring per producer: a burst of same-shaped eval batches must not lap the train queue's buffers
+    def _pinned_batch(self, batch, train=True):
+        """One ring SLOT holds the page-locked buffers of ONE whole batch (a buffer per tensor position).  The ring is keyed by the
+        producer and by the (dtype, shape) of every tensor of the batch, so a slot is reused only PIN_RING batches later whatever the
+        tensors look like.  (Round 4 keyed a ring per tensor shape: a mulaw-quantize batch, whose inputs and targets are the same
+        int32 [B, T] array, took TWO buffers of one ring per batch, the ring covered 8 batches instead of 16, and with a full train
+        queue batch k + 8 was staged into the input buffers of the still-queued batch k -- ADVICE round 4.)"""
+        key = (bool(train),) + tuple(None if b is None else (b.dtype.str, b.shape) for b in batch)
         with self._pin_lock:
             ring = self._pin_pool.get(key)
             if ring is None:
                 if len(self._pin_pool) >= 64:       # many distinct padded lengths (real data): drop the oldest shape's ring
                     self._pin_pool.pop(next(iter(self._pin_pool)))
-                ring = self._pin_pool[key] = {'bufs': [], 'next': 0}
-            if len(ring['bufs']) < self._PIN_RING:
-                buf = _new_pinned(src.shape, src.dtype)
-                ring['bufs'].append(buf)
+                ring = self._pin_pool[key] = {'slots': [], 'next': 0}
+            if len(ring['slots']) < self._PIN_RING:
+                slot = [None if b is None else _new_pinned(torch.from_numpy(b).shape, torch.from_numpy(b).dtype) for b in batch]
+                ring['slots'].append(slot)
             else:
-                buf = ring['bufs'][ring['next'] % self._PIN_RING]
+                slot = ring['slots'][ring['next'] % self._PIN_RING]
             ring['next'] += 1
-        buf.copy_(src)
-        return buf
+        for buf, b in zip(slot, batch):
+            if b is not None:
+                buf.copy_(torch.from_numpy(b))
+        return tuple(slot)
 
     def _put(self, q, item):
         """Blocking put that gives up when the coordinator stops (returns True then)."""

@@ -7,7 +7,9 @@ LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port).  Ra
 one JSON line), the other ranks' stdout goes to stderr; the first rank to fail takes the others down (by PID, never by pattern)
 and its exit code is returned.  A process that already runs under a launcher (WORLD_SIZE set) never calls this.
 """
+import ctypes
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -25,6 +27,20 @@ def free_port():
         return s.getsockname()[1]
 
 
+def init_process_group(**kw):
+    """torch.distributed.init_process_group for a rank started by spawn_ranks: a rendezvous that fails because the port picked by
+    free_port() was taken in the meantime ends this rank with EADDRINUSE_RC, which spawn_ranks answers with a fresh port."""
+    import torch.distributed as dist
+    try:
+        return dist.init_process_group(**kw)
+    except Exception as e:      # noqa: BLE001 -- DistNetworkError / RuntimeError, by message: torch has no stable exception type for it
+        msg = str(e).lower()
+        if os.environ.get('WN_SELF_LAUNCHED') == '1' and ('address already in use' in msg or 'eaddrinuse' in msg or 'errno: 98' in msg):
+            sys.stderr.write('launch: rendezvous on port %s failed (%s)\n' % (os.environ.get('MASTER_PORT'), str(e).splitlines()[0][:160]))
+            sys.exit(EADDRINUSE_RC)
+        raise
+
+
 def require_gpus(n):
     """Fail loudly -- before any rank starts -- when this node has fewer GPUs than ranks were asked for."""
     import torch
@@ -34,10 +50,49 @@ def require_gpus(n):
                          % (n, have, n))
 
 
-def spawn_ranks(argv, n, env_extra=None, poll_s=0.2):
-    """Run ``sys.executable argv...`` as ranks 0..n-1 and wait.  Returns the exit code (0 = every rank returned 0)."""
+def _die_with_parent():
+    """preexec_fn of every rank (Linux): SIGTERM when the launching process dies, however it dies (a SIGKILLed parent cannot forward anything)."""
+    try:
+        ctypes.CDLL('libc.so.6', use_errno=True).prctl(1, signal.SIGTERM)      # PR_SET_PDEATHSIG
+    except Exception:       # noqa: BLE001 -- best effort: the SIGTERM handler below is the portable path
+        pass
+
+
+class _Terminated(BaseException):
+    pass
+
+
+def spawn_ranks(argv, n, env_extra=None, poll_s=0.2, attempts=3):
+    """Run ``sys.executable argv...`` as ranks 0..n-1 and wait.  Returns the exit code (0 = every rank returned 0).
+    A SIGTERM / SIGINT to this process is forwarded to every rank (they would otherwise keep the GPUs); the port is picked by binding
+    port 0 and released before the ranks bind it, so a lost race (exit code EADDRINUSE_RC of a rank within the first seconds: another
+    process took the port) is retried on a fresh port up to `attempts` times."""
+    rc = 0
+    for attempt in range(attempts):
+        t0 = time.time()
+        rc, stderr_tail_hint = _spawn_once(argv, n, env_extra, poll_s)
+        if rc == EADDRINUSE_RC and time.time() - t0 < 60 and attempt + 1 < attempts:
+            sys.stderr.write('launch: rendezvous port was taken by another process, retrying on a fresh port (%d/%d)\n' % (attempt + 2, attempts))
+            continue
+        break
+    return rc
+
+
+EADDRINUSE_RC = 98      # a rank whose rendezvous failed with "address already in use" exits with errno EADDRINUSE (bench.py / train.py map it)
+
+
+def _spawn_once(argv, n, env_extra, poll_s):
     port = free_port()
     procs = []
+
+    def on_term(signum, frame):
+        raise _Terminated(signum)
+    old = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old[sg] = signal.signal(sg, on_term)
+        except ValueError:          # not the main thread: the caller owns signal handling
+            pass
     for r in range(n):
         env = dict(os.environ)
         env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(n), 'LOCAL_WORLD_SIZE': str(n),
@@ -46,7 +101,7 @@ def spawn_ranks(argv, n, env_extra=None, poll_s=0.2):
         env.setdefault('GPU_MAX_HW_QUEUES', '8')
         if env_extra:
             env.update(env_extra)
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if r == 0 else sys.stderr, preexec_fn=_die_with_parent))
     rc = 0
     try:
         live = list(procs)
@@ -61,6 +116,11 @@ def spawn_ranks(argv, n, env_extra=None, poll_s=0.2):
                     for q in live:            # a rank died: the others would hang in their next collective
                         q.terminate()
             time.sleep(poll_s)
+    except _Terminated as t:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        rc = 128 + int(t.args[0])
     except BaseException:
         for p in procs:
             if p.poll() is None:
@@ -74,4 +134,6 @@ def spawn_ranks(argv, n, env_extra=None, poll_s=0.2):
                     p.wait(timeout=max(0.1, deadline - time.time()))
                 except subprocess.TimeoutExpired:
                     p.kill()
-    return rc
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    return rc, None

@@ -286,9 +286,13 @@ class WaveNet(object):
             # independent: wavenet.py:237-239 splits them over towers).  Models the pipeline does not fit take the launch-per-layer graph
             # path, whose time per step is nearly independent of the batch: up to 32 streams per run.
             group = min(B, 32)
-            piped = spg_ <= 0 and self.engine.pipeline_eligible(group)
-            if spg_ <= 0 and not piped and self.engine.pipeline_eligible(min(B, 8)):
-                piped, group = True, 8
+            piped = False
+            if spg_ <= 0:                   # the largest run of <= B streams the pipeline takes (an inference-only context is pre-sized: it never grows)
+                g = group
+                while g > 0 and not self.engine.pipeline_eligible(g):
+                    g -= 1
+                if g > 0:
+                    piped, group = True, g
             for b0 in range(0, B, group):
                 b1 = min(B, b0 + group)
                 nz = None if noise is None else noise[:, b0:b1].contiguous()

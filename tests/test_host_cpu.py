@@ -571,6 +571,20 @@ def test_static_isa_audit_no_scratch_and_two_workgroups_per_cu():
         assert 2 * r['lds'] <= 160 * 1024, (r['name'], r['lds'])   # two residents in the 160 KB LDS
 
 
+def test_isa_audit_unwaited_prefetch_registers_stay_untouched():
+    """wn_synth_pipe.hip issues its ring-tap prefetches as inline-asm loads with the wait many instructions later; hipcc
+    does not track loads inside inline asm, so a register copy / spill / re-use in that window would read the destination before the data
+    lands.  The disassembly is checked at every build: between each such load and its `s_waitcnt vmcnt(0)` nothing touches the destination
+    registers and nothing goes to scratch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('isa_audit', os.path.join(ROOT, 'tools', 'isa_audit.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen, bad = mod.unwaited_load_hazards()
+    assert seen >= 2, seen              # the two prefetches are there (otherwise this test looks at nothing)
+    assert not bad, bad
+
+
 def test_c_abi_rejects_bad_configurations_before_touching_the_gpu():
     """wn_create validates the configuration (the constraints the reference asserts, plus the tiling limits of this build) before any
     HIP call, so status codes and messages can be checked on a box without a GPU.  No exception crosses the C boundary."""
@@ -694,22 +708,53 @@ def test_feeder_ranks_take_disjoint_slices_of_the_same_batches(tmp_path, monkeyp
 
 
 def test_feeder_pinned_rings_are_per_producer(tmp_path, monkeypatch):
-    """The page-locked staging buffers are a ring per (producer, shape).  The train queue keeps up to 8 batches + the one being built + the
-    consumer's two alive; a burst of same-shaped eval batches (eval queue depth 1, but one batch per eval step) must not lap them."""
+    """The page-locked staging buffers are a ring of whole-batch SLOTS per (producer, shapes of the batch's tensors).  The train queue keeps
+    up to 8 batches + the one being built + the consumer's two alive; a burst of same-shaped eval batches (eval queue depth 1, but one
+    batch per eval step) must not lap them."""
     import hparams as H
     from wavenet_vocoder import feeder as F
     hp = H._build()
     hp.parse('hop_size=16,num_mels=16,cin_channels=16,upsample_scales=[4,4],max_time_steps=500,wavenet_batch_size=4,wavenet_test_batches=1')
     fd = F.Feeder(None, _write_dataset(str(tmp_path)), str(tmp_path), hp, device=torch.device('cpu'))
     monkeypatch.setattr(F, '_new_pinned', lambda shape, dtype: torch.empty(shape, dtype=dtype))
-    live = [fd._pinned_copy(np.full((4, 7), float(i), np.float32), True) for i in range(12)]          # the train side's live set
-    for i in range(40):                                                                                 # an eval phase of the same shape
-        fd._pinned_copy(np.full((4, 7), -1.0 - i, np.float32), False)
+    one = lambda v: (np.full((4, 7), float(v), np.float32),)
+    live = [fd._pinned_batch(one(i), True)[0] for i in range(12)]          # the train side's live set
+    for i in range(40):                                                       # an eval phase of the same shape
+        fd._pinned_batch(one(-1.0 - i), False)
     for i, t in enumerate(live):
         assert torch.equal(t, torch.full((4, 7), float(i))), i
-    # the ring itself wraps after _PIN_RING buffers of one producer (bounded page-locked memory)
-    again = [fd._pinned_copy(np.full((4, 7), 100.0 + i, np.float32), True) for i in range(fd._PIN_RING)]
+    # the ring itself wraps after _PIN_RING slots of one producer (bounded page-locked memory)
+    again = [fd._pinned_batch(one(100.0 + i), True)[0] for i in range(fd._PIN_RING)]
     assert again[4].data_ptr() == live[0].data_ptr() and len({t.data_ptr() for t in live + again}) == fd._PIN_RING
+
+
+def test_feeder_pinned_ring_takes_a_whole_batch_per_slot(tmp_path, monkeypatch):
+    """a mulaw-quantize batch has inputs and targets of the SAME dtype and shape (int32 [B, T]).  With a ring per tensor
+    shape each batch took two buffers of one ring, the ring covered 8 batches, and with the train queue full (8 queued + the one being
+    built + the consumer's three) batch k + 8 was staged into the x / y buffers of the still-queued batch k while its lengths and mel
+    conditioning stayed batch k's.  A slot now holds one whole batch: 16 batches of identical tensor shapes are 16 disjoint buffer sets."""
+    import hparams as H
+    from wavenet_vocoder import feeder as F
+    hp = H._build()
+    hp.parse('hop_size=16,num_mels=16,cin_channels=16,upsample_scales=[4,4],max_time_steps=500,wavenet_batch_size=4,wavenet_test_batches=1,'
+             'input_type=mulaw-quantize,quantize_channels=256,out_channels=256')
+    fd = F.Feeder(None, _write_dataset(str(tmp_path)), str(tmp_path), hp, device=torch.device('cpu'))
+    monkeypatch.setattr(F, '_new_pinned', lambda shape, dtype: torch.empty(shape, dtype=dtype))
+
+    def batch(k):       # the tensor shapes _prepare_batch emits for mulaw-quantize: x and y identical int32 [B, T]; lengths; mel c
+        return (np.full((4, 96), k, np.int32), np.full((4, 96), 1000 + k, np.int32), np.full((4,), k, np.int32), np.full((4, 16, 6), float(k), np.float32))
+
+    held = [fd._pinned_batch(batch(k), True) for k in range(fd._PIN_RING)]       # queue full and then some: every batch still referenced
+    ptrs = [t.data_ptr() for b in held for t in b]
+    assert len(set(ptrs)) == 4 * fd._PIN_RING                                   # no buffer is shared between positions or batches
+    for k, b in enumerate(held):
+        assert int(b[0][0, 0]) == k and int(b[1][0, 0]) == 1000 + k and int(b[2][0]) == k and float(b[3][0, 0, 0]) == float(k), k
+    # the real producer path: batches prepared from the dataset keep inputs / targets / lengths / conditioning of ONE batch together
+    prepared = [fd._prepare_batch(b) for b in list(fd._iter_group(train=True))[:10]]
+    pinned = [fd._pin(p, True) if torch.cuda.is_available() else fd._pinned_batch(p, True) for p in prepared]
+    for p, q in zip(prepared, pinned):
+        for a, t in zip(p, q):
+            assert (a is None and t is None) or np.array_equal(a, t.numpy())
 
 
 def test_feeder_thread_errors_reach_the_training_loop(tmp_path):

@@ -56,6 +56,45 @@ def test_spawn_ranks_propagates_failure_and_stops_the_other_ranks(tmp_path):
     assert time.time() - t0 < 30                           # ranks 0 and 2 were terminated, not waited for
 
 
+def test_spawn_ranks_forwards_sigterm_and_retries_a_lost_port_race(tmp_path):
+    """(1) a SIGTERM to the launching process must reach the ranks (they would keep the GPUs): run a launcher in a child
+    interpreter, kill it with SIGTERM, and require that its ranks are gone; (2) free_port() releases the port before the ranks bind it --
+    a rank that loses that race exits with launch.EADDRINUSE_RC and spawn_ranks starts the ranks again on a fresh port."""
+    import signal
+    import time
+    from wavenet_vocoder import launch
+    pidfile = tmp_path / 'pids'
+    worker = tmp_path / 'w.py'
+    worker.write_text('import os, time\nopen(%r, "a").write(str(os.getpid()) + "\\n")\ntime.sleep(120)\n' % str(pidfile))
+    parent = tmp_path / 'p.py'
+    parent.write_text('import sys\nsys.path.insert(0, %r)\nfrom wavenet_vocoder import launch\nsys.exit(launch.spawn_ranks([%r], 2))\n'
+                      % (os.path.join(ROOT, 'tacotron-2_amd'), str(worker)))
+    p = subprocess.Popen([sys.executable, str(parent)])
+    t0 = time.time()
+    while time.time() - t0 < 60 and (not pidfile.exists() or len(pidfile.read_text().split()) < 2):
+        time.sleep(0.1)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in pids:                                       # the ranks were children of p: reaped by it, so the pid must be gone
+        try:
+            os.kill(pid, 0)
+            alive = open('/proc/%d/stat' % pid).read().split()[2] != 'Z'
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
+    # (2) first attempt: every rank reports the lost race; second attempt: success
+    marker = tmp_path / 'attempt'
+    flaky = tmp_path / 'f.py'
+    flaky.write_text('import os, sys\nm = %r\nr = os.environ["RANK"]\n'
+                     'if not os.path.exists(m + r):\n    open(m + r, "w").write(os.environ["MASTER_PORT"])\n    sys.exit(%d)\n'
+                     'assert open(m + r).read() != "" \nsys.exit(0)\n' % (str(marker), launch.EADDRINUSE_RC))
+    assert launch.spawn_ranks([str(flaky)], 2) == 0
+    assert os.path.exists(str(marker) + '0') and os.path.exists(str(marker) + '1')
+
+
 def test_train_cli_self_launches_when_wavenet_num_gpus_is_set(monkeypatch):
     spec = importlib.util.spec_from_file_location('train_cli', os.path.join(ROOT, 'tacotron-2_amd', 'train.py'))
     cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)

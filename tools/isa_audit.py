@@ -81,7 +81,60 @@ def audit(so_path=SO):
     return rows
 
 
+def unwaited_load_hazards(so_path=SO, kernel_substr='synth_pipe_kernel'):
+    """csrc/wn_synth_pipe.hip issues ring-tap prefetches as inline-asm `global_load_dwordx4 ... sc1` WITHOUT a wait
+    (ld_g16_nowait) and waits by hand after the skip chain (pf_wait).  hipcc's waitcnt pass does not see loads inside inline asm: if
+    register allocation ever copies, spills or re-uses the destination registers in that window the copy reads them before the data has
+    landed.  This scans the disassembly of every kernel whose name contains `kernel_substr`: for each `global_load_dwordx4 ... sc1` that is
+    not followed by its `s_waitcnt vmcnt(0)` within two instructions, every instruction up to the next `s_waitcnt vmcnt(0)` (program
+    order) must leave the destination registers alone and must not be a scratch access.  Returns a list of (kernel, load, offender)."""
+    bad, seen = [], 0
+    with tempfile.TemporaryDirectory() as wd:
+        for elf in code_objects(so_path, wd):
+            txt = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', elf], capture_output=True, text=True, check=True).stdout
+            cur, body = None, []
+            blocks = []
+            for line in txt.splitlines():
+                m = re.match(r'^[0-9a-f]+ <(\S+)>:', line)
+                if m:
+                    cur = m.group(1); body = []; blocks.append((cur, body)); continue
+                if cur is not None and line.strip() and not line.strip().startswith('//'):
+                    body.append(line.split('//')[0].strip())
+            for name, ins in blocks:
+                if kernel_substr not in name or name.endswith('.kd'):
+                    continue
+                for i, x in enumerate(ins):
+                    m = re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\], .* sc1', x)
+                    if not m or any(re.match(r's_waitcnt vmcnt\(0\)', y) for y in ins[i + 1:i + 3]):
+                        continue
+                    seen += 1
+                    lo, hi = int(m.group(1)), int(m.group(2))
+                    for y in ins[i + 1:]:
+                        if re.match(r's_waitcnt vmcnt\(0\)', y):
+                            break
+                        if y.startswith('scratch_'):
+                            bad.append((name, x, y)); continue
+                        if re.match(r'global_load_dwordx4 v\[\d+:\d+\], .* sc1', y):      # a sibling prefetch: its own destination
+                            m2 = re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]', y)
+                            if not (int(m2.group(2)) < lo or int(m2.group(1)) > hi):
+                                bad.append((name, x, y))
+                            continue
+                        regs = set()
+                        for a, b in re.findall(r'\bv\[(\d+):(\d+)\]', y):
+                            regs.update(range(int(a), int(b) + 1))
+                        regs.update(int(a) for a in re.findall(r'\bv(\d+)\b', y))
+                        if any(lo <= r <= hi for r in regs):
+                            bad.append((name, x, y))
+    return seen, bad
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--unwaited':
+        seen, bad = unwaited_load_hazards()
+        print('%d un-waited sc1 loads, %d instructions touching their destination before the wait' % (seen, len(bad)))
+        for b in bad:
+            print('  ', b)
+        return 1 if bad else 0
     rows = audit()
     lines = ['| kernel | VGPR (incl. AGPR) | AGPR | SGPR | scratch B | VGPR spills | static LDS B | max WG | waves/SIMD by VGPR |', '|---|---|---|---|---|---|---|---|---|']
     for r in rows:
