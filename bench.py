@@ -477,6 +477,37 @@ class _DryEngine(object):
         return None
 
 
+def gather_per_rank(dist, rank, world, ms_per_step, timer):
+    """N > 1: every rank's own step time and exchange spans, collected on rank 0 (`per_rank` of the JSON line).  The driver computes
+    scaling from its per-N runs; this says WHERE an N-rank step spends its exchange: per gradient bucket the span from its ready event
+    to the end of its all-reduce on the communication stream, and how long the caller's stream stood at the join in front of the
+    optimiser (0 = the exchange hid under the backward)."""
+    mine = {'rank': rank, 'ms_per_step': ms_per_step, 'exchange': timer.summary() if timer is not None else None,
+            'host': os.uname().nodename, 'local_rank': int(os.environ.get('LOCAL_RANK', '0'))}
+    if world == 1:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out if rank == 0 else None
+
+
+def rccl_topology_excerpt(debug_dir, limit=60):
+    """NCCL_DEBUG=INFO lines of the ranks' RCCL initialisation that describe the topology it built (rings / trees / channels, transport per
+    peer: xGMI P2P vs SHM vs NET), for the JSON line of an N > 1 run; the full logs stay in `debug_dir`."""
+    import glob
+    import re
+    keep = re.compile(r'(Channel \d+|Ring \d+|Trees?|via P2P|via SHM|via NET|xGMI|XGMI|nRanks|comm 0x.* rank|Connected all|NCCL_|RCCL|topology|busId)')
+    lines = []
+    for f in sorted(glob.glob(os.path.join(debug_dir, '*'))):
+        try:
+            for ln in open(f, errors='replace'):
+                if keep.search(ln):
+                    lines.append(os.path.basename(f) + ': ' + ln.strip()[:200])
+        except OSError:
+            pass
+    return {'dir': debug_dir, 'files': len(glob.glob(os.path.join(debug_dir, '*'))), 'lines_matched': len(lines), 'excerpt': lines[:limit]}
+
+
 def dry_run(args):
     """Launch / rendezvous rehearsal on CPU (gloo): proves that `python bench.py --gpus N` starts N ranks that find each other and walk
     the product's bucketed tower-gradient mean (wavenet_vocoder.parallel) in step.  Prints ONE line marked dry_run; value is null."""
@@ -492,19 +523,22 @@ def dry_run(args):
     _launch.init_process_group(backend='gloo', rank=rank, world_size=world)
     ones = torch.ones(1)
     dist.all_reduce(ones)
+    from wavenet_vocoder.parallel import ExchangeTimer
     eng = _DryEngine(1000)
     flat = torch.zeros(eng.n_params)
     dist.barrier()
     t0 = time.time()
     ok = True
+    timer = ExchangeTimer()
     for i in range(args.warmup + args.steps):
         grads = torch.full((eng.n_params,), float(rank + 1 + i))
-        allreduce_mean_buckets_(eng, grads)
+        allreduce_mean_buckets_(eng, grads, timer=timer)
         want = sum(r + 1 + i for r in range(world)) / world               # the tower mean every rank must hold
         ok = ok and bool(torch.allclose(grads, torch.full_like(grads, want)))
         flat -= 0.1 * grads
     dist.barrier()
     dt = time.time() - t0
+    per_rank = gather_per_rank(dist, rank, world, dt / (args.warmup + args.steps) * 1e3, timer)
     cs = flat.sum().reshape(1).double()
     lo, hi = cs.clone(), cs.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -513,7 +547,8 @@ def dry_run(args):
                           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
                           'collective': {'backend': 'gloo', 'world_size': dist.get_world_size(), 'ranks_counted_by_allreduce': int(round(ones.item())),
                                          'self_launched': os.environ.get('WN_SELF_LAUNCHED') == '1'},
-                          'tower_mean_correct': ok, 'replicas_identical': bool(lo.item() == hi.item()), 'wall_s': dt,
+                          'tower_mean_correct': ok, 'replicas_identical': bool(lo.item() == hi.item()), 'wall_s': dt, 'per_rank': per_rank,
+                          'config': {'workload_key': args.workload},
                           'note': 'launch rehearsal on CPU: no kernel ran, nothing here is a measurement'}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -582,6 +617,15 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         from wavenet_vocoder import launch as _launch
+        if world > 1 and os.environ.get('WN_BENCH_RCCL_DEBUG', '1') != '0':
+            # the first multi-GPU run explains itself: RCCL's own account of the topology it built goes to side files (one per process),
+            # an excerpt into the JSON line (collective.rccl_topology)
+            rccl_dir = os.environ.get('WN_BENCH_RCCL_DEBUG_DIR') or os.path.join(ROOT, 'bench_rccl_debug_n%d' % world)
+            if rank == 0:
+                os.makedirs(rccl_dir, exist_ok=True)
+            os.environ.setdefault('NCCL_DEBUG', 'INFO')
+            os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,ENV')
+            os.environ.setdefault('NCCL_DEBUG_FILE', os.path.join(rccl_dir, 'rccl.%h.%p.log'))
         if world > 1:
             _launch.init_process_group(backend='nccl', device_id=device)
         else:
@@ -745,6 +789,28 @@ def main():
         eng.profile(False)
         eng.set_batch_parts(0)
     final_loss = float(loss.item())
+    # untimed extra under the multi-rank code path: 10 more steps with the exchange instrumented (device events per bucket and at the
+    # join), every rank's figures gathered on rank 0
+    per_rank = None
+    if use_dist:
+        from wavenet_vocoder.parallel import ExchangeTimer
+        xt = ExchangeTimer()
+        torch.cuda.synchronize(); dist.barrier()
+
+        def timed_exchange_step(i):
+            eng.pack_weights(flat)
+            eng.train_fwd(x, c, y, lengths, 1000 + i, loss)
+            eng.train_bwd(grads)
+            allreduce_mean_buckets_(eng, grads, single_rank_ok=args.force_dist, timer=xt)
+            eng.optim_step(flat, grads, m, v, ema, 1e-4, i)
+        for i in range(10):
+            timed_exchange_step(70000 + i)
+        torch.cuda.synchronize()
+        per_rank = gather_per_rank(dist, rank, world, dt / args.steps * 1e3, xt)
+        if collective is not None and world > 1 and os.environ.get('NCCL_DEBUG_FILE'):
+            dist.barrier()
+            if rank == 0:
+                collective['rccl_topology'] = rccl_topology_excerpt(os.path.dirname(os.environ['NCCL_DEBUG_FILE']))
     if use_dist:
         tmax = torch.tensor([dt], device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -792,7 +858,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'C2 paper_hparams WaveNet 24L/%d-stack R256 G512 S256 10-MoL raw16, 2D upsample [5,5,11], B=%d x T=%d per GPU, dropout %.2f'
-                                   % (hp.stacks, B, T, hp.wavenet_dropout) if args.workload.startswith('c2') else args.workload,
+                                   % (hp.stacks, B, T, hp.wavenet_dropout) if args.workload.startswith('c2') else
+                                   ('C5 Gaussian raw 24 kHz WaveNet %dL/%d-stack R%d G%d S%d, SubPixel %s, legacy scalings, B=%d x T=%d per GPU, dropout %.2f (BASELINE configs[4])'
+                                    % (hp.layers, hp.stacks, hp.residual_channels, hp.gate_channels, hp.skip_out_channels, list(hp.upsample_scales), B, T, hp.wavenet_dropout)
+                                    if args.workload == 'c5_stress' else args.workload),
                        'workload_key': args.workload, 'global_batch': world * B, 'seq_len': T, 'parallelism': 'dp%d' % world,
                        'layers': hp.layers, 'stacks': hp.stacks, 'params': int(eng.n_params)},
             'samples_per_sec_per_gpu': value / world,
@@ -827,7 +896,7 @@ def main():
             'mfma_whole_step_frac': 6.0 * mac * value / world / 1e12 / peak,
             'sustained': sustained, 'with_feeder': with_feeder, 'host_enqueue': host_enqueue, 'device_timeline': device_timeline,
             'grad_buckets': [list(b) for b in eng.grad_buckets()], 'force_dist': bool(args.force_dist),
-            'collective': collective, 'n1_reference': n1_reference,
+            'collective': collective, 'per_rank': per_rank, 'n1_reference': n1_reference,
             'scaling_vs_n1': (value / n1_reference['value']) if n1_reference else None,      # speed-up factor over this box's own 1-rank run
             'emulated_allreduce': ({'gbps': args.emulate_allreduce_gbps, 'bytes': int(eng.n_params) * 4,
                                     'serial_ms': int(eng.n_params) * 4 / (args.emulate_allreduce_gbps * 1e9) * 1e3,

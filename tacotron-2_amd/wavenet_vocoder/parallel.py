@@ -61,7 +61,43 @@ def _comm_stream(device):
     return _COMM_STREAMS[key]
 
 
-def allreduce_mean_buckets_(engine, flat, single_rank_ok=False):
+class ExchangeTimer(object):
+    """Optional instrumentation of allreduce_mean_buckets_ (bench.py under N > 1 ranks: the first multi-GPU run must explain itself).
+    Per call and bucket: the span on the communication stream from "the bucket's ready event has fired" to "its all-reduce has ended", and
+    the time the CALLER's stream stood at the final join (0 when the exchange had already finished under the backward).  GPU: device events
+    (read after a synchronise, in ``summary``); CPU tensors (gloo tests): wall clock."""
+
+    def __init__(self):
+        self.calls = []         # per call: {'buckets': [(ready, done) ...], 'join': (before, after)}
+
+    def _stamp(self, stream=None):
+        if stream is None:
+            import time
+            return time.time()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    @staticmethod
+    def _ms(a, b):
+        return (b - a) * 1e3 if isinstance(a, float) else a.elapsed_time(b)
+
+    def summary(self):
+        """median over the recorded calls: per bucket [first float, floats, all-reduce span ms], the join wait, and exchange start -> end"""
+        import statistics
+        if not self.calls:
+            return None
+        if not isinstance(self.calls[0]['join'][0], float):
+            torch.cuda.synchronize()
+        nb = len(self.calls[0]['buckets'])
+        med = lambda xs: float(statistics.median(xs))
+        return {'calls': len(self.calls),
+                'bucket_ready_to_allreduce_end_ms': [med([self._ms(*c['buckets'][i]) for c in self.calls]) for i in range(nb)],
+                'first_bucket_ready_to_last_allreduce_end_ms': med([self._ms(c['buckets'][0][0], c['buckets'][-1][1]) for c in self.calls]),
+                'caller_stream_wait_at_join_ms': med([self._ms(*c['join']) for c in self.calls])}
+
+
+def allreduce_mean_buckets_(engine, flat, single_rank_ok=False, timer=None):
     """Tower-gradient mean (wavenet.py:564-575) overlapped with the backward pass.
 
     ``engine.train_bwd(flat)`` completes the flat gradient in ``engine.grad_buckets()`` contiguous pieces, top layers first, on
@@ -70,24 +106,38 @@ def allreduce_mean_buckets_(engine, flat, single_rank_ok=False):
     piece.  xGMI is point-to-point (7 x ~153 GB/s per GPU): the pieces stay large (4-6 of ~10-15 MB for the paper model), never
     one call per tensor.  Must be called right after ``engine.train_bwd(flat)`` on the same stream.  CPU tensors (gloo tests) take
     the same bucket walk without streams.  ``single_rank_ok`` runs the walk on a one-rank group too (GPU test of the stream /
-    event ordering against RCCL without a second GPU).
+    event ordering against RCCL without a second GPU).  ``timer`` (an ExchangeTimer): record this call's spans.
     """
     if not is_distributed() or (world_size() == 1 and not single_rank_ok):
         return flat
     buckets = engine.grad_buckets()
     covered = sum(n for _, n in buckets)
+    rec = {'buckets': [], 'join': None} if timer is not None else None
     if not flat.is_cuda:
         for i, (off, n) in enumerate(buckets):
             engine.wait_bucket(i, None)
+            t_ready = timer._stamp() if rec is not None else None
             _mean_(flat[off:off + n])
+            if rec is not None:
+                rec['buckets'].append((t_ready, timer._stamp()))
+        if rec is not None:
+            t = timer._stamp(); rec['join'] = (t, t)
     else:
         cur = torch.cuda.current_stream(flat.device)
         comm = _comm_stream(flat.device)
         for i, (off, n) in enumerate(buckets):
             engine.wait_bucket(i, comm)                     # comm stream waits for bucket i only (not for the rest of the backward)
             with torch.cuda.stream(comm):
+                t_ready = timer._stamp(comm) if rec is not None else None
                 _mean_(flat[off:off + n])
+                if rec is not None:
+                    rec['buckets'].append((t_ready, timer._stamp(comm)))
+        t_before = timer._stamp(cur) if rec is not None else None
         cur.wait_stream(comm)
+        if rec is not None:
+            rec['join'] = (t_before, timer._stamp(cur))
+    if rec is not None:
+        timer.calls.append(rec)
     if covered != flat.numel():                             # alignment padding between tensors is inside the buckets; anything else is a bug
         raise RuntimeError('gradient buckets cover %d of %d floats' % (covered, flat.numel()))
     return flat

@@ -32,6 +32,31 @@ def test_bench_gpus2_starts_two_ranks_that_rendezvous():
     assert d['n_gpus'] == 2 and d['collective'] == {'backend': 'gloo', 'world_size': 2, 'ranks_counted_by_allreduce': 2, 'self_launched': True}
     assert d['tower_mean_correct'] and d['replicas_identical']
     assert 'starting 2 ranks' in r.stderr
+    # the N-rank line explains itself -- every rank's own step time and, per gradient bucket, the span from its
+    # ready event to the end of its all-reduce, plus the caller stream's wait at the join (bench.py gather_per_rank / parallel.ExchangeTimer)
+    pr = d['per_rank']
+    assert [p['rank'] for p in pr] == [0, 1] and all(p['ms_per_step'] > 0 for p in pr)
+    for p in pr:
+        x = p['exchange']
+        assert x['calls'] == 4 and len(x['bucket_ready_to_allreduce_end_ms']) == 3 and all(v >= 0 for v in x['bucket_ready_to_allreduce_end_ms'])
+        assert x['caller_stream_wait_at_join_ms'] >= 0 and x['first_bucket_ready_to_last_allreduce_end_ms'] >= max(x['bucket_ready_to_allreduce_end_ms']) - 1e-6
+
+
+def test_bench_accepts_the_c5_workload_under_n_ranks():
+    """`--workload c5_stress --gpus N` (BASELINE configs[4]: the Gaussian / raw-PCM 24 kHz model on 8 GPUs) parses and launches."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'c5_stress', '--dry-run', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=240, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 2 and d['config']['workload_key'] == 'c5_stress' and len(d['per_rank']) == 2
+
+
+def test_rccl_topology_excerpt_reads_the_debug_files(tmp_path):
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    (tmp_path / 'rccl.h.1.log').write_text('h:1:1 [0] NCCL INFO Channel 00/08 : 0 1 2 3\nh:1:1 [0] NCCL INFO something else\nh:1:1 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via P2P/IPC\n')
+    t = b.rccl_topology_excerpt(str(tmp_path))
+    assert t['files'] == 1 and t['lines_matched'] == 2 and 'via P2P' in t['excerpt'][1]
 
 
 def test_bench_refuses_more_gpus_than_the_node_has():
