@@ -211,6 +211,12 @@ int wn_synth_last_path(const wn_ctx* ctx);
  * (10 streams cost the wall time of one -- 34 - 37 us per sample --, every further stream adds ~3.6 us per sample: real time at
  * 22.05 kHz up to 12 streams per run, profiles/r5u_pipe_batch_scaling.txt), else groups of 8. */
 int wn_synth_pipe_eligible(const wn_ctx* ctx, int32_t B);
+/* 16-bit storage type of the persistent pipeline's weights, hand-off granules and ring queues for the NEXT runs of this context
+ * (fp32 accumulation either way): 1 = IEEE half (the default: raw outputs 1.2e-3 from the reference's fp32 loop at C4's model, 34.8 us per
+ * sample), 0 = bf16 (8.7e-3, 35.0 us; 8 exponent bits).  A half run whose residual stream leaves the half range (|x| > 65504) is
+ * reported by wn_synth_check / the next wn_synthesize as WN_E_HIP ("left the half-precision range"): switch to bf16 and run again.
+ * Environment at wn_create: WN_PIPE_DTYPE=fp16|bf16. */
+int wn_synth_pipe_dtype(wn_ctx* ctx, int32_t half);
 
 /* Stand-alone samplers on [B,O,T] parameters (train-time log path, wavenet.py:302-325). */
 int wn_sample(wn_ctx* ctx, const float* y_hat, int32_t B, int32_t T, const float* noise /*[T,B,nps]*/,

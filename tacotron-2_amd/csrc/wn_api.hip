@@ -220,6 +220,7 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     c->lbias = cfg->use_bias != 0;
     c->wnorm = cfg->weight_normalization != 0;
     c->inference = cfg->inference_only != 0;
+    { const char* ed = getenv("WN_PIPE_DTYPE"); c->pipe_f16 = ed ? (strcmp(ed, "fp16") == 0 || strcmp(ed, "f16") == 0) : WN_PIPE_F16_DEFAULT; }
     { const char* e8 = getenv("WN_GEMM8P"); c->gemm8p = e8 ? atoi(e8) : 0; }      // bit 0: gate, bit 1: d x on the 8-phase kernel (wn_tile8p.h; measured: not faster on any shipped workload)
     c->gin = cfg->gin_channels > 0 ? cfg->gin_channels : 0;
     c->OP = (int)align_up(c->O, 32); c->CP = (int)align_up(c->C, 32);
@@ -445,6 +446,7 @@ extern "C" int wn_fill_noise(wn_ctx* c, float* noise, int32_t B, int32_t T, uint
 }
 extern "C" int wn_synth_check(wn_ctx* c) { if (!c) return WN_E_ARG; return wn_pipe_check(c, true); }
 extern "C" int wn_synth_last_path(const wn_ctx* c) { return c ? c->synth_path : WN_E_ARG; }
+extern "C" int wn_synth_pipe_dtype(wn_ctx* c, int32_t half) { if (!c) return WN_E_ARG; c->pipe_f16 = half != 0; return WN_OK; }
 extern "C" int wn_test_gemm8p_mask(const wn_ctx* c) {
     if (!c) return WN_E_ARG;
     if (c->packs.empty()) return 0;

@@ -151,6 +151,7 @@ struct wn_ctx {
     float* wg_partial = nullptr; size_t wg_partial_bytes = 0;   // split-K partial tiles of the grouped wgrad (wn_wgrad.h)
     bf16_t* GXall = nullptr;              // [L+1][NT][R] gradient wrt every layer input (kept for the grouped W_out wgrad)
 #define WN_ZERO_PAGE_BYTES 4096
+#define WN_PIPE_F16_DEFAULT true       // storage type of the persistent synthesis pipeline when WN_PIPE_DTYPE is not set: IEEE half (1.2e-3 vs bf16's 8.7e-3 from the fp32 loop, same speed)
     bf16_t* zero_page = nullptr;          // zeros: DMA source for out-of-range rows / k-steps (wn_gemm_lds_kernel: 16 B per lane from one address;
                                           // wn_gemm8p_kernel's SGPR-base form: base + 16 * lane, i.e. 1 KiB)
     int gemm8p = 0;                       // WN_GEMM8P at wn_create, bit 0: gate, bit 1: d x on the 8-phase kernel (wn_tile8p.h) where the model fits it; default 0: the 256 x 128 LDS-DMA ring kernel
@@ -188,6 +189,7 @@ struct wn_ctx {
     struct Synth* synth = nullptr;
     void* synth32 = nullptr;              // fp32 synthesis state (wn_synth_f32.hip; cfg.compute_dtype = WN_COMPUTE_F32)
     void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)
+    bool pipe_f16 = false;                // persistent pipeline: IEEE-half weights / hand-offs / queues instead of bf16 (WN_PIPE_DTYPE=fp16|bf16 at wn_create, wn_synth_pipe_dtype)
     int pipe_cap = 0;                     // inference-only contexts: streams of ONE pipeline run the pre-sized buffers hold (0: pipeline not used / not limited)
     void* f32 = nullptr;                  // fp32-forward state (wn_f32.hip), allocated on the first forward of a cfg.compute_dtype = WN_COMPUTE_F32 context
     bool fwd_was_f32 = false;

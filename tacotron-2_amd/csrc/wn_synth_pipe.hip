@@ -96,15 +96,48 @@ __device__ __forceinline__ float dot8(const uint4 w, const uint4 x, float acc) {
     return acc;
 }
 
-// matvec over k-chunks [kc0, kc1) of a [kchunk][rows][8] bf16 LDS image against a bf16 vector in LDS; this lane's row
-__device__ __forceinline__ float mv_rows(const char* W, int rows, int row, const char* vec, int kc0, int kc1) {
+// ---- the pipeline's 16-bit storage type (weights in LDS / registers, hand-off granules, ring queues): H = 0 bf16 (v_dot2_f32_bf16),
+// H = 1 IEEE half (v_dot2_f32_f16: same LDS footprint, same rate, 3 more mantissa bits; fp32 accumulation either way).  The reference's loop
+// is fp32 (modules.py:273-303); the distance to it is a dtype choice: measured in tests/test_hip_round5.py for both.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <int H> __device__ __forceinline__ uint16_t f2n(float f) {
+    if constexpr (H) return __builtin_bit_cast(uint16_t, (_Float16)f); else return f2bf(f);
+}
+template <int H> __device__ __forceinline__ float n2f(uint16_t h) {
+    if constexpr (H) return (float)__builtin_bit_cast(_Float16, h); else return bf2f(h);
+}
+template <int H> __device__ __forceinline__ uint32_t pack_n2(float lo, float hi) {
+    if constexpr (H) { typedef float f32x2_t __attribute__((ext_vector_type(2))); const f32x2_t v = {lo, hi}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t)); }
+    else return pack_bf2(lo, hi);
+}
+template <int H> __device__ __forceinline__ float dot8n(const uint4 w, const uint4 x, float acc) {
+    if constexpr (H) {
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w.x), __builtin_bit_cast(f16x2_t, x.x), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w.y), __builtin_bit_cast(f16x2_t, x.y), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w.z), __builtin_bit_cast(f16x2_t, x.z), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w.w), __builtin_bit_cast(f16x2_t, x.w), acc, false);
+        return acc;
+    } else return dot8(w, x, acc);
+}
+// 8 bf16 values (the upsampled conditioning the training path shares) -> the pipeline's storage type
+template <int H> __device__ __forceinline__ uint4 cvt8_bf16(const uint4 v) {
+    if constexpr (H) {
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w}; uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_n2<1>(bf2f((bf16_t)(in[i] & 0xffffu)), bf2f((bf16_t)(in[i] >> 16)));
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    } else return v;
+}
+
+// matvec over k-chunks [kc0, kc1) of a [kchunk][rows][8] 16-bit LDS image against a 16-bit vector in LDS; this lane's row
+template <int H> __device__ __forceinline__ float mv_rows(const char* W, int rows, int row, const char* vec, int kc0, int kc1) {
     float a0 = 0.0f, a1 = 0.0f;
     int kc = kc0;
     for (; kc + 1 < kc1; kc += 2) {
-        a0 = dot8(*reinterpret_cast<const uint4*>(W + ((size_t)kc * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + kc * 16), a0);
-        a1 = dot8(*reinterpret_cast<const uint4*>(W + ((size_t)(kc + 1) * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + (kc + 1) * 16), a1);
+        a0 = dot8n<H>(*reinterpret_cast<const uint4*>(W + ((size_t)kc * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + kc * 16), a0);
+        a1 = dot8n<H>(*reinterpret_cast<const uint4*>(W + ((size_t)(kc + 1) * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + (kc + 1) * 16), a1);
     }
-    if (kc < kc1) a0 = dot8(*reinterpret_cast<const uint4*>(W + ((size_t)kc * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + kc * 16), a0);
+    if (kc < kc1) a0 = dot8n<H>(*reinterpret_cast<const uint4*>(W + ((size_t)kc * rows + row) * 16), *reinterpret_cast<const uint4*>(vec + kc * 16), a0);
     return a0 + a1;
 }
 
@@ -114,7 +147,7 @@ struct SliceJob { int64_t dst; int64_t src; int32_t rows, kchunks, stride_k, str
 // kind 0: bf16 image [kc][row][8], element (kc,row,e) = scale * params[src + (kc*8+e)*stride_k + rowsrc(row)*stride_row]
 //         rowsrc(row) = row < split ? base + row : GHoff + base + (row - split)   (gate pairs; split = 0 -> identity + base)
 // kind 1: fp32 vector of `rows` floats, element row = scale * params[src + rowsrc(row)]
-__global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __restrict__ slices, const SliceJob* __restrict__ jobs, const int* __restrict__ job_block0, int njobs, int GH) {
+__global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __restrict__ slices, const SliceJob* __restrict__ jobs, const int* __restrict__ job_block0, int njobs, int GH, int f16) {
     int lo = 0, hi = njobs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (job_block0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
     const SliceJob jb = jobs[lo];
@@ -126,7 +159,7 @@ __global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __r
         const int e = (int)(idx & 7); const int64_t r2 = idx >> 3;
         const int row = (int)(r2 % jb.rows), kc = (int)(r2 / jb.rows);
         const float v = jb.scale * params[jb.src + (int64_t)(kc * 8 + e) * jb.stride_k + (int64_t)rowsrc(row) * jb.stride_row];
-        reinterpret_cast<bf16_t*>(slices + jb.dst)[idx] = f2bf(v);
+        reinterpret_cast<bf16_t*>(slices + jb.dst)[idx] = f16 ? f2n<1>(v) : f2bf(v);
     } else {
         if (idx >= jb.rows) return;
         reinterpret_cast<float*>(slices + jb.dst)[idx] = jb.scale * params[jb.src + rowsrc((int)idx)];
@@ -134,6 +167,7 @@ __global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __r
 }
 
 // ======================================================================================================================
+template <int H>
 __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -208,13 +242,13 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     const int tau = tn - d;
                     if (tau >= 0) v = tap1_is_cur ? *reinterpret_cast<const uint4*>(xcur_b + (k - R))
                                                   : __builtin_bit_cast(uint4, ld_g16(reinterpret_cast<const u32x4*>(ringb + (int64_t)(tau & mask) * R + (k - R))));
-                } else v = *reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (k - 2 * R));
+                } else v = cvt8_bf16<H>(*reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (k - 2 * R)));
                 *reinterpret_cast<uint4*>(vec + k) = v;
             }
             lds_barrier();
             {
                 const int per = (KP + 3) / 4, kc0 = wave * per, kc1 = min(KP, kc0 + per);
-                zpart[wave * 64 + lane] = mv_rows(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
+                zpart[wave * 64 + lane] = mv_rows<H>(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
             }
             lds_barrier();
             if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + (a.gbias ? gb : zb[tid]);
@@ -259,11 +293,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 }
             }
             for (int i = KR + tid; i < KP; i += PIPE_THREADS)                // the conditioning chunks
-                *reinterpret_cast<uint4*>(vec + i * 8) = *reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (i * 8 - 2 * R));
+                *reinterpret_cast<uint4*>(vec + i * 8) = cvt8_bf16<H>(*reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (i * 8 - 2 * R)));
             lds_barrier();
             {
                 const int per = (KP + 3) / 4, kc0 = wave * per, kc1 = min(KP, kc0 + per);
-                zpart[wave * 64 + lane] = mv_rows(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
+                zpart[wave * 64 + lane] = mv_rows<H>(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
             }
             lds_barrier();
             if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + (a.gbias ? gb : zb[tid]);
@@ -312,8 +346,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                                 if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
                             }
                             if (!two) g1 = (u32x4){0, 0, 0, 0};
-                            v[0] = bf2f((bf16_t)(g0.x & 0xffff)) + bf2f((bf16_t)(g1.x & 0xffff)); v[1] = bf2f((bf16_t)(g0.x >> 16)) + bf2f((bf16_t)(g1.x >> 16));
-                            v[2] = bf2f((bf16_t)(g0.y & 0xffff)) + bf2f((bf16_t)(g1.y & 0xffff)); v[3] = bf2f((bf16_t)(g0.y >> 16)) + bf2f((bf16_t)(g1.y >> 16));
+                            v[0] = n2f<H>((bf16_t)(g0.x & 0xffff)) + n2f<H>((bf16_t)(g1.x & 0xffff)); v[1] = n2f<H>((bf16_t)(g0.x >> 16)) + n2f<H>((bf16_t)(g1.x >> 16));
+                            v[2] = n2f<H>((bf16_t)(g0.y & 0xffff)) + n2f<H>((bf16_t)(g1.y & 0xffff)); v[3] = n2f<H>((bf16_t)(g0.y >> 16)) + n2f<H>((bf16_t)(g1.y >> 16));
                         }
                         *reinterpret_cast<float4*>(psum + wave * R + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
                     }
@@ -326,7 +360,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     {
                         const float4 q0 = *reinterpret_cast<const float4*>(psum + lane * 4), q1 = *reinterpret_cast<const float4*>(psum + R + lane * 4);
                         const float4 q2 = *reinterpret_cast<const float4*>(psum + 2 * R + lane * 4), q3 = *reinterpret_cast<const float4*>(psum + 3 * R + lane * 4);
-                        const uint2 pk = make_uint2(pack_bf2(q0.x + q1.x + q2.x + q3.x, q0.y + q1.y + q2.y + q3.y), pack_bf2(q0.z + q1.z + q2.z + q3.z, q0.w + q1.w + q2.w + q3.w));
+                        const uint2 pk = make_uint2(pack_n2<H>(q0.x + q1.x + q2.x + q3.x, q0.y + q1.y + q2.y + q3.y), pack_n2<H>(q0.z + q1.z + q2.z + q3.z, q0.w + q1.w + q2.w + q3.w));
                         *reinterpret_cast<uint2*>(myx + lane * 4) = pk;
                         if (wave == 0) *reinterpret_cast<uint2*>(xcur_b + lane * 4) = pk;               // the copy the off-critical-path steps read
                     }
@@ -335,7 +369,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
 #pragma unroll
                     for (int cix = 0; cix < 4; ++cix) {
                         const uint4 xv = *reinterpret_cast<const uint4*>(myx + (4 * k8 + cix) * 8);
-                        zt = dot8(w1t[cix], xv, zt); zs = dot8(w1s[cix], xv, zs);
+                        zt = dot8n<H>(w1t[cix], xv, zt); zs = dot8n<H>(w1s[cix], xv, zs);
                     }
                     zt += dpp_f<DPP_XOR1>(zt); zs += dpp_f<DPP_XOR1>(zs);
                     zt += dpp_f<DPP_XOR2>(zt); zs += dpp_f<DPP_XOR2>(zs);
@@ -343,17 +377,17 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     if (k8 == 0) {
                         zt += zpast[s * 64 + zrow_t]; zs += zpast[s * 64 + zrow_s];
                         const float e = __expf(2.0f * zt);
-                        ucur[8 * wave + pr] = f2bf((1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f)) * __builtin_amdgcn_rcpf(1.0f + __expf(-zs)));
+                        ucur[8 * wave + pr] = f2n<H>((1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f)) * __builtin_amdgcn_rcpf(1.0f + __expf(-zs)));
                     }
                     lds_barrier();                                                                 // (B) the 32 gate outputs of this CU
                     // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0]) -> granules (modules.py:512-521)
                     if (!top) {
                         float o = 0.0f, o2 = 0.0f;
-                        o = dot8(wor[0], *reinterpret_cast<const uint4*>(ucur), o); o2 = dot8(wor[1], *reinterpret_cast<const uint4*>(ucur + 8), o2);
-                        o = dot8(wor[2], *reinterpret_cast<const uint4*>(ucur + 16), o); o2 = dot8(wor[3], *reinterpret_cast<const uint4*>(ucur + 24), o2);
+                        o = dot8n<H>(wor[0], *reinterpret_cast<const uint4*>(ucur), o); o2 = dot8n<H>(wor[1], *reinterpret_cast<const uint4*>(ucur + 8), o2);
+                        o = dot8n<H>(wor[2], *reinterpret_cast<const uint4*>(ucur + 16), o); o2 = dot8n<H>(wor[3], *reinterpret_cast<const uint4*>(ucur + 24), o2);
                         o += o2;
-                        if (j == 0) o += bf2f(myx[tid]) + ob[tid];
-                        const uint32_t me = f2bf(o * a.rho);
+                        if (j == 0) o += n2f<H>(myx[tid]) + ob[tid];
+                        const uint32_t me = f2n<H>(o * a.rho);
                         const uint32_t n1 = dpp_u<DPP_QUAD_BCAST(1)>(me), n2 = dpp_u<DPP_QUAD_BCAST(2)>(me), n3 = dpp_u<DPP_QUAD_BCAST(3)>(me);
                         if (a.trace && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
                         if ((lane & 3) == 0) {
@@ -362,32 +396,32 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                             st_g16_local(a.XML + gi, g); st_g16(a.XM + gi, g);
                         }
                     }
-                    if (tid < R) xcur_f[tid] = bf2f(myx[tid]);
+                    if (tid < R) xcur_f[tid] = n2f<H>(myx[tid]);
                 } else {
                     for (int r = tid; r < R; r += PIPE_THREADS) {
-                        const bf16_t xb = f2bf(psum[r] + psum[R + r] + psum[2 * R + r] + psum[3 * R + r]);
-                        xcur_b[r] = xb; xcur_f[r] = bf2f(xb);
+                        const bf16_t xb = f2n<H>(psum[r] + psum[R + r] + psum[2 * R + r] + psum[3 * R + r]);
+                        xcur_b[r] = xb; xcur_f[r] = n2f<H>(xb);
                     }
                     lds_barrier();
                     // ---- 2. z = z_past + W_tap2 x ; gate (modules.py:494-510)
                     {
                         const int KC = R / 8, per = (KC + 3) / 4, kc0 = wave * per, kc1 = min(KC, kc0 + per);
-                        zpart[wave * 64 + lane] = mv_rows(W1c, 64, lane, reinterpret_cast<const char*>(xcur_b), kc0, kc1);
+                        zpart[wave * 64 + lane] = mv_rows<H>(W1c, 64, lane, reinterpret_cast<const char*>(xcur_b), kc0, kc1);
                     }
                     lds_barrier();
                     if (tid < 32) {
                         const float za = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zpast[s * 64 + tid];
                         const float zs = zpart[32 + tid] + zpart[96 + tid] + zpart[160 + tid] + zpart[224 + tid] + zpast[s * 64 + 32 + tid];
                         const float e = __expf(2.0f * za);
-                        ucur[tid] = f2bf((1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zs))));
+                        ucur[tid] = f2n<H>((1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zs))));
                     }
                     lds_barrier();
                     // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0])  -> granules (modules.py:512-521)
                     if (!top) {
                         for (int r = tid; r < R; r += PIPE_THREADS) {
-                            float o = mv_rows(Wo, R, r, reinterpret_cast<const char*>(ucur), 0, 4);
+                            float o = mv_rows<H>(Wo, R, r, reinterpret_cast<const char*>(ucur), 0, 4);
                             if (j == 0) o += xcur_f[r] + ob[r];
-                            outp[r] = f2bf(o * a.rho);
+                            outp[r] = f2n<H>(o * a.rho);
                         }
                         lds_barrier();
                         for (int g = tid; g < NXG; g += PIPE_THREADS) {
@@ -405,7 +439,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 {
                     // own contribution first (the running sum of CU (l-1, j) is published ~1 us after its x partial: no point in
                     // polling early, and every useless poll slows somebody's critical hop)
-                    for (int r = tid; r < S; r += PIPE_THREADS) skp[r] = mv_rows(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
+                    for (int r = tid; r < S; r += PIPE_THREADS) skp[r] = mv_rows<H>(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
                     if (tid < 4) skp[S + tid] = 0.0f;
                     lds_barrier();
                     if (l > 0) {       // one poll per GRANULE (3 channels), by the first (S+2)/3 threads
@@ -435,6 +469,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
                     for (int i = tid; i < R / 8; i += PIPE_THREADS)
                         *reinterpret_cast<uint4*>(ringb + (int64_t)(t & mask) * R + i * 8) = *reinterpret_cast<const uint4*>(xcur_b + i * 8);
+                    if constexpr (H) {      // half has 5 exponent bits: a residual stream beyond 65504 became inf in the hand-off -- report it, do not synthesise garbage
+                        if (tid < R && !(fabsf(xcur_f[tid]) <= 65504.0f)) pipe_abort(abortf, 400 + l);
+                    }
                     if (t + 1 < T) pre_finish(s, t + 1, d == 1);      // ring rows are read past this CU's L1 (sc1): slots are recycled
                 }
                 if (pipe_aborted(abortf)) return;
@@ -481,7 +518,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 float v;
                 if (mode == 2) v = a.win_global[(int64_t)nxt_i[0] * R + r] + a.bin_global[r];
                 else v = win[r] * nxt_f[0] + bin[r];
-                outp[r] = f2bf(v);
+                outp[r] = f2n<H>(v);
             }
             lds_barrier();
             for (int g = tid; g < R / 4; g += PIPE_THREADS) {
@@ -544,7 +581,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 for (int r = tid; r < S; r += PIPE_THREADS) {
                     float tot = sb[r];
                     for (int w = 0; w < 4 && w < P; ++w) tot += psum[w * (S + 4) + r];
-                    r1[r] = f2bf(fmaxf(tot, 0.0f));
+                    r1[r] = f2n<H>(fmaxf(tot, 0.0f));
                 }
                 lds_barrier();
                 // ---- head convolutions (wavenet.py:840-844)
@@ -552,23 +589,23 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     float h0 = 0.0f, h1 = 0.0f, h2a = 0.0f, h3 = 0.0f;
 #pragma unroll
                     for (int kc = 0; kc < 32; kc += 4) {
-                        h0 = dot8(wh1r[kc], *reinterpret_cast<const uint4*>(r1 + kc * 8), h0); h1 = dot8(wh1r[kc + 1], *reinterpret_cast<const uint4*>(r1 + (kc + 1) * 8), h1);
-                        h2a = dot8(wh1r[kc + 2], *reinterpret_cast<const uint4*>(r1 + (kc + 2) * 8), h2a); h3 = dot8(wh1r[kc + 3], *reinterpret_cast<const uint4*>(r1 + (kc + 3) * 8), h3);
+                        h0 = dot8n<H>(wh1r[kc], *reinterpret_cast<const uint4*>(r1 + kc * 8), h0); h1 = dot8n<H>(wh1r[kc + 1], *reinterpret_cast<const uint4*>(r1 + (kc + 1) * 8), h1);
+                        h2a = dot8n<H>(wh1r[kc + 2], *reinterpret_cast<const uint4*>(r1 + (kc + 2) * 8), h2a); h3 = dot8n<H>(wh1r[kc + 3], *reinterpret_cast<const uint4*>(r1 + (kc + 3) * 8), h3);
                     }
-                    h2[tid] = f2bf(fmaxf((h0 + h1) + (h2a + h3) + b1[tid], 0.0f));
+                    h2[tid] = f2n<H>(fmaxf((h0 + h1) + (h2a + h3) + b1[tid], 0.0f));
                 } else {
-                    for (int r = tid; r < S; r += PIPE_THREADS) h2[r] = f2bf(fmaxf(mv_rows(Wh1, S, r, reinterpret_cast<const char*>(r1), 0, S / 8) + b1[r], 0.0f));
+                    for (int r = tid; r < S; r += PIPE_THREADS) h2[r] = f2n<H>(fmaxf(mv_rows<H>(Wh1, S, r, reinterpret_cast<const char*>(r1), 0, S / 8) + b1[r], 0.0f));
                 }
                 lds_barrier();
                 if (hfast) {      // thread = (row = tid >> 3, k-eighth = tid & 7): 4 chunks each, summed with DPP
                     const int row = tid >> 3, ke = tid & 7;
                     float y = 0.0f;
 #pragma unroll
-                    for (int cix = 0; cix < 4; ++cix) y = dot8(wh2r[cix], *reinterpret_cast<const uint4*>(h2 + (ke * 4 + cix) * 8), y);
+                    for (int cix = 0; cix < 4; ++cix) y = dot8n<H>(wh2r[cix], *reinterpret_cast<const uint4*>(h2 + (ke * 4 + cix) * 8), y);
                     y += dpp_f<DPP_XOR1>(y); y += dpp_f<DPP_XOR2>(y); y += dpp_f<DPP_HALF_MIRROR>(y);
                     if (ke == 0) yraw[row] = (row < O) ? y + b2[row] : 0.0f;
                 } else {
-                    for (int r = tid; r < OP; r += PIPE_THREADS) yraw[r] = (r < O) ? mv_rows(Wh2, OP, r, reinterpret_cast<const char*>(h2), 0, S / 8) + b2[r] : 0.0f;
+                    for (int r = tid; r < OP; r += PIPE_THREADS) yraw[r] = (r < O) ? mv_rows<H>(Wh2, OP, r, reinterpret_cast<const char*>(h2), 0, S / 8) + b2[r] : 0.0f;
                 }
                 lds_barrier();
                 if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 1] = wall_clock64();
@@ -634,6 +671,7 @@ struct Pipe {
     bool pending = false;               // a run has been enqueued whose flag has not been inspected yet
     int test_aborts = 0;
     int layer_lds = 0, head_lds = 0;
+    bool f16 = false;                   // 16-bit storage type of weights / hand-offs / queues: IEEE half instead of bf16 (wn_ctx::pipe_f16 at the run)
     PipeArgs proto;
     hipStream_t priv = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -743,7 +781,7 @@ static int pipe_build(wn_ctx* c, Pipe* p) {
 
 // small fix-up kernels of the slice images: z bias = dil_b + cin_b ; skip bias total ; Wh2 image with row pitch OP
 __global__ void wn_pipe_fixup_kernel(const float* __restrict__ params, char* __restrict__ slices, const PipeArgs a, int64_t layer_slice_bytes,
-                                     const float* __restrict__ skip_bias_total, int64_t fin2_k) {
+                                     const float* __restrict__ skip_bias_total, int64_t fin2_k, int f16) {
     const int l = blockIdx.x / a.P, j = blockIdx.x % a.P;
     if (blockIdx.x < a.L * a.P) {
         float* zb = reinterpret_cast<float*>(slices + (int64_t)(l * a.P + j) * layer_slice_bytes + a.off_zb);
@@ -759,7 +797,8 @@ __global__ void wn_pipe_fixup_kernel(const float* __restrict__ params, char* __r
         const int n = (a.S / 8) * a.OP * 8;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int e = i & 7, row = (i >> 3) % a.OP, kc = (i >> 3) / a.OP;
-            w[i] = row < a.O ? f2bf(params[fin2_k + (int64_t)(kc * 8 + e) * a.O + row]) : (bf16_t)0;
+            const float wv = row < a.O ? params[fin2_k + (int64_t)(kc * 8 + e) * a.O + row] : 0.0f;
+            w[i] = f16 ? f2n<1>(wv) : f2bf(wv);
         }
     }
 }
@@ -801,6 +840,9 @@ int wn_pipe_check(wn_ctx* c, bool wait) {
     if (flag != 0) {
         *p->abort_host = 0;
         (void)hipMemsetAsync(p->abort_dev + 1, 0, 4, p->priv);      // reported: the next runs start clean (ordered before them on the pipeline's stream)
+        if (flag >= 400 && flag < 400 + 64)
+            WN_FAIL(c, WN_E_HIP, "synthesis pipeline (fp16 storage): the residual stream of layer %d left the half-precision range (|x| > 65504); "
+                                 "use the bf16 pipeline (WN_PIPE_DTYPE=bf16) for this model", flag - 400);
         WN_FAIL(c, WN_E_HIP, "synthesis pipeline timed out waiting for a hand-off (code %d): are all %d workgroups resident?", flag, p->grid);
     }
     return WN_OK;
@@ -813,6 +855,7 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     int rc;
     if ((rc = wn_pipe_reserve(c, B, T))) return rc;
     Pipe* p = (Pipe*)c->pipe;
+    p->f16 = c->pipe_f16;
     hipStream_t st = p->priv;
     WN_HIP(c, hipEventRecord(p->ev0, caller_st));
     WN_HIP(c, hipStreamWaitEvent(st, p->ev0, 0));
@@ -824,10 +867,10 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     a.slices = p->slices; a.layer_slice_bytes = p->layer_slice_bytes; a.head_slice_off = p->head_slice_off;
     // ---- slice images from the current parameters (cheap: 27 MB)
     {
-        hipLaunchKernelGGL(wn_pipe_slice_kernel, dim3(p->nblocks), dim3(256), 0, st, c->params_dev, p->slices, p->jobs_dev, p->job_block0_dev, p->njobs, c->GH);
+        hipLaunchKernelGGL(wn_pipe_slice_kernel, dim3(p->nblocks), dim3(256), 0, st, c->params_dev, p->slices, p->jobs_dev, p->job_block0_dev, p->njobs, c->GH, p->f16 ? 1 : 0);
         WN_LAUNCH_CHECK(c);
         for (int l = 0; l < L; ++l) a.cin_b_off[l] = c->lay[l].cin_b;
-        hipLaunchKernelGGL(wn_pipe_fixup_kernel, dim3(L * P + 1), dim3(256), 0, st, c->params_dev, p->slices, a, p->layer_slice_bytes, c->skip_bias_total, c->fin2_k);
+        hipLaunchKernelGGL(wn_pipe_fixup_kernel, dim3(L * P + 1), dim3(256), 0, st, c->params_dev, p->slices, a, p->layer_slice_bytes, c->skip_bias_total, c->fin2_k, p->f16 ? 1 : 0);
         WN_LAUNCH_CHECK(c);
     }
     // ---- mailboxes, rings
@@ -858,8 +901,13 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         a.trace = trace_dev; a.trace_t0 = 500; a.trace_n = trace_n;
     }
     const int lds_bytes = std::max(p->layer_lds + 256 * B, p->head_lds);      // z_past [B][64] fp32 per layer CU (wn_pipe_eligible checked that it fits)
-    WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL(wn_synth_pipe_kernel, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
+    if (p->f16) {
+        WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL(wn_synth_pipe_kernel<1>, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
+    } else {
+        WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL(wn_synth_pipe_kernel<0>, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
+    }
     WN_LAUNCH_CHECK(c);
     // the abort flag travels to pinned host memory behind the kernel; nobody waits for it here (wn_pipe_check / the next call read it)
     if (const char* e = getenv("WN_PIPE_TEST_ABORT")) {      // test hook: raise the flag as a timed-out hand-off would, until `n` runs of this context were flagged in total

@@ -98,6 +98,7 @@ def load_library():
         'wn_synth_check': (ctypes.c_int, [vp]),
         'wn_synth_last_path': (ctypes.c_int, [vp]),
         'wn_test_gemm8p_mask': (ctypes.c_int, [vp]),
+        'wn_synth_pipe_dtype': (ctypes.c_int, [vp, i32]),
         'wn_synth_pipe_eligible': (ctypes.c_int, [vp, i32]),
         'wn_sample': (ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         'wn_mulaw': (ctypes.c_int, [vp, vp, i64, vp]),
@@ -336,6 +337,10 @@ class Engine:
         if rc < 0:
             self._ok(rc)
         return rc == 1
+
+    def pipeline_dtype(self, half):
+        """16-bit storage type of the persistent pipeline for the next runs: True = IEEE half (default), False = bf16."""
+        self._ok(self.lib.wn_synth_pipe_dtype(self.h, 1 if half else 0))
 
     @property
     def synth_path(self):

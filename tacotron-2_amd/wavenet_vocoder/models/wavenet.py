@@ -313,16 +313,22 @@ class WaveNet(object):
         try:
             group = attempt(spg)
         except _ext.WnError as e:
-            if not check or self.engine.synth_path != 'pipeline' or 'timed out' not in str(e):
+            out_of_range = 'half-precision range' in str(e)
+            if not check or self.engine.synth_path != 'pipeline' or not ('timed out' in str(e) or out_of_range):
                 raise
-            log('WaveNet synthesis: {} -- re-running this batch on the launch-per-layer graph path'.format(e))
             self.synth_fallbacks = getattr(self, 'synth_fallbacks', 0) + 1
             torch.cuda.synchronize()
             try:
                 self.engine.synth_check()          # (a flag of a later group of the same batch may still be pending)
             except _ext.WnError:
                 pass
-            group = attempt(32)
+            if out_of_range:                       # the residual stream of this model exceeds 65504 somewhere: bf16 storage (8 exponent bits) from now on
+                log('WaveNet synthesis: {} -- re-running this batch with bf16 pipeline storage'.format(e))
+                self.engine.pipeline_dtype(False)
+                group = attempt(spg)
+            else:
+                log('WaveNet synthesis: {} -- re-running this batch on the launch-per-layer graph path'.format(e))
+                group = attempt(32)
         if getattr(self, '_logged_synth_path', None) != self.engine.synth_path:
             self._logged_synth_path = self.engine.synth_path
             log('WaveNet synthesis path: {} ({} streams per run)'.format(self.engine.synth_path, group))

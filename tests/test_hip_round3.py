@@ -90,11 +90,11 @@ def test_c4_full_length_one_stream_vs_oracle():
     raw = raw.cpu()
     with torch.no_grad():
         xs = torch.cat([torch.zeros(1, 1), wav[:, :-1]], 1).view(1, 1, T)
-        r_em = O.step(params, cfg, xs, c, emulate_bf16=True)
+        r_em = O.step(params, cfg, xs, c)                # the FP32 oracle: the pipeline stores IEEE half since round 5 (measured 1.2e-3; bf16 storage was 9.7e-3 from the emulating oracle)
     e = rel_err(raw, r_em)
     seg = [rel_err(raw[:, :, a:a + 22055], r_em[:, :, a:a + 22055]) for a in range(0, T, 22055)]
-    print('\npipe C4 full length (110 275 steps) vs emulating oracle: %.3e; per second of audio: %s' % (e, ' '.join('%.2e' % s for s in seg)))
-    assert e < 2.5e-2 and max(seg) < 2.5e-2           # flat over the utterance: no drift with the ring wraps (13 wraps of the d = 2048 rings)
+    print('\npipe C4 full length (110 275 steps) vs the FP32 oracle: %.3e; per second of audio: %s' % (e, ' '.join('%.2e' % s for s in seg)))
+    assert e < 4e-3 and max(seg) < 4e-3               # flat over the utterance: no drift with the ring wraps (13 wraps of the d = 2048 rings)
     exp = O.sample_from_discretized_mix_logistic(raw, nz_or['u1'].permute(1, 0, 2), nz_or['u2'].t(), cfg.log_scale_min)
     assert torch.allclose(out.cpu(), exp, atol=2e-5)
 
@@ -237,7 +237,7 @@ def test_pipe_global_conditioning_matches_oracle(kw):
     e = rel_err(raw.cpu(), r_or)
     per = [rel_err(raw.cpu()[b], r_or[b]) for b in range(B)]
     print('\npipe + global conditioning: raw rel err %.3e (per stream %s)' % (e, ' '.join('%.2e' % v for v in per)))
-    assert max(per) < 1.4e-2
+    assert max(per) < 4e-3                               # half storage (bf16 storage measured 3.9 - 5.5e-3)
     # a wrong speaker must be visible at this tolerance (the bias is not a rounding-level effect)
     g2 = torch.roll(g, 1, 0)
     _, r_wrong = O.incremental(params, cfg, c, noise=nz_or, test_inputs=wav.unsqueeze(-1), formulation='reference', g=g2)

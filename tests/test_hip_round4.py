@@ -209,7 +209,7 @@ def test_pipe_whole_batch_in_one_run(B):
     _, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=wav.unsqueeze(-1), formulation='ring')
     per = [rel_err(raw.cpu()[b], r_or[b]) for b in range(B)]
     print('\npipeline, %d streams in one run: worst stream %.2e' % (B, max(per)))
-    assert max(per) < 1.4e-2
+    assert max(per) < 4e-3                               # half storage (bf16 storage measured 6.1e-3)
     model = WaveNet(hp)
     model.build(B, T)
     model.params.copy_(upload_params(model.engine, params)); model._dirty = True
@@ -254,7 +254,7 @@ def test_pipe_c4_at_the_benched_batch_8x110275():
     with torch.no_grad():
         for b in range(B):
             xs = torch.cat([torch.zeros(1, 1), wav[b:b + 1, :-1]], 1)[:, w0:].reshape(1, 1, T - w0)
-            r_em = O.step(params, cfg, xs, c[b:b + 1, :, fr0:], emulate_bf16=True)[0]
+            r_em = O.step(params, cfg, xs, c[b:b + 1, :, fr0:])[0]          # FP32 oracle (half storage since round 5; bf16 storage: 9.7 - 9.9e-3 vs the emulating oracle, profiles/r5a_parity_c4_b8_full.json)
             per.append(rel_err(raw[b, :, T - sec:], r_em[:, T - sec - w0:]))
     rec = {'B': B, 'T': T, 'wall_s_device': dt, 'rtf_per_stream': dt / (T / 22050.0), 'rel_l2_final_second_per_stream': per, 'window_start': w0, 'oracle_seconds': time.time() - t1}
     print('\npipe C4 at the benched batch (8 x 110 275), final second of every stream: %s; device %.2f s (RTF %.2f), oracle %.0f s'
@@ -263,6 +263,6 @@ def test_pipe_c4_at_the_benched_batch_8x110275():
     if d:
         with open(os.path.join(d, 'parity_c4_b8_final_second.json'), 'w') as f:
             json.dump(rec, f, indent=1)
-    assert max(per) < 2.5e-2
+    assert max(per) < 4e-3
     exp = O.sample_from_discretized_mix_logistic(raw, nz_or['u1'].permute(1, 0, 2), nz_or['u2'].t(), cfg.log_scale_min)
     assert torch.allclose(out.cpu(), exp, atol=2e-5)

@@ -34,7 +34,7 @@ def test_pipe_teacher_forced_matches_oracle(kw):
     o_or, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=ti_or, formulation='reference')
     e = rel_err(raw.cpu(), r_or)
     print('\npipe teacher-forced raw rel err %.3e' % e)
-    assert e < 1.4e-2                                  # measured 3.3 - 4.4e-3
+    assert e < 4e-3                                    # half storage (the default since round 5): measured 0.9 - 1.2e-3 (bf16 storage: 3.3 - 4.4e-3, tests/test_hip_round5.py)
     if cfg.input_type == 'mulaw-quantize':
         exp = torch.stack([O.sample_categorical(raw.cpu()[:, :, t], nz_or['gumbel_u'][t]) for t in range(T)], 1)
         assert torch.equal(out.cpu().long(), exp)                                   # bit-exact class ids
@@ -48,7 +48,7 @@ def test_pipe_teacher_forced_matches_oracle(kw):
     out2 = torch.empty_like(out); raw2 = torch.empty_like(raw)
     eng.synthesize(c.cuda(), nz_dev.cuda(), out2, raw2, ti_dev, steps_per_graph=8)
     torch.cuda.synchronize()
-    assert rel_err(raw, raw2) < 1.4e-2
+    assert rel_err(raw, raw2) < 1.4e-2                 # (the launch-per-layer path keeps bf16 weights and queues)
 
 
 def test_pipe_free_running_feedback_path():
@@ -86,8 +86,10 @@ def test_pipe_incremental_equals_batch_forward_on_device(B, kw):
 # ---- C4 scale (BASELINE configs[3]): the 24-layer / 2-stack paper model, against the ORACLE (not against another HIP path) ------
 PAPER_FULL = dict(PAPER_WIDTH, layers=24, stacks=2, out_channels=30, upsample_type='2D', upsample_scales=[5, 5, 11], hop_size=275,
                   legacy=False, residual_legacy=False, NN_scaler=0.1, log_scale_min=float(np.log(1e-14)))
-TOL_RAW_EMUL = 2.5e-2     # raw network outputs vs the bf16-emulating oracle  (measured 1.03e-2: the sqrt(depth) rounding-decorrelation floor, see test_hip_bench_geometry.py)
-TOL_RAW_FP32 = 2.5e-2     # ... vs the fp32 oracle (reference arithmetic)       (measured 8.7e-3; profiles/r2e_pytest_gpu_verbose.log)
+# The pipeline stores weights, hand-offs and queues in IEEE half since round 5 (fp32 accumulation): its raw outputs are compared with the FP32
+# oracle -- the reference's arithmetic (modules.py:273-303) -- directly.  Measured 1.15 - 1.2e-3 at this depth (bf16 storage: 8.7e-3 from the
+# fp32 oracle, 9.7e-3 from the bf16-emulating one; both dtypes side by side: tests/test_hip_round5.py, profiles/r6g_parity_pipe_dtype.json).
+TOL_RAW_FP32 = 4e-3
 
 
 def _oracle_teacher_forced(params, cfg, wav, c, emulate):
@@ -113,16 +115,12 @@ def test_pipe_c4_scale_teacher_forced_vs_oracle():
     eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, wav.contiguous().cuda(), steps_per_graph=0)
     torch.cuda.synchronize()
     raw = raw.cpu()
-    r_em = _oracle_teacher_forced(params, cfg, wav, c, True)
-    per = [rel_err(raw[b], r_em[b]) for b in range(B)]
-    tail = [rel_err(raw[b, :, 17000:], r_em[b, :, 17000:]) for b in range(B)]      # steps whose whole receptive field went through wrapped rings
-    print('\npipe C4-scale teacher-forced vs emulating oracle: per stream ' + ' '.join('%.2e' % e for e in per))
+    r_fp = _oracle_teacher_forced(params, cfg, wav, c, False)
+    per = [rel_err(raw[b], r_fp[b]) for b in range(B)]
+    tail = [rel_err(raw[b, :, 17000:], r_fp[b, :, 17000:]) for b in range(B)]      # steps whose whole receptive field went through wrapped rings
+    print('\npipe C4-scale teacher-forced vs the FP32 oracle: per stream ' + ' '.join('%.2e' % e for e in per))
     print('   last 5000 steps only: ' + ' '.join('%.2e' % e for e in tail))
-    assert max(per) < TOL_RAW_EMUL and max(tail) < TOL_RAW_EMUL
-    r_fp = _oracle_teacher_forced(params, cfg, wav[:2], c[:2], False)
-    e_fp = [rel_err(raw[b], r_fp[b]) for b in range(2)]
-    print('   vs fp32 oracle (streams 0, 1): ' + ' '.join('%.2e' % e for e in e_fp))
-    assert max(e_fp) < TOL_RAW_FP32
+    assert max(per) < TOL_RAW_FP32 and max(tail) < TOL_RAW_FP32
     # the sampler ran on those raw outputs (mixture.py:76-107)
     exp = O.sample_from_discretized_mix_logistic(raw, nz_or['u1'].permute(1, 0, 2), nz_or['u2'].t(), cfg.log_scale_min)
     assert torch.allclose(out.cpu(), exp, atol=2e-5)
@@ -138,7 +136,7 @@ def test_pipe_c4_scale_free_running_feedback():
     eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, None, steps_per_graph=0)
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
-    r_em = _oracle_teacher_forced(params, cfg, out.cpu(), c, True)
-    e = rel_err(raw.cpu(), r_em)
-    print('\npipe C4-scale free-running vs emulating oracle (fed the device samples): %.2e' % e)
-    assert e < TOL_RAW_EMUL
+    r_fp = _oracle_teacher_forced(params, cfg, out.cpu(), c, False)
+    e = rel_err(raw.cpu(), r_fp)
+    print('\npipe C4-scale free-running vs the FP32 oracle (fed the device samples): %.2e' % e)
+    assert e < TOL_RAW_FP32
