@@ -49,6 +49,7 @@ struct PipeArgs {
     int32_t* abort_flag;
     const float* gbias;              // global conditioning: [L][B][G] gate bias per stream (b_dil + b_cin + W_g^T g_s + b_g), else null
     unsigned long long* trace; int32_t trace_t0, trace_n;     // optional timestamps (WN_PIPE_TRACE=1): [trace_n][2*(L+2)] of s_memrealtime
+    unsigned long long* svc; int32_t svc_l, svc_s;            // optional (WN_PIPE_SVC_TRACE=1): [trace_n][16] stamps of ONE layer CU's iteration for one stream (where its service time goes)
     int64_t ring_off[32]; int64_t cin_b_off[32]; int32_t ring_mask[32]; int32_t dil[32];
 };
 
@@ -75,7 +76,13 @@ __device__ __forceinline__ u32x4 poll_ld(__amdgpu_buffer_rsrc_t r, int byte_off)
     asm volatile("" ::: "memory");          // keeps successive polls of the same address from being merged
     return v;
 }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t poll_rsrc(const void* base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000); }
+// (the base is wave-uniform by construction -- mailbox of (layer, stream), chosen by a per-wave flag -- but hipcc cannot prove it and wraps every
+// load through the descriptor in a waterfall loop of readfirstlane / compare / branch: the descriptor is built from readfirstlane'd words)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t poll_rsrc(const void* base, int bytes) {
+    const uint64_t b = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
 
 __device__ __forceinline__ bool pipe_aborted(const int32_t* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 __device__ __forceinline__ void pipe_abort(int32_t* f, int code) { __hip_atomic_store(f, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -167,6 +174,7 @@ __global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __r
 }
 
 // ======================================================================================================================
+#define PIPE_SVC(k) do { if (a.svc && l == a.svc_l && j == 0 && s == a.svc_s && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.svc[(size_t)(t - a.trace_t0) * 16 + (k)] = wall_clock64(); } while (0)
 template <int H>
 __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -260,7 +268,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         // skip chain, so their latency lies under the skip matvec and the wait for the previous layer's running sum instead of in front of
         // the matvec.  Wave 3 on purpose: vmcnt retires in order per WAVE, and waves 0 / 1 poll the skip granules in between (a poll
         // behind an older outstanding load would wait for it: the skip chain is the second latency-critical chain of the ring).
-        const int KR = 2 * R / 8;                                            // 16-B chunks of the two past taps
+        const bool many = B > 10;            // (see the sample loop)
+        const int KR = 2 * R / 8;                                            // 16-B chunks of the two past taps (KP <= 128: two chunks per lane of wave 3, wn_pipe_eligible)
         u32x4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0};
         auto pre_issue = [&](int s, int tn, bool tap1_is_cur) {
             if (wave != 3) return;
@@ -270,12 +279,30 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 const int i = lane + 64 * q, k = i * 8;
                 u32x4& dst = q ? pf1 : pf0;
                 dst = (u32x4){0, 0, 0, 0};
-                if (i < KR) {
-                    const bool tap0 = k < R;
-                    const int tau = tn - (tap0 ? 2 * d : d);
-                    if (tau >= 0 && (tap0 || !tap1_is_cur)) ld_g16_nowait(dst, reinterpret_cast<const u32x4*>(ringb + (int64_t)(tau & mask) * R + (tap0 ? k : k - R)));
-                }
+                // ONE load site (an address select, not two exec-masked branches writing the same destination registers): ring row of a past tap,
+                // or -- round 5 -- the conditioning chunk c(s, tn) of the same pre-multiplication: that read used to sit INSIDE pre_finish, a
+                // dependent global load on the layer CU's service path (0.26 us per stream, profiles/r6i_pipe_svc_trace.txt vs r6k)
+                const bool tap0 = k < R;
+                const int tau = tn - (tap0 ? 2 * d : d);
+                const bool is_tap = i < KR, is_cond = !is_tap && i < KP;
+                const bf16_t* src = is_tap ? ringb + (int64_t)(tau & mask) * R + (tap0 ? k : k - R) : a.cbt + ((int64_t)s * T + tn) * C + (k - 2 * R);
+                if ((is_tap && tau >= 0 && (tap0 || !tap1_is_cur)) || is_cond) ld_g16_nowait(dst, reinterpret_cast<const u32x4*>(src));
             }
+        };
+        u32x4 xp0 = {0, 0, 0, 0}, xp1 = {0, 0, 0, 0}; bool xp_valid = false;
+        // the next stream's x granules (first pass), requested inside pre_finish once wave 3 has consumed its ring prefetch (its hand-written
+        // vmcnt(0) would otherwise wait for this load too) and consumed at the top of the next iteration, ~0.6 us later: an L2 round trip
+        auto x_request = [&](int s, int t) {
+            xp_valid = false;
+            if (!(many && wave < nprod)) return;
+            const int sn = s + 1 < B ? s + 1 : 0;
+            if (!(s + 1 < B || t + 1 < T)) return;
+            const __amdgpu_buffer_rsrc_t rn0 = poll_rsrc((loc0 ? a.XML : a.XM) + ((int64_t)(l * B + sn) * P) * PIPE_XG, P * PIPE_XG * 16);
+            const __amdgpu_buffer_rsrc_t rn1 = poll_rsrc((loc1 ? a.XML : a.XM) + ((int64_t)(l * B + sn) * P) * PIPE_XG, P * PIPE_XG * 16);
+            const bool two = wave + 4 < nprod;
+            const int o0 = (wave * PIPE_XG + lane) * 16, o1 = two ? ((wave + 4) * PIPE_XG + lane) * 16 : o0;
+            xp0 = poll_ld(rn0, o0); xp1 = poll_ld(two ? rn1 : rn0, o1);
+            xp_valid = true;
         };
         auto pre_finish = [&](int s, int tn, bool tap1_is_cur) {
             float gb = 0.0f;
@@ -289,12 +316,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         uint4 v = __builtin_bit_cast(uint4, q ? pf1 : pf0);
                         if (k >= R && tap1_is_cur && tn - d >= 0) v = *reinterpret_cast<const uint4*>(xcur_b + (k - R));
                         *reinterpret_cast<uint4*>(vec + k) = v;
-                    }
+                    } else if (i < KP) *reinterpret_cast<uint4*>(vec + k) = cvt8_bf16<H>(__builtin_bit_cast(uint4, q ? pf1 : pf0));      // the conditioning chunks
                 }
             }
-            for (int i = KR + tid; i < KP; i += PIPE_THREADS)                // the conditioning chunks
-                *reinterpret_cast<uint4*>(vec + i * 8) = cvt8_bf16<H>(*reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (i * 8 - 2 * R)));
             lds_barrier();
+            x_request(s, tn - 1);
             {
                 const int per = (KP + 3) / 4, kc0 = wave * per, kc1 = min(KP, kc0 + per);
                 zpart[wave * 64 + lane] = mv_rows<H>(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
@@ -323,10 +349,18 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
             for (int cix = 0; cix < 4; ++cix) wor[cix] = *reinterpret_cast<const uint4*>(Wo + ((size_t)cix * R + tid) * 16);
         }
         const int NXG = R / 4;
+        // Runs of MORE THAN 10 streams are throughput-bound on the layer CUs' service time per stream (3.7 us, of which 1.0 us were two
+        // dependent L2 round trips: the x poll and the skip poll; profiles/r6i_pipe_svc_trace.txt), and what a CU polls for has normally been
+        // published long before: there the first-pass x granules of the NEXT stream and this stream's skip granule are REQUESTED one stage
+        // early and only tested where they used to be polled (a tag that is not there yet falls back to the polling loop).  Runs of up to 10
+        // streams are latency-bound: an early poll finds nothing and slows somebody's critical hop, so they keep one poll in flight.
 
         for (int t = 0; t < T; ++t) {
             const uint32_t want = (uint32_t)(t + 1);
             for (int s = 0; s < B; ++s) {
+                PIPE_SVC(0);
+                const bool xp_have = xp_valid;       // a request is good for exactly ONE iteration (the last sample makes none: pre_finish does not run)
+                xp_valid = false;
                 // ---- 1. x_l(t) = sum of the partial vectors published by the previous stage (granule g = channels 4g..4g+3)
                 {
                     const __amdgpu_buffer_rsrc_t rs0 = poll_rsrc((loc0 ? a.XML : a.XM) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
@@ -337,9 +371,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         if (p0 < nprod) {
                             const bool two = p1 < nprod;
                             const int o0 = (p0 * PIPE_XG + g) * 16, o1 = two ? (p1 * PIPE_XG + g) * 16 : o0;
-                            u32x4 g0, g1;
+                            u32x4 g0 = xp0, g1 = xp1;
+                            bool have = false;
+                            if (xp_have && g == lane) have = __all(g0.w == want && g1.w == want) != 0;      // requested during the previous stream's iteration
                             int spins = 0;
-                            for (;;) {          // ONE poll in flight: more concurrent polls measurably slow every hop (fabric contention)
+                            while (!have) {     // ONE poll in flight: more concurrent polls measurably slow every hop (fabric contention)
                                 g0 = poll_ld(rs0, o0); g1 = poll_ld(two ? rs1 : rs0, o1);
                                 if (__all(g0.w == want && g1.w == want)) break;
                                 if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 100 + l); break; }
@@ -352,7 +388,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         *reinterpret_cast<float4*>(psum + wave * R + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
+                PIPE_SVC(1);
                 lds_barrier();                                                                   // (A) the 4 waves' partial sums
+                PIPE_SVC(2);
                 if (a.trace && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l] = wall_clock64();
                 if (fast) {
                     // every wave rebuilds the full bf16 x_l(t) for itself (no second barrier): lane g -> channels 4g..4g+3
@@ -380,6 +418,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         ucur[8 * wave + pr] = f2n<H>((1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f)) * __builtin_amdgcn_rcpf(1.0f + __expf(-zs)));
                     }
                     lds_barrier();                                                                 // (B) the 32 gate outputs of this CU
+                    PIPE_SVC(3);
                     // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0]) -> granules (modules.py:512-521)
                     if (!top) {
                         float o = 0.0f, o2 = 0.0f;
@@ -432,22 +471,28 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         }
                     }
                 }
+                PIPE_SVC(4);
                 lds_barrier();
+                PIPE_SVC(5);
                 if (a.trace && (!fast || top) && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
                 if (t + 1 < T) pre_issue(s, t + 1, d == 1);          // wave 3: ring reads of this stream's NEXT sample, consumed in step 5
                 // ---- 4. skip chain: running sum of CU (l-1, j) + W_skip[:, mine] u_mine  -> CU (l+1, j) / head (wavenet.py:833-836)
                 {
                     // own contribution first (the running sum of CU (l-1, j) is published ~1 us after its x partial: no point in
-                    // polling early, and every useless poll slows somebody's critical hop)
+                    // polling early, and every useless poll slows somebody's critical hop -- except in runs of many streams, see `many`)
+                    u32x4 skpre = {0, 0, 0, 0};
+                    const __amdgpu_buffer_rsrc_t rsk = poll_rsrc((loc_skip ? a.SML : a.SM) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
+                    if (many && l > 0 && tid * 3 < S) skpre = poll_ld(rsk, tid * 16);
                     for (int r = tid; r < S; r += PIPE_THREADS) skp[r] = mv_rows<H>(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
                     if (tid < 4) skp[S + tid] = 0.0f;
                     lds_barrier();
+                    PIPE_SVC(6);
                     if (l > 0) {       // one poll per GRANULE (3 channels), by the first (S+2)/3 threads
-                        const __amdgpu_buffer_rsrc_t rs = poll_rsrc((loc_skip ? a.SML : a.SM) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
+                        const __amdgpu_buffer_rsrc_t rs = rsk;
                         for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
-                            u32x4 g;
+                            u32x4 g = skpre;
                             int spins = 0;
-                            for (;;) {
+                            while (!(many && g3 == tid && g.w == want)) {
                                 g = poll_ld(rs, g3 * 16);
                                 if (g.w == want) break;
                                 __builtin_amdgcn_s_sleep(2);
@@ -458,22 +503,26 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         }
                     }
                     lds_barrier();
+                    PIPE_SVC(7);
                     for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
                         u32x4 g = {__float_as_uint(skp[g3 * 3]), __float_as_uint(skp[g3 * 3 + 1]), __float_as_uint(skp[g3 * 3 + 2]), want};
                         const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_SG + g3;
                         st_g16_local(a.SML + gi, g); st_g16(a.SM + gi, g);
                     }
                 }
+                PIPE_SVC(8);
                 // ---- 5. queue update (private ring) and the pre-multiplication for this stream's next step
                 {
                     bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
                     for (int i = tid; i < R / 8; i += PIPE_THREADS)
                         *reinterpret_cast<uint4*>(ringb + (int64_t)(t & mask) * R + i * 8) = *reinterpret_cast<const uint4*>(xcur_b + i * 8);
+                    PIPE_SVC(9);
                     if constexpr (H) {      // half has 5 exponent bits: a residual stream beyond 65504 became inf in the hand-off -- report it, do not synthesise garbage
                         if (tid < R && !(fabsf(xcur_f[tid]) <= 65504.0f)) pipe_abort(abortf, 400 + l);
                     }
                     if (t + 1 < T) pre_finish(s, t + 1, d == 1);      // ring rows are read past this CU's L1 (sc1): slots are recycled
                 }
+                PIPE_SVC(10);
                 if (pipe_aborted(abortf)) return;
             }
         }
@@ -693,7 +742,7 @@ bool wn_pipe_eligible(const wn_ctx* c, int B) {
     const int R = c->R, S = c->S, C = c->C, GH = c->GH, L = c->L;
     if (GH % 32 || R % 8 || S % 8 || C % 8 || R > 512) return false;
     const int P = GH / 32;
-    if (P > 8 || L > 32 || B > 32 || R > 384 || S > 384 || c->OP > 256) return false;      // (B: 256 B of LDS per stream, checked below; beyond 10 streams a run costs + 3.6 us per stream and sample)
+    if (P > 8 || L > 32 || B > 32 || R > 384 || S > 384 || c->OP > 256 || (2 * R + C) / 8 > 128) return false;      // (B: 256 B of LDS per stream, checked below; beyond 10 streams a run costs + 3.6 us per stream and sample)
     const int spx = (L + 7) / 8;
     if (spx * P + 1 > 30) return false;                 // 32 CUs per XCD, keep slack
     const int64_t layer_static = 64LL * R * 2 + 64LL * (2 * R + C) * 2 + 32LL * R * 2 + 32LL * S * 2 + 256 + R * 4;
@@ -900,6 +949,12 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         WN_HIP(c, hipMemsetAsync(trace_dev, 0, (size_t)trace_n * 2 * (L + 2) * 8, st));
         a.trace = trace_dev; a.trace_t0 = 500; a.trace_n = trace_n;
     }
+    unsigned long long* svc_dev = nullptr;
+    if (getenv("WN_PIPE_SVC_TRACE") && T > 600) {
+        WN_HIP(c, hipMalloc((void**)&svc_dev, (size_t)trace_n * 16 * 8));
+        WN_HIP(c, hipMemsetAsync(svc_dev, 0, (size_t)trace_n * 16 * 8, st));
+        a.svc = svc_dev; a.svc_l = L / 2; a.svc_s = B / 2; a.trace_t0 = 500; a.trace_n = trace_n;
+    }
     const int lds_bytes = std::max(p->layer_lds + 256 * B, p->head_lds);      // z_past [B][64] fp32 per layer CU (wn_pipe_eligible checked that it fits)
     if (p->f16) {
         WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -916,6 +971,18 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     hipLaunchKernelGGL(wn_pipe_sticky_kernel, dim3(1), dim3(64), 0, st, p->abort_dev);
     WN_HIP(c, hipMemcpyAsync(p->abort_host, p->abort_dev + 1, 4, hipMemcpyDeviceToHost, st));
     p->pending = true; c->synth_path = 2;
+    if (svc_dev) {        // where a layer CU's service time per stream goes (diagnostic mode: synchronises)
+        WN_HIP(c, hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)trace_n * 16);
+        hipMemcpy(h.data(), svc_dev, h.size() * 8, hipMemcpyDeviceToHost); hipFree(svc_dev);
+        static const char* nm[10] = {"x poll", "barrier A", "x rebuild + z + gate + barrier B", "out matvec + publish x", "barrier", "skip own matvec + barrier", "skip poll + add + barrier",
+                                     "skip publish", "ring store", "pre-multiplication of the next sample"};
+        double d[10] = {0}; double tot = 0; int n = 0;
+        for (int i = 0; i < trace_n; ++i) { const unsigned long long* r = &h[(size_t)i * 16]; if (!r[0] || !r[10]) continue; ++n; for (int k = 0; k < 10; ++k) d[k] += (double)(r[k + 1] - r[k]); tot += (double)(r[10] - r[0]); }
+        fprintf(stderr, "[pipe svc] layer %d CU 0, stream %d of %d: %.2f us per stream iteration (mean of %d):", L / 2, B / 2, B, n ? tot / n / 100.0 : 0.0, n);
+        for (int k = 0; k < 10; ++k) fprintf(stderr, " | %s %.2f", nm[k], n ? d[k] / n / 100.0 : 0.0);
+        fprintf(stderr, "\n");
+    }
     if (trace_dev) {      // per-stage latencies in units of the 100 MHz real-time counter (10 ns)   [diagnostic mode: synchronises]
         WN_HIP(c, hipStreamSynchronize(st));
         std::vector<unsigned long long> h((size_t)trace_n * 2 * (L + 2));
