@@ -94,5 +94,7 @@ def sanitizer_runtime():
 
 
 if __name__ == '__main__':
-    print(build_sanitized() if '--sanitize' in sys.argv else build(force='--force' in sys.argv))
+    if '--pipe-svc' in sys.argv:      # diagnostic build: the synthesis pipeline with its service-time stamps compiled in (tools/pipe_svc_trace.py)
+        FLAGS.append('-DWN_PIPE_SVC_BUILD')
+    print(build_sanitized() if '--sanitize' in sys.argv else build(force='--force' in sys.argv or '--pipe-svc' in sys.argv))
     print('build mode: ' + ', '.join('%s %s' % kv for kv in sorted(LAST_BUILD.items())))

@@ -174,7 +174,11 @@ __global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __r
 }
 
 // ======================================================================================================================
+#ifdef WN_PIPE_SVC_BUILD      // diagnostic build only (csrc/build.py --pipe-svc): the eleven stamp sites cost SGPRs the kernel does not have
 #define PIPE_SVC(k) do { if (a.svc && l == a.svc_l && j == 0 && s == a.svc_s && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.svc[(size_t)(t - a.trace_t0) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define PIPE_SVC(k) do { } while (0)
+#endif
 template <int H>
 __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -268,41 +272,28 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         // skip chain, so their latency lies under the skip matvec and the wait for the previous layer's running sum instead of in front of
         // the matvec.  Wave 3 on purpose: vmcnt retires in order per WAVE, and waves 0 / 1 poll the skip granules in between (a poll
         // behind an older outstanding load would wait for it: the skip chain is the second latency-critical chain of the ring).
-        const bool many = B > 10;            // (see the sample loop)
         const int KR = 2 * R / 8;                                            // 16-B chunks of the two past taps (KP <= 128: two chunks per lane of wave 3, wn_pipe_eligible)
         u32x4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0};
         auto pre_issue = [&](int s, int tn, bool tap1_is_cur) {
             if (wave != 3) return;
-            const bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
+            // wave-uniform parts as scalars, per-lane parts as 32-bit byte offsets (a ring of one stream is <= 8192 rows x R x 2 B; the conditioning of a
+            // run is B x T x C x 2 B < 4 GB): a per-lane 64-bit multiply per candidate address cost this wave 0.35 us per stream
+            const char* ringb = (const char*)(a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R);
+            const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane(((tn - 2 * d) & mask) * R * 2), row1 = (uint32_t)__builtin_amdgcn_readfirstlane(((tn - d) & mask) * R * 2);
+            const char* cb = (const char*)a.cbt + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((s * T + tn) * C) * 2;
+            const bool ok0 = tn - 2 * d >= 0, ok1 = tn - d >= 0 && !tap1_is_cur;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int i = lane + 64 * q, k = i * 8;
                 u32x4& dst = q ? pf1 : pf0;
                 dst = (u32x4){0, 0, 0, 0};
-                // ONE load site (an address select, not two exec-masked branches writing the same destination registers): ring row of a past tap,
-                // or -- round 5 -- the conditioning chunk c(s, tn) of the same pre-multiplication: that read used to sit INSIDE pre_finish, a
-                // dependent global load on the layer CU's service path (0.26 us per stream, profiles/r6i_pipe_svc_trace.txt vs r6k)
-                const bool tap0 = k < R;
-                const int tau = tn - (tap0 ? 2 * d : d);
-                const bool is_tap = i < KR, is_cond = !is_tap && i < KP;
-                const bf16_t* src = is_tap ? ringb + (int64_t)(tau & mask) * R + (tap0 ? k : k - R) : a.cbt + ((int64_t)s * T + tn) * C + (k - 2 * R);
-                if ((is_tap && tau >= 0 && (tap0 || !tap1_is_cur)) || is_cond) ld_g16_nowait(dst, reinterpret_cast<const u32x4*>(src));
+                // ONE load site (an address select, not exec-masked branches writing the same destination registers): ring row of a past tap, or --
+                // round 5 -- the conditioning chunk c(s, tn) of the same pre-multiplication, which used to be read INSIDE pre_finish: a dependent
+                // global load on the layer CU's service path (profiles/r6i_pipe_svc_trace.txt)
+                const bool tap0 = k < R, is_tap = i < KR, is_cond = !is_tap && i < KP;
+                const char* src = is_tap ? ringb + (tap0 ? row0 + (uint32_t)k * 2 : row1 + (uint32_t)(k - R) * 2) : cb + (uint32_t)(k - 2 * R) * 2;
+                if ((is_tap && (tap0 ? ok0 : ok1)) || is_cond) ld_g16_nowait(dst, reinterpret_cast<const u32x4*>(src));
             }
-        };
-        u32x4 xp0 = {0, 0, 0, 0}, xp1 = {0, 0, 0, 0}; bool xp_valid = false;
-        // the next stream's x granules (first pass), requested inside pre_finish once wave 3 has consumed its ring prefetch (its hand-written
-        // vmcnt(0) would otherwise wait for this load too) and consumed at the top of the next iteration, ~0.6 us later: an L2 round trip
-        auto x_request = [&](int s, int t) {
-            xp_valid = false;
-            if (!(many && wave < nprod)) return;
-            const int sn = s + 1 < B ? s + 1 : 0;
-            if (!(s + 1 < B || t + 1 < T)) return;
-            const __amdgpu_buffer_rsrc_t rn0 = poll_rsrc((loc0 ? a.XML : a.XM) + ((int64_t)(l * B + sn) * P) * PIPE_XG, P * PIPE_XG * 16);
-            const __amdgpu_buffer_rsrc_t rn1 = poll_rsrc((loc1 ? a.XML : a.XM) + ((int64_t)(l * B + sn) * P) * PIPE_XG, P * PIPE_XG * 16);
-            const bool two = wave + 4 < nprod;
-            const int o0 = (wave * PIPE_XG + lane) * 16, o1 = two ? ((wave + 4) * PIPE_XG + lane) * 16 : o0;
-            xp0 = poll_ld(rn0, o0); xp1 = poll_ld(two ? rn1 : rn0, o1);
-            xp_valid = true;
         };
         auto pre_finish = [&](int s, int tn, bool tap1_is_cur) {
             float gb = 0.0f;
@@ -320,7 +311,6 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 }
             }
             lds_barrier();
-            x_request(s, tn - 1);
             {
                 const int per = (KP + 3) / 4, kc0 = wave * per, kc1 = min(KP, kc0 + per);
                 zpart[wave * 64 + lane] = mv_rows<H>(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
@@ -349,18 +339,14 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
             for (int cix = 0; cix < 4; ++cix) wor[cix] = *reinterpret_cast<const uint4*>(Wo + ((size_t)cix * R + tid) * 16);
         }
         const int NXG = R / 4;
-        // Runs of MORE THAN 10 streams are throughput-bound on the layer CUs' service time per stream (3.7 us, of which 1.0 us were two
-        // dependent L2 round trips: the x poll and the skip poll; profiles/r6i_pipe_svc_trace.txt), and what a CU polls for has normally been
-        // published long before: there the first-pass x granules of the NEXT stream and this stream's skip granule are REQUESTED one stage
-        // early and only tested where they used to be polled (a tag that is not there yet falls back to the polling loop).  Runs of up to 10
-        // streams are latency-bound: an early poll finds nothing and slows somebody's critical hop, so they keep one poll in flight.
-
+        // (Round 5, measured and removed: in runs of more than 10 streams, requesting the next stream's x granules and this stream's skip granule one
+        // stage early -- the polls then only test a value that is already in registers -- changes nothing: 72.0 vs 71.7 us per sample at 20 streams,
+        // profiles/r6n_pipe_batch_scaling*.txt.  The layer CUs and the head wait for EACH OTHER there, not for L2: every one of them serves a stream
+        // in 3.6 - 3.9 us, profiles/r6k_pipe_svc_trace.txt.)
         for (int t = 0; t < T; ++t) {
             const uint32_t want = (uint32_t)(t + 1);
             for (int s = 0; s < B; ++s) {
                 PIPE_SVC(0);
-                const bool xp_have = xp_valid;       // a request is good for exactly ONE iteration (the last sample makes none: pre_finish does not run)
-                xp_valid = false;
                 // ---- 1. x_l(t) = sum of the partial vectors published by the previous stage (granule g = channels 4g..4g+3)
                 {
                     const __amdgpu_buffer_rsrc_t rs0 = poll_rsrc((loc0 ? a.XML : a.XM) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
@@ -371,11 +357,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         if (p0 < nprod) {
                             const bool two = p1 < nprod;
                             const int o0 = (p0 * PIPE_XG + g) * 16, o1 = two ? (p1 * PIPE_XG + g) * 16 : o0;
-                            u32x4 g0 = xp0, g1 = xp1;
-                            bool have = false;
-                            if (xp_have && g == lane) have = __all(g0.w == want && g1.w == want) != 0;      // requested during the previous stream's iteration
+                            u32x4 g0, g1;
                             int spins = 0;
-                            while (!have) {     // ONE poll in flight: more concurrent polls measurably slow every hop (fabric contention)
+                            for (;;) {          // ONE poll in flight: more concurrent polls measurably slow every hop (fabric contention)
                                 g0 = poll_ld(rs0, o0); g1 = poll_ld(two ? rs1 : rs0, o1);
                                 if (__all(g0.w == want && g1.w == want)) break;
                                 if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 100 + l); break; }
@@ -479,20 +463,17 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 // ---- 4. skip chain: running sum of CU (l-1, j) + W_skip[:, mine] u_mine  -> CU (l+1, j) / head (wavenet.py:833-836)
                 {
                     // own contribution first (the running sum of CU (l-1, j) is published ~1 us after its x partial: no point in
-                    // polling early, and every useless poll slows somebody's critical hop -- except in runs of many streams, see `many`)
-                    u32x4 skpre = {0, 0, 0, 0};
-                    const __amdgpu_buffer_rsrc_t rsk = poll_rsrc((loc_skip ? a.SML : a.SM) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
-                    if (many && l > 0 && tid * 3 < S) skpre = poll_ld(rsk, tid * 16);
+                    // polling early, and every useless poll slows somebody's critical hop)
                     for (int r = tid; r < S; r += PIPE_THREADS) skp[r] = mv_rows<H>(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
                     if (tid < 4) skp[S + tid] = 0.0f;
                     lds_barrier();
                     PIPE_SVC(6);
                     if (l > 0) {       // one poll per GRANULE (3 channels), by the first (S+2)/3 threads
-                        const __amdgpu_buffer_rsrc_t rs = rsk;
+                        const __amdgpu_buffer_rsrc_t rs = poll_rsrc((loc_skip ? a.SML : a.SM) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
                         for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
-                            u32x4 g = skpre;
+                            u32x4 g;
                             int spins = 0;
-                            while (!(many && g3 == tid && g.w == want)) {
+                            for (;;) {
                                 g = poll_ld(rs, g3 * 16);
                                 if (g.w == want) break;
                                 __builtin_amdgcn_s_sleep(2);
@@ -956,12 +937,10 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         a.svc = svc_dev; a.svc_l = L / 2; a.svc_s = B / 2; a.trace_t0 = 500; a.trace_n = trace_n;
     }
     const int lds_bytes = std::max(p->layer_lds + 256 * B, p->head_lds);      // z_past [B][64] fp32 per layer CU (wn_pipe_eligible checked that it fits)
-    if (p->f16) {
-        WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        hipLaunchKernelGGL(wn_synth_pipe_kernel<1>, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
-    } else {
-        WN_HIP(c, hipFuncSetAttribute((const void*)wn_synth_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        hipLaunchKernelGGL(wn_synth_pipe_kernel<0>, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
+    {
+        void (*kern)(const PipeArgs) = p->f16 ? wn_synth_pipe_kernel<1> : wn_synth_pipe_kernel<0>;
+        WN_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL(kern, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     }
     WN_LAUNCH_CHECK(c);
     // the abort flag travels to pinned host memory behind the kernel; nobody waits for it here (wn_pipe_check / the next call read it)

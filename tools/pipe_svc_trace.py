@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Where a layer CU's service time per stream goes (WN_PIPE_SVC_TRACE=1; stderr) at a few batch sizes, C2 model.   python tools/pipe_svc_trace.py [B ...]"""
+"""Where a layer CU's service time per stream goes (WN_PIPE_SVC_TRACE=1; stderr) at a few batch sizes, C2 model.  Needs the diagnostic build of the
+library (the stamp sites are compiled out of the product: they cost SGPRs):
+    python tacotron-2_amd/csrc/build.py --pipe-svc && python tools/pipe_svc_trace.py [B ...] ; python tacotron-2_amd/csrc/build.py --force"""
 import os
 import sys
 import time
