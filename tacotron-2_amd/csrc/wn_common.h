@@ -143,7 +143,7 @@ struct wn_ctx {
     bf16_t* XD;                           // [L][NT][R] dropout-applied layer inputs (aliases X when dropout == 0)
     bf16_t *cbt, *X, *TS, *U, *R1, *H2, *DY, *DPRE1, *DSKIP, *DZ, *GX0, *GX1;
     float *YHAT, *DC, *CUP[WN_MAX_UPSAMPLE + 1], *DCUP[2];
-#define WN_CS_MAXBLK 512                  // row blocks of wn_colsum2 (wn_misc.hip); sizes cs_part (wn_api.hip)
+#define WN_CS_MAXBLK 512                  // row blocks of wn_colsum2 (wn_frontend.hip); sizes cs_part (wn_api.hip)
 #define WN_CS_SLOTS 2
     float* cs_part = nullptr;             // partial sums of wn_colsum2: WN_CS_SLOTS regions of WN_CS_MAXBLK x 2 x 1024 floats
     float* UPPART = nullptr; int64_t uppart_floats = 0;   // partial sums of the upsample-kernel gradients (two-stage, no atomics)

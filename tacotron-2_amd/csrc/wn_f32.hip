@@ -520,7 +520,7 @@ static int wgrad32(wn_ctx* c, const float* A, int lda, int shift, int K, const f
 
 // Backward of the last fp32 forward into the flat gradient buffer (effective-parameter layout): heads, then every layer top to bottom
 // with its weight gradients computed on the spot, d c_up accumulated over the layers, input conv, upsample net (the fp32 kernels of
-// wn_misc.hip).  Replaces optimizer.compute_gradients (wavenet.py:557) in the reference's own arithmetic.
+// wn_frontend.hip).  Replaces optimizer.compute_gradients (wavenet.py:557) in the reference's own arithmetic.
 int wn_f32_backward(wn_ctx* c, float* grads, hipStream_t st) {
     F32State* s = (F32State*)c->f32;
     if (!s || !s->DY) WN_FAIL(c, WN_E_STATE, "fp32 backward without an fp32 forward that computed the loss");

@@ -116,7 +116,7 @@ def synth_batch(cfg, B, T, seed=0):
     return wav, c
 
 
-# ---- device noise stream mirror (csrc/wn_misc.hip: wn_philox4x32_10 / wn_u01 / wn_noise_kernel) -----------------------------
+# ---- device noise stream mirror (csrc/wn_loss.hip: wn_philox4x32_10 / wn_u01 / wn_noise_kernel) -----------------------------
 def philox4x32_10(counter, key):
     """counter: uint64 array (group indices), key: 64-bit seed -> uint32 [n, 4] (Philox4x32-10, counter words (lo, hi, 0, 0))."""
     c = [(counter & 0xffffffff).astype(np.uint64), (counter >> 32).astype(np.uint64), np.zeros_like(counter, dtype=np.uint64), np.zeros_like(counter, dtype=np.uint64)]

@@ -1,3 +1,6 @@
+// NOTE (round 5): this harness compiles tools/wn_tile_variants.h -- a FORK of the library's tile engine that keeps the schedules measured and
+// rejected in rounds 2 - 4; its "production" arm is that fork's copy of the main loop.  The production kernels THEMSELVES (csrc/wn_tile.h,
+// included unchanged) are timed by tools/gemm8p_harness.hip, next to the 8-phase kernel and the vendor GEMM (tools/vendor_gemm_yardstick.py).
 // Stand-alone check + timing of the tile-engine main loops (run on the GPU box):
 //   v1 = wn_gemm_tile_kernel (A fragments straight from L2), v2 = wn_gemm_lds_kernel (LDS-DMA ring).
 // Same GemmArgs, same accumulation order => outputs must be BITWISE identical.
