@@ -37,12 +37,17 @@ __device__ __forceinline__ float acc_at(const float* red, int wave_stride, int n
     return s;
 }
 
+// Launch-per-layer kernels are LATENCY-bound (a few blocks per launch, one dependent chain of L2 reads per wave): round 5 splits K over NW waves
+// (4 or 8 by the K of the launch) and issues EVERY fragment load of a wave up front (<= WN_SYN_MAXK k-steps per pass, unrolled and predicated:
+// one L2 round trip per pass instead of one per k-step).  C5 width (G = 1024, K = 1616): 834 -> see profiles/ (DESIGN 3.4).
+#define WN_SYN_MAXK 8
 // ---- stage A: z = [W_dil | W_cin] [x(t-2d); x(t-d); x(t); c_t] + b  -> tanh * sigmoid -> u    (modules.py:273-303, 494-510)
-__global__ __launch_bounds__(256) void wn_synth_gate(const bf16_t* __restrict__ Apk, int ksteps, const bf16_t* __restrict__ ring, int mask,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wn_synth_gate(const bf16_t* __restrict__ Apk, int ksteps, const bf16_t* __restrict__ ring, int mask,
                                                      int d, int R, const bf16_t* __restrict__ cbt, int C, int T, int B,
                                                      const float* __restrict__ bias, int bias_bstride, int GH, bf16_t* __restrict__ ucur,
                                                      const int32_t* __restrict__ t_dev, int kil) {
-    __shared__ float red[4 * 2 * 64 * 16];
+    __shared__ float red[NW * 2 * 64 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = *t_dev;
     const int n = lane & 31, h = lane >> 5;
@@ -50,38 +55,47 @@ __global__ __launch_bounds__(256) void wn_synth_gate(const bf16_t* __restrict__ 
     f32x16_t acc0 = zero16(), acc1 = zero16();
     const bf16_t* A0 = Apk + ((size_t)(2 * blk) * ksteps * 64 + lane) * 8;
     const bf16_t* A1 = Apk + ((size_t)(2 * blk + 1) * ksteps * 64 + lane) * 8;
-    for (int ks = wave; ks < ksteps; ks += 4) {
-        const int k0 = ks * 16 + h * 8;
-        uint4 bv = make_uint4(0, 0, 0, 0);
-        if (n < B) {
-            if (k0 < 3 * R) {
-                // K order of the pack: [tap0 | tap1 | tap2] or, interleaved in blocks of `kil` channels, [tap0 b0 | tap1 b0 | tap2 b0 | tap0 b1 | ...]
-                int j, r;
-                if (kil > 0) { const int blk = k0 / kil; j = blk % 3; r = (blk / 3) * kil + (k0 - blk * kil); }
-                else { j = k0 / R; r = k0 - j * R; }
-                const int tau = t - (2 - j) * d;
-                if (tau >= 0) bv = *reinterpret_cast<const uint4*>(ring + ((size_t)(tau & mask) * 32 + n) * R + r);
-            } else {
-                bv = *reinterpret_cast<const uint4*>(cbt + ((size_t)n * T + t) * C + (k0 - 3 * R));
+    for (int ks0 = wave; ks0 < ksteps; ks0 += NW * WN_SYN_MAXK) {
+        uint4 bv[WN_SYN_MAXK], a0[WN_SYN_MAXK], a1[WN_SYN_MAXK];
+#pragma unroll
+        for (int i = 0; i < WN_SYN_MAXK; ++i) {
+            const int ks = ks0 + i * NW;
+            bv[i] = make_uint4(0, 0, 0, 0); a0[i] = make_uint4(0, 0, 0, 0); a1[i] = make_uint4(0, 0, 0, 0);
+            if (ks < ksteps) {
+                const int k0 = ks * 16 + h * 8;
+                if (n < B) {
+                    if (k0 < 3 * R) {
+                        // K order of the pack: [tap0 | tap1 | tap2] or, interleaved in blocks of `kil` channels, [tap0 b0 | tap1 b0 | tap2 b0 | tap0 b1 | ...]
+                        int j, r;
+                        if (kil > 0) { const int kb = k0 / kil; j = kb % 3; r = (kb / 3) * kil + (k0 - kb * kil); }
+                        else { j = k0 / R; r = k0 - j * R; }
+                        const int tau = t - (2 - j) * d;
+                        if (tau >= 0) bv[i] = *reinterpret_cast<const uint4*>(ring + ((size_t)(tau & mask) * 32 + n) * R + r);
+                    } else {
+                        bv[i] = *reinterpret_cast<const uint4*>(cbt + ((size_t)n * T + t) * C + (k0 - 3 * R));
+                    }
+                }
+                a0[i] = *reinterpret_cast<const uint4*>(A0 + (size_t)ks * 512);
+                a1[i] = *reinterpret_cast<const uint4*>(A1 + (size_t)ks * 512);
             }
         }
-        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, bv);
-        const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(A0 + (size_t)ks * 512));
-        const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(A1 + (size_t)ks * 512));
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WN_SYN_MAXK; ++i) {      // (k-steps past the end multiply zeros)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0[i]), __builtin_bit_cast(bf16x8_t, bv[i]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[i]), __builtin_bit_cast(bf16x8_t, bv[i]), acc1, 0, 0, 0);
+        }
     }
     float* my = red + (size_t)wave * (2 * 64 * 16);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { my[(0 * 64 + lane) * 16 + r] = acc0[r]; my[(1 * 64 + lane) * 16 + r] = acc1[r]; }
     __syncthreads();
-    for (int o = tid; o < 32 * 32; o += 256) {
+    for (int o = tid; o < 32 * 32; o += NW * 64) {
         const int nn = o & 31, ch = o >> 5;
         if (nn >= B) continue;
         const int g = blk * 32 + ch;
         const float* const gb = bias + (size_t)nn * bias_bstride;          // per-stream bias under global conditioning (wavenet.py:766-777)
-        const float za = acc_at(red, 2 * 64 * 16, 4, 0, ch, nn) + gb[g];
-        const float zb = acc_at(red, 2 * 64 * 16, 4, 1, ch, nn) + gb[GH + g];
+        const float za = acc_at(red, 2 * 64 * 16, NW, 0, ch, nn) + gb[g];
+        const float zb = acc_at(red, 2 * 64 * 16, NW, 1, ch, nn) + gb[GH + g];
         const float e = __expf(2.0f * za);
         const float u = (1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zb)));
         ucur[(size_t)nn * GH + g] = f2bf(u);
@@ -89,14 +103,15 @@ __global__ __launch_bounds__(256) void wn_synth_gate(const bf16_t* __restrict__ 
 }
 
 // ---- stage B: x_next = (W_out u + b + x) * rho -> next layer's ring;  skip_acc += c_l W_skip u   (modules.py:512-521, wavenet.py:833-836)
-__global__ __launch_bounds__(256) void wn_synth_out(const bf16_t* __restrict__ Wo, const bf16_t* __restrict__ Ws, int ksteps,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wn_synth_out(const bf16_t* __restrict__ Wo, const bf16_t* __restrict__ Ws, int ksteps,
                                                     int R, int S, const bf16_t* __restrict__ ucur, int GH,
                                                     const float* __restrict__ out_bias, float rho,
                                                     const bf16_t* __restrict__ ring_cur, int mask_cur,
                                                     bf16_t* __restrict__ ring_next, int mask_next,
                                                     float* __restrict__ skip_acc, int first_layer, int B,
                                                     const int32_t* __restrict__ t_dev) {
-    __shared__ float red[4 * 64 * 16];
+    __shared__ float red[NW * 64 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = *t_dev;
     const int n = lane & 31, h = lane >> 5;
@@ -106,20 +121,29 @@ __global__ __launch_bounds__(256) void wn_synth_out(const bf16_t* __restrict__ W
     if (!is_skip && ring_next == nullptr) return;        // top layer: residual output unused
     const bf16_t* A = (is_skip ? Ws + ((size_t)(mt - nR) * ksteps * 64 + lane) * 8 : Wo + ((size_t)mt * ksteps * 64 + lane) * 8);
     f32x16_t acc = zero16();
-    for (int ks = wave; ks < ksteps; ks += 4) {
-        uint4 bv = make_uint4(0, 0, 0, 0);
-        if (n < B) bv = *reinterpret_cast<const uint4*>(ucur + (size_t)n * GH + ks * 16 + h * 8);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(A + (size_t)ks * 512)),
-                                                      __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+    for (int ks0 = wave; ks0 < ksteps; ks0 += NW * WN_SYN_MAXK) {
+        uint4 bv[WN_SYN_MAXK], av[WN_SYN_MAXK];
+#pragma unroll
+        for (int i = 0; i < WN_SYN_MAXK; ++i) {
+            const int ks = ks0 + i * NW;
+            bv[i] = make_uint4(0, 0, 0, 0); av[i] = make_uint4(0, 0, 0, 0);
+            if (ks < ksteps) {
+                if (n < B) bv[i] = *reinterpret_cast<const uint4*>(ucur + (size_t)n * GH + ks * 16 + h * 8);
+                av[i] = *reinterpret_cast<const uint4*>(A + (size_t)ks * 512);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WN_SYN_MAXK; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av[i]), __builtin_bit_cast(bf16x8_t, bv[i]), acc, 0, 0, 0);
     }
     float* my = red + (size_t)wave * (64 * 16);
 #pragma unroll
     for (int r = 0; r < 16; ++r) my[lane * 16 + r] = acc[r];
     __syncthreads();
-    for (int o = tid; o < 32 * 32; o += 256) {
+    for (int o = tid; o < 32 * 32; o += NW * 64) {
         const int nn = o & 31, ch = o >> 5;
         if (nn >= B) continue;
-        const float v = acc_at(red, 64 * 16, 4, 0, ch, nn);
+        const float v = acc_at(red, 64 * 16, NW, 0, ch, nn);
         if (is_skip) {
             const int s = (mt - nR) * 32 + ch;
             float* p = skip_acc + (size_t)nn * S + s;
@@ -264,12 +288,19 @@ void wn_synth_free(wn_ctx* c) {
 static int enqueue_step(wn_ctx* c, Synth* s, const float* noise, const void* test_inputs, void* out_samples, float* out_raw, hipStream_t st) {
     const int L = c->L, R = c->R, GH = c->GH, S = c->S, C = c->C, B = s->B, T = s->T;
     for (int l = 0; l < L; ++l) {
-        hipLaunchKernelGGL(wn_synth_gate, dim3(GH / 32), dim3(256), 0, st, c->packs[l].w1.dev, c->packs[l].w1.K >> 4, s->ring[l], s->mask[l],
-                           c->dil[l], R, c->cbt, C, T, B, c->gin > 0 ? c->gbias + (size_t)l * B * c->G : c->b1sum + (size_t)l * c->G, c->gin > 0 ? c->G : 0, GH, s->ucur, s->t_dev, c->packs[l].w1.kil);
+        // waves per block by the K of the launch: every wave should get its k-steps in ONE pass of <= WN_SYN_MAXK loads
+        const int ksg = c->packs[l].w1.K >> 4, kso = GH >> 4;
+        const float* gbias_l = c->gin > 0 ? c->gbias + (size_t)l * B * c->G : c->b1sum + (size_t)l * c->G;
+#define WN_LAUNCH_GATE(NW_) hipLaunchKernelGGL(wn_synth_gate<NW_>, dim3(GH / 32), dim3(NW_ * 64), 0, st, c->packs[l].w1.dev, ksg, s->ring[l], s->mask[l], \
+                           c->dil[l], R, c->cbt, C, T, B, gbias_l, c->gin > 0 ? c->G : 0, GH, s->ucur, s->t_dev, c->packs[l].w1.kil)
+        if (ksg > 4 * WN_SYN_MAXK) WN_LAUNCH_GATE(8); else WN_LAUNCH_GATE(4);      // (16 waves = 1024 threads cap the kernel at 128 VGPRs: the up-front loads spill)
+#undef WN_LAUNCH_GATE
         const bool top = (l == L - 1);
-        hipLaunchKernelGGL(wn_synth_out, dim3(R / 32 + S / 32), dim3(256), 0, st, c->packs[l].wo.dev, c->packs[l].ws.dev, GH >> 4, R, S, s->ucur, GH,
-                           c->params_dev + c->lay[l].out_b, c->res_scale, s->ring[l], s->mask[l], top ? nullptr : s->ring[l + 1], top ? 0 : s->mask[l + 1],
-                           s->skip_acc, l == 0 ? 1 : 0, B, s->t_dev);
+#define WN_LAUNCH_OUT(NW_) hipLaunchKernelGGL(wn_synth_out<NW_>, dim3(R / 32 + S / 32), dim3(NW_ * 64), 0, st, c->packs[l].wo.dev, c->packs[l].ws.dev, kso, R, S, s->ucur, GH, \
+                           c->params_dev + c->lay[l].out_b, c->res_scale, s->ring[l], s->mask[l], top ? nullptr : s->ring[l + 1], top ? 0 : s->mask[l + 1], \
+                           s->skip_acc, l == 0 ? 1 : 0, B, s->t_dev)
+        if (kso > 4 * WN_SYN_MAXK) WN_LAUNCH_OUT(8); else WN_LAUNCH_OUT(4);
+#undef WN_LAUNCH_OUT
     }
     hipLaunchKernelGGL(wn_synth_head1, dim3(S / 32), dim3(256), 0, st, c->wh1.dev, S >> 4, S, s->skip_acc, c->skip_bias_total, c->params_dev + c->fin1_b, s->h2, B);
     hipLaunchKernelGGL(wn_synth_head2, dim3(c->OP / 32), dim3(256), 0, st, c->wh2.dev, S >> 4, S, s->h2, c->params_dev + c->fin2_b, s->yraw, c->O, c->OP, B);
