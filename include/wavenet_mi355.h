@@ -217,6 +217,9 @@ int wn_synth_pipe_eligible(const wn_ctx* ctx, int32_t B);
  * reported by wn_synth_check / the next wn_synthesize as WN_E_HIP ("left the half-precision range"): switch to bf16 and run again.
  * Environment at wn_create: WN_PIPE_DTYPE=fp16|bf16. */
 int wn_synth_pipe_dtype(wn_ctx* ctx, int32_t half);
+/* how many pipeline INSTANCES the last wn_synthesize ran side by side (1 for a run of <= 10 streams or a model whose CUs fit the chip once:
+ * the paper model takes 193 of 256; hparams.py's default model 81: up to three instances of <= 10 streams each). */
+int wn_synth_last_instances(const wn_ctx* ctx);
 
 /* Stand-alone samplers on [B,O,T] parameters (train-time log path, wavenet.py:302-325). */
 int wn_sample(wn_ctx* ctx, const float* y_hat, int32_t B, int32_t T, const float* noise /*[T,B,nps]*/,

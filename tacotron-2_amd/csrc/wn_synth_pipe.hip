@@ -43,7 +43,11 @@ struct PipeArgs {
     u32x4* XM; u32x4* SM;            // mailboxes written with write-through (sc1) stores: visible to every XCD
     u32x4* XML; u32x4* SML;          // the same mailboxes written with plain stores: they live in the WRITER's XCD L2, readable (sc1 loads) by CUs of that XCD only
     int32_t* xcc_tab;                // [grid] XCC id + 1 of every workgroup (0 = not started)
-    bf16_t* ring; const bf16_t* cbt;
+    const int32_t* role_tab;         // [grid] role of every workgroup: layer << 8 | j, bit 23: head, -1: none (host-built: which XCD hosts which layers)
+    const int32_t* block_tab;        // [L * P + 1] inverse: workgroup id of CU (layer, j); [L * P]: the head
+    int32_t ninst, iB[4], is0[4];    // pipeline instances side by side in ONE launch (round 5): instance i serves the streams [is0[i], is0[i] + iB[i]) of the
+                                     // batch of B on its own CUs (role table: bits 24-25), mailboxes and ring queues (offsets linear in is0); ninst = 1: iB[0] = B
+    bf16_t* ring; int64_t ring_unit; const bf16_t* cbt;      // ring_unit: ring elements of ONE stream over all layers and CUs (instance offset = ring_unit * is0)
     const float* noise; const void* test_inputs; void* out_samples; float* out_raw;
     const float* win_global; const float* bin_global;
     int32_t* abort_flag;
@@ -175,31 +179,42 @@ __global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __r
 
 // ======================================================================================================================
 #ifdef WN_PIPE_SVC_BUILD      // diagnostic build only (csrc/build.py --pipe-svc): the eleven stamp sites cost SGPRs the kernel does not have
-#define PIPE_SVC(k) do { if (a.svc && l == a.svc_l && j == 0 && s == a.svc_s && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.svc[(size_t)(t - a.trace_t0) * 16 + (k)] = wall_clock64(); } while (0)
+#define PIPE_SVC(k) do { if (a.svc && inst == 0 && l == a.svc_l && j == 0 && s == a.svc_s && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.svc[(size_t)(t - a.trace_t0) * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define PIPE_SVC(k) do { } while (0)
 #endif
-template <int H>
+template <int H, int MULTI>
 __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int R = a.R, S = a.S, P = a.P, B = a.B, T = a.T, C = a.C;
-    // ---- role: spx consecutive layers per XCD (block b runs on XCD b % 8), the head on XCD 0
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int layer_slots = a.spx * P;
-    int layer = -1, j = 0; bool is_head = false;
-    if (slot < layer_slots) { layer = a.spx * xcd + slot / P; j = slot % P; if (layer >= a.L) return; }
-    else if (slot == layer_slots && xcd == 0) is_head = true;
-    else return;
+    const int R = a.R, S = a.S, P = a.P, T = a.T, C = a.C;
+    // ---- role (host-built table: consecutive layers share an XCD -- block b runs on XCD b % 8 --; one instance: spx layers per XCD, the head on XCD 0)
+    const int32_t role = a.role_tab[blockIdx.x];
+    if (role < 0) return;
+    const bool is_head = (role >> 23) & 1;
+    const int layer = (role >> 8) & 0xff, j = role & 0xff;
+    // ---- instance (MULTI: several independent pipelines in this launch; else compile-time instance 0 = the whole batch, nothing rebased)
+    const int inst = MULTI ? (role >> 24) & 3 : 0;
+    const int B = MULTI ? a.iB[inst] : a.B, s0 = MULTI ? a.is0[inst] : 0, Bn = a.B;
+    const int64_t moff = MULTI ? (int64_t)(a.L + 1) * s0 * P : 0;                       // mailbox granule sets in front of this instance's
+    u32x4* const XM_ = a.XM + moff * PIPE_XG; u32x4* const XML_ = a.XML + moff * PIPE_XG;
+    u32x4* const SM_ = a.SM + moff * PIPE_SG; u32x4* const SML_ = a.SML + moff * PIPE_SG;
+    bf16_t* const ring_ = a.ring + (MULTI ? a.ring_unit * s0 : 0);                       // a.ring_off[l] is per STREAM: x B for this instance's layer offset
+    const bf16_t* const cbt_ = a.cbt + (MULTI ? (int64_t)s0 * T * C : 0);
+    const char* const ti_ = a.test_inputs ? (const char*)a.test_inputs + (MULTI ? (int64_t)s0 * T * 4 : 0) : nullptr;
+    char* const outs_ = (char*)a.out_samples + (MULTI ? (int64_t)s0 * T * 4 : 0);
+    float* const outr_ = a.out_raw ? a.out_raw + (MULTI ? (int64_t)s0 * a.O * T : 0) : nullptr;
+    const int32_t* const btab = a.block_tab + (MULTI ? inst * (a.L * P + 1) : 0);
+    const bool trace_on = a.trace && inst == 0;
     int32_t* const abortf = a.abort_flag;
     // ---- which XCD am I really on?  (block -> XCD = b % 8 is observed, not guaranteed: the table makes the fast path a pure
     // speed choice -- a hand-off whose two ends share an XCD uses the plain-store copy of the mailbox, served by that XCD's L2
     // in about half the round trip of the write-through copy)
     int my_xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc)); my_xcc &= 0xf;
     if (threadIdx.x == 0) __hip_atomic_store(a.xcc_tab + blockIdx.x, my_xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    auto block_of = [&](int lay, int jj) { return (((lay % a.spx) * P + jj) << 3) | (lay / a.spx); };     // inverse of the role map
-    const int head_block = (a.spx * P) << 3;
+    auto block_of = [&](int lay, int jj) { return btab[lay * P + jj]; };     // inverse of the role map
+    const int head_block = btab[a.L * P];
     auto same_xcc = [&](int block) {
         int v = 0, spins = 0;
         while ((v = __hip_atomic_load(a.xcc_tab + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
@@ -241,11 +256,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
 
         // z_past for (s, tn): taps x(tn-2d), x(tn-d) from this CU's ring (zero before the utterance), conditioning c(s, tn)
         auto precompute = [&](int s, int tn, bool tap1_is_cur) {
-            bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
+            bf16_t* ringb = ring_ + a.ring_off[l] * B + ((int64_t)(j * B + s) * (mask + 1)) * R;
             // global conditioning (wavenet.py:766-777, modules.py:503-508): g is constant over time, so W_g^T g + b_g is a per-STREAM gate
             // bias; it replaces the layer's own bias vector here, off the critical path (the load flies under the matvec below)
             float gb = 0.0f;
-            if (a.gbias && tid < 64) gb = a.gbias[((int64_t)l * B + s) * a.G + (tid < 32 ? 32 * j + tid : a.GH + 32 * j + (tid - 32))];
+            if (a.gbias && tid < 64) gb = a.gbias[((int64_t)l * Bn + s0 + s) * a.G + (tid < 32 ? 32 * j + tid : a.GH + 32 * j + (tid - 32))];
             for (int i = tid; i < KP; i += PIPE_THREADS) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 const int k = i * 8;
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     const int tau = tn - d;
                     if (tau >= 0) v = tap1_is_cur ? *reinterpret_cast<const uint4*>(xcur_b + (k - R))
                                                   : __builtin_bit_cast(uint4, ld_g16(reinterpret_cast<const u32x4*>(ringb + (int64_t)(tau & mask) * R + (k - R))));
-                } else v = cvt8_bf16<H>(*reinterpret_cast<const uint4*>(a.cbt + ((int64_t)s * T + tn) * C + (k - 2 * R)));
+                } else v = cvt8_bf16<H>(*reinterpret_cast<const uint4*>(cbt_ + ((int64_t)s * T + tn) * C + (k - 2 * R)));
                 *reinterpret_cast<uint4*>(vec + k) = v;
             }
             lds_barrier();
@@ -278,9 +293,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
             if (wave != 3) return;
             // wave-uniform parts as scalars, per-lane parts as 32-bit byte offsets (a ring of one stream is <= 8192 rows x R x 2 B; the conditioning of a
             // run is B x T x C x 2 B < 4 GB): a per-lane 64-bit multiply per candidate address cost this wave 0.35 us per stream
-            const char* ringb = (const char*)(a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R);
+            const char* ringb = (const char*)(ring_ + a.ring_off[l] * B + ((int64_t)(j * B + s) * (mask + 1)) * R);
             const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane(((tn - 2 * d) & mask) * R * 2), row1 = (uint32_t)__builtin_amdgcn_readfirstlane(((tn - d) & mask) * R * 2);
-            const char* cb = (const char*)a.cbt + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((s * T + tn) * C) * 2;
+            const char* cb = (const char*)cbt_ + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((s * T + tn) * C) * 2;
             const bool ok0 = tn - 2 * d >= 0, ok1 = tn - d >= 0 && !tap1_is_cur;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         };
         auto pre_finish = [&](int s, int tn, bool tap1_is_cur) {
             float gb = 0.0f;
-            if (a.gbias && tid < 64) gb = a.gbias[((int64_t)l * B + s) * a.G + (tid < 32 ? 32 * j + tid : a.GH + 32 * j + (tid - 32))];
+            if (a.gbias && tid < 64) gb = a.gbias[((int64_t)l * Bn + s0 + s) * a.G + (tid < 32 ? 32 * j + tid : a.GH + 32 * j + (tid - 32))];
             if (wave == 3) {
                 pf_wait(pf0, pf1);
 #pragma unroll
@@ -349,8 +364,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 PIPE_SVC(0);
                 // ---- 1. x_l(t) = sum of the partial vectors published by the previous stage (granule g = channels 4g..4g+3)
                 {
-                    const __amdgpu_buffer_rsrc_t rs0 = poll_rsrc((loc0 ? a.XML : a.XM) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
-                    const __amdgpu_buffer_rsrc_t rs1 = poll_rsrc((loc1 ? a.XML : a.XM) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
+                    const __amdgpu_buffer_rsrc_t rs0 = poll_rsrc((loc0 ? XML_ : XM_) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
+                    const __amdgpu_buffer_rsrc_t rs1 = poll_rsrc((loc1 ? XML_ : XM_) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
                     for (int g = lane; g < NXG; g += 64) {
                         float v[4] = {0, 0, 0, 0};
                         const int p0 = wave, p1 = wave + 4;
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 PIPE_SVC(1);
                 lds_barrier();                                                                   // (A) the 4 waves' partial sums
                 PIPE_SVC(2);
-                if (a.trace && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l] = wall_clock64();
+                if (trace_on && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l] = wall_clock64();
                 if (fast) {
                     // every wave rebuilds the full bf16 x_l(t) for itself (no second barrier): lane g -> channels 4g..4g+3
                     bf16_t* myx = xwave + wave * R;
@@ -412,11 +427,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         if (j == 0) o += n2f<H>(myx[tid]) + ob[tid];
                         const uint32_t me = f2n<H>(o * a.rho);
                         const uint32_t n1 = dpp_u<DPP_QUAD_BCAST(1)>(me), n2 = dpp_u<DPP_QUAD_BCAST(2)>(me), n3 = dpp_u<DPP_QUAD_BCAST(3)>(me);
-                        if (a.trace && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
+                        if (trace_on && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
                         if ((lane & 3) == 0) {
                             u32x4 g = {me | (n1 << 16), n2 | (n3 << 16), 0, want};
                             const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + (tid >> 2);
-                            st_g16_local(a.XML + gi, g); st_g16(a.XM + gi, g);
+                            st_g16_local(XML_ + gi, g); st_g16(XM_ + gi, g);
                         }
                     }
                     if (tid < R) xcur_f[tid] = n2f<H>(myx[tid]);
@@ -451,14 +466,14 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                             const uint2 q = *reinterpret_cast<const uint2*>(outp + g * 4);
                             u32x4 gr = {q.x, q.y, 0, want};
                             const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + g;
-                            st_g16_local(a.XML + gi, gr); st_g16(a.XM + gi, gr);
+                            st_g16_local(XML_ + gi, gr); st_g16(XM_ + gi, gr);
                         }
                     }
                 }
                 PIPE_SVC(4);
                 lds_barrier();
                 PIPE_SVC(5);
-                if (a.trace && (!fast || top) && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
+                if (trace_on && (!fast || top) && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
                 if (t + 1 < T) pre_issue(s, t + 1, d == 1);          // wave 3: ring reads of this stream's NEXT sample, consumed in step 5
                 // ---- 4. skip chain: running sum of CU (l-1, j) + W_skip[:, mine] u_mine  -> CU (l+1, j) / head (wavenet.py:833-836)
                 {
@@ -469,7 +484,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     lds_barrier();
                     PIPE_SVC(6);
                     if (l > 0) {       // one poll per GRANULE (3 channels), by the first (S+2)/3 threads
-                        const __amdgpu_buffer_rsrc_t rs = poll_rsrc((loc_skip ? a.SML : a.SM) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
+                        const __amdgpu_buffer_rsrc_t rs = poll_rsrc((loc_skip ? SML_ : SM_) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
                         for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
                             u32x4 g;
                             int spins = 0;
@@ -488,13 +503,13 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
                         u32x4 g = {__float_as_uint(skp[g3 * 3]), __float_as_uint(skp[g3 * 3 + 1]), __float_as_uint(skp[g3 * 3 + 2]), want};
                         const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_SG + g3;
-                        st_g16_local(a.SML + gi, g); st_g16(a.SM + gi, g);
+                        st_g16_local(SML_ + gi, g); st_g16(SM_ + gi, g);
                     }
                 }
                 PIPE_SVC(8);
                 // ---- 5. queue update (private ring) and the pre-multiplication for this stream's next step
                 {
-                    bf16_t* ringb = a.ring + a.ring_off[l] + ((int64_t)(j * B + s) * (mask + 1)) * R;
+                    bf16_t* ringb = ring_ + a.ring_off[l] * B + ((int64_t)(j * B + s) * (mask + 1)) * R;
                     for (int i = tid; i < R / 8; i += PIPE_THREADS)
                         *reinterpret_cast<uint4*>(ringb + (int64_t)(t & mask) * R + i * 8) = *reinterpret_cast<const uint4*>(xcur_b + i * 8);
                     PIPE_SVC(9);
@@ -555,7 +570,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 const uint2 q = *reinterpret_cast<const uint2*>(outp + g * 4);
                 u32x4 gr = {q.x, q.y, 0, (uint32_t)(tn + 1)};
                 const int64_t gi = ((int64_t)(0 * B + s) * P + 0) * PIPE_XG + g;
-                st_g16_local(a.XML + gi, gr); st_g16(a.XM + gi, gr);
+                st_g16_local(XML_ + gi, gr); st_g16(XM_ + gi, gr);
             }
             lds_barrier();
         };
@@ -570,13 +585,13 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 float nz_pre = 0.0f, ti_pre = 0.0f;       // nz_pre: lane i < M: -log(-log u1_i) (Gumbel); lane M: log u2 - log(1 - u2) (logistic)
                 if (mode == 0 && wave == 0) {
                     const int M = O / 3;
-                    if (lane < a.nps) { const float uu = a.noise[((int64_t)t * B + s) * a.nps + lane]; nz_pre = (lane < M) ? -logf(-logf(uu)) : logf(uu) - logf(1.0f - uu); }
-                    if (a.test_inputs) ti_pre = ((const float*)a.test_inputs)[(int64_t)s * T + t];
+                    if (lane < a.nps) { const float uu = a.noise[((int64_t)t * Bn + s0 + s) * a.nps + lane]; nz_pre = (lane < M) ? -logf(-logf(uu)) : logf(uu) - logf(1.0f - uu); }
+                    if (ti_) ti_pre = ((const float*)ti_)[(int64_t)s * T + t];
                 }
                 // ---- total skip = sum of the P running sums that left the top layer (+ all skip biases), ReLU (wavenet.py:840)
                 {
-                    const __amdgpu_buffer_rsrc_t rsa = poll_rsrc((hloc0 ? a.SML : a.SM) + ((int64_t)(L * B + s) * P) * PIPE_SG, P * PIPE_SG * 16);
-                    const __amdgpu_buffer_rsrc_t rsb = poll_rsrc((hloc1 ? a.SML : a.SM) + ((int64_t)(L * B + s) * P) * PIPE_SG, P * PIPE_SG * 16);
+                    const __amdgpu_buffer_rsrc_t rsa = poll_rsrc((hloc0 ? SML_ : SM_) + ((int64_t)(L * B + s) * P) * PIPE_SG, P * PIPE_SG * 16);
+                    const __amdgpu_buffer_rsrc_t rsb = poll_rsrc((hloc1 ? SML_ : SM_) + ((int64_t)(L * B + s) * P) * PIPE_SG, P * PIPE_SG * 16);
                     const int ng = (S + 2) / 3;
                     float v[2][3] = {{0, 0, 0}, {0, 0, 0}};
                     const bool h0 = lane < ng, h1 = lane + 64 < ng;
@@ -607,7 +622,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         for (int e = 0; e < 3; ++e) { const int ch = (lane + 64 * hh) * 3 + e; if (ch < S) psum[wave * (S + 4) + ch] = v[hh][e]; }
                 }
                 lds_barrier();
-                if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L] = wall_clock64();
+                if (trace_on && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L] = wall_clock64();
                 for (int r = tid; r < S; r += PIPE_THREADS) {
                     float tot = sb[r];
                     for (int w = 0; w < 4 && w < P; ++w) tot += psum[w * (S + 4) + r];
@@ -638,7 +653,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     for (int r = tid; r < OP; r += PIPE_THREADS) yraw[r] = (r < O) ? mv_rows<H>(Wh2, OP, r, reinterpret_cast<const char*>(h2), 0, S / 8) + b2[r] : 0.0f;
                 }
                 lds_barrier();
-                if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 1] = wall_clock64();
+                if (trace_on && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 1] = wall_clock64();
                 // ---- sample (wavenet.py:847-878); noise [T][B][nps] was prefetched while the message was in the stack
                 if (mode == 0 && O / 3 <= 16) {
                     if (wave == 0) {         // mixture.py:76-107: Gumbel-max over the mixture logits (first maximum wins), then the logistic
@@ -652,17 +667,17 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                             const float ls = fmaxf(yraw[2 * M + bi], a.lsmin);
                             float x = yraw[M + bi] + expf(ls) * lgt;
                             x = fminf(fmaxf(x, -1.0f), 1.0f);
-                            ((float*)a.out_samples)[(int64_t)s * T + t] = x;
-                            nxt_f[0] = a.test_inputs ? ti_pre : x;
+                            ((float*)outs_)[(int64_t)s * T + t] = x;
+                            nxt_f[0] = ti_ ? ti_pre : x;
                         }
                     }
                 } else if (tid == 0) {
-                    const float* nz = a.noise + ((int64_t)t * B + s) * a.nps;
+                    const float* nz = a.noise + ((int64_t)t * Bn + s0 + s) * a.nps;
                     if (mode == 2) {
                         float best = -INFINITY; int bi = 0;
                         for (int q = 0; q < O; ++q) { const float vv = yraw[q] - logf(-logf(nz[q])); if (vv > best) { best = vv; bi = q; } }
-                        ((int32_t*)a.out_samples)[(int64_t)s * T + t] = bi;
-                        nxt_i[0] = a.test_inputs ? ((const int32_t*)a.test_inputs)[(int64_t)s * T + t] : bi;
+                        ((int32_t*)outs_)[(int64_t)s * T + t] = bi;
+                        nxt_i[0] = ti_ ? ((const int32_t*)ti_)[(int64_t)s * T + t] : bi;
                     } else {
                         float x;
                         if (mode == 0) {
@@ -674,15 +689,15 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                             x = yraw[M + bi] + expf(ls) * (logf(u) - logf(1.0f - u));
                         } else x = yraw[0] + expf(fmaxf(yraw[1], a.lsmin)) * nz[0];
                         x = fminf(fmaxf(x, -1.0f), 1.0f);
-                        ((float*)a.out_samples)[(int64_t)s * T + t] = x;
-                        nxt_f[0] = a.test_inputs ? ((const float*)a.test_inputs)[(int64_t)s * T + t] : x;
+                        ((float*)outs_)[(int64_t)s * T + t] = x;
+                        nxt_f[0] = ti_ ? ((const float*)ti_)[(int64_t)s * T + t] : x;
                     }
                 }
-                if (a.out_raw) for (int o = tid; o < O; o += PIPE_THREADS) a.out_raw[((int64_t)s * O + o) * T + t] = yraw[o];
+                if (outr_) for (int o = tid; o < O; o += PIPE_THREADS) outr_[((int64_t)s * O + o) * T + t] = yraw[o];
                 lds_barrier();
-                if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 2] = wall_clock64();
+                if (trace_on && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 2] = wall_clock64();
                 if (t + 1 < T) publish_input(s, t + 1);
-                if (a.trace && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 3] = wall_clock64();
+                if (trace_on && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 3] = wall_clock64();
                 if (pipe_aborted(abortf)) return;
             }
         }
@@ -704,7 +719,57 @@ struct Pipe {
     bool f16 = false;                   // 16-bit storage type of weights / hand-offs / queues: IEEE half instead of bf16 (wn_ctx::pipe_f16 at the run)
     PipeArgs proto;
     hipStream_t priv = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // several pipeline INSTANCES side by side (round 5): a model whose L * P + 1 CUs fit the chip more than once (hparams.py's defaults: 81 CUs, three
+    // times by CU count, twice with the slack the dispatcher needs) serves a batch of more than 8 streams as NI independent runs of <= 8 where they fit -- the regime in which a run costs the wall time of ONE stream
+#define PIPE_MAX_INST 3
+    int ni_max = 1;                                    // how many instances the chip holds (layout below)
+    int32_t* tabs_dev[PIPE_MAX_INST + 1] = {};         // [ni]: role table (256) + ni block tables (L * P + 1 each) of the ni-instance layout
+    int grid_ni[PIPE_MAX_INST + 1] = {};
 };
+
+// Which workgroup plays which CU.  Block b runs on XCD b % 8 (observed; speed only): one instance keeps the scheme of rounds 2-4 (spx consecutive
+// layers per XCD, the head on XCD 0, <= 30 CUs per XCD); several instances share ONE launch of 256 workgroups and are packed XCD by XCD, a layer's P CUs
+// never split.  (One launch PER instance was built first and fails: where a kernel's ids land is only modulo-8 regular WITHIN a launch, so the
+// instances' CU sets collide on some XCD, a launch stays partially resident and its hand-offs time out -- measured, profiles/r7f.)
+static bool pipe_layout(int L, int P, int ni, std::vector<int32_t>& role, std::vector<int32_t>& blk, int& grid) {
+    const int per = L * P + 1;
+    blk.assign((size_t)ni * per, -1);
+    if (ni == 1) {
+        const int spx = (L + 7) / 8;
+        grid = 8 * (spx * P + 1);
+        role.assign(grid, -1);
+        for (int b = 0; b < grid; ++b) {
+            const int xcd = b & 7, slot = b >> 3;
+            if (slot < spx * P) { const int layer = spx * xcd + slot / P, j = slot % P; if (layer < L) { role[b] = (layer << 8) | j; blk[layer * P + j] = b; } }
+            else if (xcd == 0) { role[b] = 1 << 23; blk[L * P] = b; }
+        }
+        return true;
+    }
+    grid = 256; role.assign(grid, -1);           // ONE launch for all instances: every XCD gets exactly 32 ids, any CU of the XCD takes any of them
+    int xcd = 0, used = 0;
+    auto place = [&](int n) { if (used + n > 32) { ++xcd; used = 0; } const int k = used; used += n; return xcd < 8 ? k : -1; };
+    for (int i = 0; i < ni; ++i) {
+        for (int l = 0; l < L; ++l) {
+            const int k = place(P); if (k < 0) return false;
+            for (int j = 0; j < P; ++j) { const int b = 8 * (k + j) + xcd; role[b] = (i << 24) | (l << 8) | j; blk[(size_t)i * per + l * P + j] = b; }
+        }
+        const int k = place(1); if (k < 0) return false;
+        role[8 * k + xcd] = (i << 24) | (1 << 23); blk[(size_t)i * per + L * P] = 8 * k + xcd;
+    }
+    return true;
+}
+static int pipe_ni_max(int L, int P) {
+    std::vector<int32_t> r, b; int g;
+    for (int ni = PIPE_MAX_INST; ni > 1; --ni) if (pipe_layout(L, P, ni, r, b, g)) return ni;
+    return 1;
+}
+// instances a batch of B streams is cut into: runs of <= 8 streams cost the wall time of ONE stream (10: + 5 %, then + 3.6 us per stream)
+static int pipe_instances(int L, int P, int B) {
+    static const int env = [] { const char* e = getenv("WN_PIPE_INSTANCES"); return e ? atoi(e) : 0; }();      // A/B switch: 1 = one run for the whole batch
+    const int want = env > 0 ? env : (B + 7) / 8;
+    return std::max(1, std::min(std::min(want, pipe_ni_max(L, P)), B));
+}
+
 
 void wn_pipe_free(wn_ctx* c) {
     Pipe* p = (Pipe*)c->pipe;
@@ -714,6 +779,7 @@ void wn_pipe_free(wn_ctx* c) {
     if (p->priv) (void)hipStreamSynchronize(p->priv);
     if (p->abort_host) hipHostFree(p->abort_host);
     if (p->ev0) hipEventDestroy(p->ev0); if (p->ev1) hipEventDestroy(p->ev1); if (p->priv) hipStreamDestroy(p->priv);
+    for (int i = 0; i <= PIPE_MAX_INST; ++i) if (p->tabs_dev[i]) hipFree(p->tabs_dev[i]);
     delete p; c->pipe = nullptr;
 }
 
@@ -727,7 +793,8 @@ bool wn_pipe_eligible(const wn_ctx* c, int B) {
     const int spx = (L + 7) / 8;
     if (spx * P + 1 > 30) return false;                 // 32 CUs per XCD, keep slack
     const int64_t layer_static = 64LL * R * 2 + 64LL * (2 * R + C) * 2 + 32LL * R * 2 + 32LL * S * 2 + 256 + R * 4;
-    const int64_t layer_dyn = R * 2 + R * 4 + 16LL * R + 8LL * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256LL * B + 64;
+    const int ni = pipe_instances(L, P, B), Bi = (B + ni - 1) / ni;                  // streams of ONE run (z_past: 256 B of LDS each)
+    const int64_t layer_dyn = R * 2 + R * 4 + 16LL * R + 8LL * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256LL * Bi + 64;
     const int64_t head_static = (int64_t)S * S * 2 + (int64_t)c->OP * S * 2 + S * 4 * 2 + c->OP * 4 + R * 8 + 64;
     const int64_t head_dyn = 16LL * (S + 4) + S * 4 + c->OP * 4 + (R + 16) * 2 + 64;
     return layer_static + layer_dyn <= 160 * 1024 && head_static + head_dyn <= 160 * 1024;
@@ -799,13 +866,23 @@ static int pipe_build(wn_ctx* c, Pipe* p) {
     WN_HIP(c, hipMemcpy(p->jobs_dev, jobs.data(), jobs.size() * sizeof(SliceJob), hipMemcpyHostToDevice));
     WN_HIP(c, hipMalloc((void**)&p->job_block0_dev, b0.size() * sizeof(int)));
     WN_HIP(c, hipMemcpy(p->job_block0_dev, b0.data(), b0.size() * sizeof(int), hipMemcpyHostToDevice));
-    WN_HIP(c, hipMalloc((void**)&p->abort_dev, 256 + 4096));       // [0]: abort flag; +256: XCC table (grid <= 1024 entries)
-    WN_HIP(c, hipMemset(p->abort_dev, 0, 256 + 4096));
+    WN_HIP(c, hipMalloc((void**)&p->abort_dev, 256 + PIPE_MAX_INST * 4096));       // [0]: abort flag; +256: one XCC table per instance (grid <= 1024 entries)
+    WN_HIP(c, hipMemset(p->abort_dev, 0, 256 + PIPE_MAX_INST * 4096));
     WN_HIP(c, hipHostMalloc((void**)&p->abort_host, 64, hipHostMallocDefault));
     *p->abort_host = 0;
     WN_HIP(c, hipStreamCreateWithFlags(&p->priv, hipStreamNonBlocking));
     WN_HIP(c, hipEventCreateWithFlags(&p->ev0, hipEventDisableTiming));
     WN_HIP(c, hipEventCreateWithFlags(&p->ev1, hipEventDisableTiming));
+    p->ni_max = pipe_ni_max(L, P);
+    for (int ni = 1; ni <= p->ni_max; ++ni) {
+        std::vector<int32_t> role, blk; int grid = 0;
+        if (!pipe_layout(L, P, ni, role, blk, grid)) WN_FAIL(c, WN_E_STATE, "pipeline layout for %d instances", ni);
+        p->grid_ni[ni] = grid;
+        std::vector<int32_t> all(role);                 // role table (grid) then the ni block tables (L * P + 1 each)
+        all.insert(all.end(), blk.begin(), blk.end());
+        WN_HIP(c, hipMalloc((void**)&p->tabs_dev[ni], all.size() * 4));
+        WN_HIP(c, hipMemcpy(p->tabs_dev[ni], all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    }
     return WN_OK;
 }
 
@@ -936,13 +1013,24 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         WN_HIP(c, hipMemsetAsync(svc_dev, 0, (size_t)trace_n * 16 * 8, st));
         a.svc = svc_dev; a.svc_l = L / 2; a.svc_s = B / 2; a.trace_t0 = 500; a.trace_n = trace_n;
     }
-    const int lds_bytes = std::max(p->layer_lds + 256 * B, p->head_lds);      // z_past [B][64] fp32 per layer CU (wn_pipe_eligible checked that it fits)
+    // ---- ONE launch; ni > 1: several pipeline instances side by side, instance i serving the streams [is0, is0 + iB) on its own CUs (role table bits
+    // 24-25), mailbox / queue regions (offsets linear in is0) -- runs of <= 8 streams cost the wall time of one stream
+    const int ni = pipe_instances(L, P, B);
+    const int per = L * P + 1, grid = p->grid_ni[ni];
+    const int Bmax = (B + ni - 1) / ni;
+    const int lds_bytes = std::max(p->layer_lds + 256 * Bmax, p->head_lds);      // z_past [iB][64] fp32 per layer CU (wn_pipe_eligible checked that it fits)
+    a.ninst = ni; a.ring_unit = 0;
+    for (int l = 0; l < L; ++l) { a.ring_off[l] = a.ring_unit; a.ring_unit += (int64_t)P * (a.ring_mask[l] + 1) * R; }      // per STREAM: the kernel multiplies by its instance's stream count
+    for (int i = 0, s0 = 0; i < ni; ++i) { a.iB[i] = B / ni + (i < B % ni ? 1 : 0); a.is0[i] = s0; s0 += a.iB[i]; }
+    a.role_tab = p->tabs_dev[ni]; a.block_tab = a.role_tab + grid;
+    (void)per;
     {
-        void (*kern)(const PipeArgs) = p->f16 ? wn_synth_pipe_kernel<1> : wn_synth_pipe_kernel<0>;
+        void (*kern)(const PipeArgs) = ni > 1 ? (p->f16 ? wn_synth_pipe_kernel<1, 1> : wn_synth_pipe_kernel<0, 1>) : (p->f16 ? wn_synth_pipe_kernel<1, 0> : wn_synth_pipe_kernel<0, 0>);
         WN_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        hipLaunchKernelGGL(kern, dim3(p->grid), dim3(PIPE_THREADS), lds_bytes, st, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     }
     WN_LAUNCH_CHECK(c);
+    c->synth_instances = ni;
     // the abort flag travels to pinned host memory behind the kernel; nobody waits for it here (wn_pipe_check / the next call read it)
     if (const char* e = getenv("WN_PIPE_TEST_ABORT")) {      // test hook: raise the flag as a timed-out hand-off would, until `n` runs of this context were flagged in total
         if (p->test_aborts < atoi(e)) { ++p->test_aborts; WN_HIP(c, hipMemsetD32Async((hipDeviceptr_t)p->abort_dev, 999, 1, st)); }

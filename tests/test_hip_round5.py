@@ -4,6 +4,7 @@ import json
 import os
 import time
 
+import numpy as np
 import pytest
 import torch
 
@@ -132,3 +133,40 @@ def test_pipe_fp16_overflow_is_reported_and_the_facade_falls_back_to_bf16():
         W.log = orig
     assert any('bf16 pipeline storage' in m for m in logged), logged
     assert torch.isfinite(got).all() and model.engine.synth_path == 'pipeline' and model.synth_fallbacks == 1
+
+
+def test_pipeline_instances_serve_the_default_synthesis_batch_side_by_side():
+    """hparams.py: wavenet_synthesis_batch_size = 20 on hparams.py's own model width (R = 128: 4 CUs per layer).  A model whose L * P + 1 CUs fit the
+    chip more than once runs a batch of more than 8 streams as several pipeline INSTANCES side by side (own CUs, mailboxes and queues each; runs
+    of <= 8 streams cost the wall time of one).  Every stream against the FP32 oracle, the instance count, and a batch that is
+    not divisible by the instance count (20 -> 7 + 7 + 6; 11 -> 6 + 5; 32 -> 11 + 11 + 10; 8 -> one run)."""
+    for B, want_ni in ((20, 3), (11, 2), (32, 3), (8, 1)):
+        hp, cfg, eng, params, wav, c, T = _setup(B, 6, layers=6, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128)
+        assert eng.pipeline_eligible(B)
+        nz_dev, nz_or = _noise(cfg, T, B)
+        out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, cfg.out_channels, T, device='cuda')
+        eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, wav.contiguous().cuda(), steps_per_graph=0)
+        torch.cuda.synchronize(); eng.synth_check()
+        assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_instances(eng.h) == want_ni
+        with torch.no_grad():
+            _, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=wav.unsqueeze(-1), formulation='ring')
+        per = [rel_err(raw.cpu()[b], r_or[b]) for b in range(B)]
+        exp = O.sample_from_discretized_mix_logistic(raw.cpu(), nz_or['u1'].permute(1, 0, 2), nz_or['u2'].t(), cfg.log_scale_min)
+        print('\n%d streams as %d pipeline instances: worst stream %.2e' % (B, want_ni, max(per)))
+        assert max(per) < 4e-3 and torch.allclose(out.cpu(), exp, atol=2e-5)
+        eng.close()
+    # hparams.py's own model (20 layers, 4 CUs per layer: 81 CUs) at hparams.py's own synthesis batch: three instances of 7 + 7 + 6 streams in ONE
+    # launch of 256 workgroups (243 resident); residency of all of them = no hand-off timeout, also on a run long enough for a partially
+    # resident launch to hit its spin limit (a launch per instance did, profiles/r7f)
+    import hparams as H
+    from wavenet_vocoder import _ext
+    from wavenet_vocoder.models.modules import initialize_parameters
+    hp = H._build()
+    hop = int(np.prod(hp.upsample_scales)); Tc = 80
+    eng = _ext.Engine(hp, 20, Tc * hop, inference_only=True)
+    eng.pack_weights(initialize_parameters(hp, eng.layout).cuda())
+    out = torch.empty(20, Tc * hop, device='cuda')
+    eng.synthesize(torch.rand(20, hp.cin_channels, Tc, device='cuda'), None, out, None, None, steps_per_graph=0, seed=3)
+    torch.cuda.synchronize(); eng.synth_check()
+    assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_instances(eng.h) == 3 and torch.isfinite(out).all()
+    eng.close()

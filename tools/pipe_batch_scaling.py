@@ -38,14 +38,24 @@ def main():
             c = torch.rand(B, hp.cin_channels, Tc, device=dev)
             samples = torch.empty(B, T, device=dev)
             eng.synthesize(c[:, :, :8].contiguous(), None, torch.empty(B, 8 * hop, device=dev), None, None, steps_per_graph=0, seed=1)
-            torch.cuda.synchronize(); eng.synth_check()
+            torch.cuda.synchronize()
+            try:
+                eng.synth_check()
+            except Exception as e:      # noqa: BLE001
+                print('%s B=%d (warm-up): %s' % (key, B, e), file=sys.stderr, flush=True)
+                rows[B] = None; eng.close(); continue
             t0 = time.time()
             eng.synthesize(c, None, samples, None, None, steps_per_graph=0, seed=2)
             torch.cuda.synchronize(); dt = time.time() - t0
-            eng.synth_check()
-            rows[B] = {'us_per_step': dt / T * 1e6, 'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt, 'finite': bool(torch.isfinite(samples).all())}
+            try:
+                eng.synth_check()
+            except Exception as e:      # noqa: BLE001
+                print('%s B=%d: %s' % (key, B, e), file=sys.stderr, flush=True)
+                rows[B] = None; eng.close(); continue
+            rows[B] = {'instances': int(eng.lib.wn_synth_last_instances(eng.h)), 'us_per_step': dt / T * 1e6, 'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt, 'finite': bool(torch.isfinite(samples).all())}
             eng.close()
         out[key] = rows
+        print(key, {b: (r and (r['instances'], round(r['us_per_step'], 1))) for b, r in rows.items()}, file=sys.stderr, flush=True)
         base = rows[8]['us_per_step']
         print('%s (R = %d, %d layers): ' % (key, hp.residual_channels, hp.layers) + '  '.join('B=%d: %.1f us (%.2fx)' % (b, r['us_per_step'], r['us_per_step'] / base) if r else 'B=%d: -' % b for b, r in rows.items()))
     print(json.dumps(out))
