@@ -447,6 +447,7 @@ extern "C" int wn_fill_noise(wn_ctx* c, float* noise, int32_t B, int32_t T, uint
 extern "C" int wn_synth_check(wn_ctx* c) { if (!c) return WN_E_ARG; return wn_pipe_check(c, true); }
 extern "C" int wn_synth_last_path(const wn_ctx* c) { return c ? c->synth_path : WN_E_ARG; }
 extern "C" int wn_synth_last_instances(const wn_ctx* c) { return c ? c->synth_instances : WN_E_ARG; }
+extern "C" int wn_synth_last_batched(const wn_ctx* c) { return c ? (c->synth_path == 2 ? c->synth_batchpre : 0) : WN_E_ARG; }
 extern "C" int wn_synth_pipe_dtype(wn_ctx* c, int32_t half) { if (!c) return WN_E_ARG; c->pipe_f16 = half != 0; return WN_OK; }
 extern "C" int wn_test_gemm8p_mask(const wn_ctx* c) {
     if (!c) return WN_E_ARG;

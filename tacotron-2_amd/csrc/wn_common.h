@@ -191,6 +191,7 @@ struct wn_ctx {
     void* pipe = nullptr;                 // persistent synthesis pipeline state (wn_synth_pipe.hip)
     bool pipe_f16 = false;                // persistent pipeline: IEEE-half weights / hand-offs / queues instead of bf16 (WN_PIPE_DTYPE=fp16|bf16 at wn_create, wn_synth_pipe_dtype)
     int synth_instances = 0;              // pipeline instances the last wn_synthesize ran side by side (wn_synth_last_instances)
+    int synth_batchpre = 0;               // the last pipeline run multiplied every stream's past taps / conditioning in ONE matrix product per sample (wn_synth_last_batched)
     int pipe_cap = 0;                     // inference-only contexts: streams of ONE pipeline run the pre-sized buffers hold (0: pipeline not used / not limited)
     void* f32 = nullptr;                  // fp32-forward state (wn_f32.hip), allocated on the first forward of a cfg.compute_dtype = WN_COMPUTE_F32 context
     bool fwd_was_f32 = false;

@@ -33,6 +33,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 #define PIPE_XG 128           // granule slots per x partial: 4 bf16 channels each (R/4 used; lane g polls g and g+64)
 #define PIPE_SG 128           // granules per skip partial: 3 fp32 channels each
 #define PIPE_SPIN_LIMIT 3000000
+#define PIPE_ZS 68             // floats of z_past per stream: 64 rows + 4 (the batched pre-multiplication stores float4s: conflict-free at a 272-B pitch)
 
 struct PipeArgs {
     int32_t L, P, R, G, GH, S, O, OP, C, Cin, B, T;
@@ -44,7 +45,10 @@ struct PipeArgs {
     u32x4* XML; u32x4* SML;          // the same mailboxes written with plain stores: they live in the WRITER's XCD L2, readable (sc1 loads) by CUs of that XCD only
     int32_t* xcc_tab;                // [grid] XCC id + 1 of every workgroup (0 = not started)
     const int32_t* role_tab;         // [grid] role of every workgroup: layer << 8 | j, bit 23: head, -1: none (host-built: which XCD hosts which layers)
-    const int32_t* block_tab;        // [L * P + 1] inverse: workgroup id of CU (layer, j); [L * P]: the head
+    const int32_t* block_tab;        // [L * P + NH] inverse: workgroup id of CU (layer, j); [L * P + h]: head h
+    int32_t abort_every;             // 1: layer CUs test the abort word after every stream (rounds 2-4), 0: once per sample
+    int32_t early_from;              // runs of at least this many streams request the NEXT stream's x granules and this stream's skip granule one stage early (see the sample loop)
+    int32_t NH;                      // head CUs of a single-instance run: head h serves the streams s = h (mod NH) (instances side by side: one head each)
     int32_t ninst, iB[4], is0[4];    // pipeline instances side by side in ONE launch (round 5): instance i serves the streams [is0[i], is0[i] + iB[i]) of the
                                      // batch of B on its own CUs (role table: bits 24-25), mailboxes and ring queues (offsets linear in is0); ninst = 1: iB[0] = B
     bf16_t* ring; int64_t ring_unit; const bf16_t* cbt;      // ring_unit: ring elements of ONE stream over all layers and CUs (instance offset = ring_unit * is0)
@@ -87,6 +91,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t poll_rsrc(const void* base, in
     const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
     return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+
+// Publishing stores the COMPILER can count (fast path of the layer CUs).  vmcnt retires in order and counts stores: hipcc does not see a store inside
+// inline asm, so every wait it emits for a later load (`vmcnt(number of younger loads)`) also waits for the acknowledgement of an older asm store -- ~1 us
+// for a write-through one.  As builtins, issued unconditionally by every wave (a lane / wave / copy that has nothing to publish passes offset -1: beyond
+// num_records, the hardware drops the write), they are part of the count on every path and a wait skips exactly the stores younger than what it needs.
+__device__ __forceinline__ void st_buf16(__amdgpu_buffer_rsrc_t r, int byte_off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0); }
+__device__ __forceinline__ void st_buf16_wt(__amdgpu_buffer_rsrc_t r, int byte_off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 17 /* sc0 sc1 */); }
 
 __device__ __forceinline__ bool pipe_aborted(const int32_t* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 __device__ __forceinline__ void pipe_abort(int32_t* f, int code) { __hip_atomic_store(f, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -180,20 +191,26 @@ __global__ void wn_pipe_slice_kernel(const float* __restrict__ params, char* __r
 // ======================================================================================================================
 #ifdef WN_PIPE_SVC_BUILD      // diagnostic build only (csrc/build.py --pipe-svc): the eleven stamp sites cost SGPRs the kernel does not have
 #define PIPE_SVC(k) do { if (a.svc && inst == 0 && l == a.svc_l && j == 0 && s == a.svc_s && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.svc[(size_t)(t - a.trace_t0) * 16 + (k)] = wall_clock64(); } while (0)
+#define PIPE_SVC_T(k) do { if (a.svc && inst == 0 && l == a.svc_l && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.svc[(size_t)(t - a.trace_t0) * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define PIPE_SVC(k) do { } while (0)
+#define PIPE_SVC_T(k) do { } while (0)
 #endif
-template <int H, int MULTI>
+template <int H, int MULTI, int BP, int SPEC>
 __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int R = a.R, S = a.S, P = a.P, T = a.T, C = a.C;
+    // SPEC: the paper model's widths as compile-time constants (R = S = 256, 8 CUs per layer).  A layer CU runs ONE wave per SIMD, so its service time per stream
+    // is an instruction count (~5 cycles per issued instruction): with the widths known the slow-path code, the granule loops, most exec masking and the
+    // address multiplications disappear from the stream iteration.
+    const int R = SPEC ? 256 : a.R, S = SPEC ? 256 : a.S, P = SPEC ? 8 : a.P, T = a.T, C = a.C;
     // ---- role (host-built table: consecutive layers share an XCD -- block b runs on XCD b % 8 --; one instance: spx layers per XCD, the head on XCD 0)
     const int32_t role = a.role_tab[blockIdx.x];
     if (role < 0) return;
     const bool is_head = (role >> 23) & 1;
-    const int layer = (role >> 8) & 0xff, j = role & 0xff;
+    const int layer = (role >> 8) & 0xff, j = role & 0xff;                     // (a head: j = its index)
+    const int NH = MULTI ? 1 : a.NH;
     // ---- instance (MULTI: several independent pipelines in this launch; else compile-time instance 0 = the whole batch, nothing rebased)
     const int inst = MULTI ? (role >> 24) & 3 : 0;
     const int B = MULTI ? a.iB[inst] : a.B, s0 = MULTI ? a.is0[inst] : 0, Bn = a.B;
@@ -206,7 +223,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
     char* const outs_ = (char*)a.out_samples + (MULTI ? (int64_t)s0 * T * 4 : 0);
     float* const outr_ = a.out_raw ? a.out_raw + (MULTI ? (int64_t)s0 * a.O * T : 0) : nullptr;
     const int32_t* const btab = a.block_tab + (MULTI ? inst * (a.L * P + 1) : 0);
+#ifdef WN_PIPE_SVC_BUILD
     const bool trace_on = a.trace && inst == 0;
+#else
+    constexpr bool trace_on = false;          // (stage trace WN_PIPE_TRACE: diagnostic build only, like the service-time stamps -- its tests sat in every stream iteration)
+#endif
     int32_t* const abortf = a.abort_flag;
     // ---- which XCD am I really on?  (block -> XCD = b % 8 is observed, not guaranteed: the table makes the fast path a pure
     // speed choice -- a hand-off whose two ends share an XCD uses the plain-store copy of the mailbox, served by that XCD's L2
@@ -214,15 +235,15 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
     int my_xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc)); my_xcc &= 0xf;
     if (threadIdx.x == 0) __hip_atomic_store(a.xcc_tab + blockIdx.x, my_xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     auto block_of = [&](int lay, int jj) { return btab[lay * P + jj]; };     // inverse of the role map
-    const int head_block = btab[a.L * P];
-    auto same_xcc = [&](int block) {
+    auto xcc_of = [&](int block) {
         int v = 0, spins = 0;
         while ((v = __hip_atomic_load(a.xcc_tab + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 50); break; }
         }
-        return v - 1 == my_xcc;
+        return v - 1;
     };
+    auto same_xcc = [&](int block) { return xcc_of(block) == my_xcc; };
 
     if (!is_head) {
         // ================================================================= layer CU (layer, j)
@@ -244,14 +265,30 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         bf16_t* outp = reinterpret_cast<bf16_t*>(p); p += ((R + 7) / 8 * 8 + 8) * 2;
         float* skp = reinterpret_cast<float*>(p); p += (S + 4) * 4;
         bf16_t* vec = reinterpret_cast<bf16_t*>(p); p += (2 * R + C) * 2;
-        float* zpast = reinterpret_cast<float*>(p);                       // [B][64]
+        float* zpast = reinterpret_cast<float*>(p);                       // [B][PIPE_ZS]
         const int d = a.dil[l], mask = a.ring_mask[l];
         const int KP = (2 * R + C) / 8;                                    // k-chunks of the past-tap image
         const int nprod = (l == 0) ? 1 : P;
-        const bool loc0 = (wave < nprod) && same_xcc(l == 0 ? head_block : block_of(l - 1, wave));
+        bool loc0 = (wave < nprod);
+        if (l == 0) { for (int h = 0; h < NH; ++h) loc0 = loc0 && same_xcc(btab[a.L * P + h]); }      // layer 0 reads what the heads publish: the XCD-local copy only if EVERY head shares the XCD
+        else loc0 = loc0 && same_xcc(block_of(l - 1, wave));
         const bool loc1 = (wave + 4 < nprod) && same_xcc(block_of(l - 1, wave + 4));
         const bool loc_skip = (l > 0) && same_xcc(block_of(l - 1, j));
         const bool top = (l == a.L - 1);
+        // Which copy of a mailbox do MY consumers read?  (A hand-off used to be written twice -- a plain store for consumers on this XCD, a write-through
+        // store for the others -- and every consumer picks by the same XCC comparison made here: the copy nobody reads is not written.  A layer's P CUs
+        // share an XCD by layout, so this halves the publishing stores; the write-through ones are the slow ones, ~1 us to acknowledge.)
+        bool xpub_loc = false, xpub_rem = false, spub_loc = false, spub_rem = false;
+        if (!top) {
+            bool all = true, any = false;
+            for (int jj = 0; jj < P; ++jj) { const bool q = same_xcc(block_of(l + 1, jj)); all = all && q; any = any || q; }
+            xpub_loc = any; xpub_rem = !all;
+            spub_loc = same_xcc(block_of(l + 1, j)); spub_rem = !spub_loc;
+        } else {
+            bool all = true, any = false;
+            for (int h = 0; h < NH; ++h) { const bool q = same_xcc(btab[a.L * P + h]); all = all && q; any = any || q; }
+            spub_loc = any; spub_rem = !all;
+        }
         lds_barrier();
 
         // z_past for (s, tn): taps x(tn-2d), x(tn-d) from this CU's ring (zero before the utterance), conditioning c(s, tn)
@@ -278,7 +315,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 zpart[wave * 64 + lane] = mv_rows<H>(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
             }
             lds_barrier();
-            if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + (a.gbias ? gb : zb[tid]);
+            if (tid < 64) zpast[s * PIPE_ZS + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + (a.gbias ? gb : zb[tid]);
             lds_barrier();
         };
         for (int s = 0; s < B; ++s) precompute(s, 0, false);
@@ -331,7 +368,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 zpart[wave * 64 + lane] = mv_rows<H>(W1p, 64, lane, reinterpret_cast<const char*>(vec), kc0, kc1);
             }
             lds_barrier();
-            if (tid < 64) zpast[s * 64 + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + (a.gbias ? gb : zb[tid]);
+            if (tid < 64) zpast[s * PIPE_ZS + tid] = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + (a.gbias ? gb : zb[tid]);
             lds_barrier();
         };
 
@@ -341,6 +378,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         //   (quad xor 1, xor 2, half-row mirror) and the gate is evaluated in the lane that owns the pair: no LDS round trip.
         //   out rows: thread r owns row r of W_out[:, my 32 columns] -> 4 k-chunks = 16 VGPRs.
         const bool fast = (R == 256);
+        const bool fast_skip = fast;
         uint4 w1t[4], w1s[4], wor[4];
         const int pr = lane >> 3, k8 = lane & 7;
         const int zrow_t = 8 * wave + pr, zrow_s = 32 + 8 * wave + pr;
@@ -353,15 +391,138 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
 #pragma unroll
             for (int cix = 0; cix < 4; ++cix) wor[cix] = *reinterpret_cast<const uint4*>(Wo + ((size_t)cix * R + tid) * 16);
         }
+        // ---- batched pre-multiplication (BP, round 5; fast path only).  A layer CU spent 1.3 of its 3.7 us per stream on the pre-multiplication of
+        // that stream's next sample (a 64 x (2R + C) matvec behind three workgroup barriers, profiles/r6i_pipe_svc_trace.txt) -- work that does not
+        // depend on the message in flight.  Here wave 3 only PARKS the stream's input vector (two ring rows + conditioning) in LDS, and once per
+        // sample, after the last stream, the CU multiplies ALL parked vectors at once on the matrix cores: [64 rows x K] x [K x streams], wave w
+        // owning rows 16w..16w+15 over the full K (no cross-wave sum), v_mfma_f32_16x16x32 with A straight from the [kc][row][8] weight image.
+        // The vectors live where the register-resident tap-2 weights were read from (W1c's 32 KiB image is dead after the copy above).
+        // parked vector = KP chunks of 16 B, zero-padded to whole passes of 16 chunks (a partial last pass multiplies weights -- or whatever finite image
+        // follows them -- by zeros), at a pitch of 2 (mod 16) chunks: the 16-lane groups of a ds_read_b128 then hit 16 different 16-B slots
+        const int KPAD = (KP + 15) / 16 * 16;
+        const int VSTR = ((KPAD + 13) / 16 * 16 + 2) * 16;
+        char* const Vb = lds + a.off_w1c;
+        if (BP) {
+            lds_barrier();                                                    // every wave holds its W1c registers before the image is overwritten
+            for (int i = tid; i < B * (KPAD - KP); i += PIPE_THREADS) *reinterpret_cast<uint4*>(Vb + (i / (KPAD - KP)) * VSTR + (KP + i % (KPAD - KP)) * 16) = make_uint4(0, 0, 0, 0);
+        }
+        auto pre_stash = [&](int s, int tn, bool tap1_is_cur) {
+            if (wave != 3) return;
+            pf_wait(pf0, pf1);
+            char* vb = Vb + s * VSTR;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = lane + 64 * q, k = i * 8;
+                if (i < KR) {
+                    uint4 v = __builtin_bit_cast(uint4, q ? pf1 : pf0);
+                    if (k >= R && tap1_is_cur && tn - d >= 0) v = *reinterpret_cast<const uint4*>(xcur_b + (k - R));
+                    *reinterpret_cast<uint4*>(vb + k * 2) = v;
+                } else if (i < KP) *reinterpret_cast<uint4*>(vb + k * 2) = cvt8_bf16<H>(__builtin_bit_cast(uint4, q ? pf1 : pf0));
+            }
+        };
+        auto pre_batch = [&](int t) {
+            (void)t;
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const int n = lane & 15, kq = lane >> 4;
+            const bool two = B > 16;
+            // per-stream gate bias (global conditioning) or the layer's own: D[m = 4 kq + i][n] is this lane's (row 16 wave + 4 kq + i, stream n / 16 + n)
+            float bias0[4], bias1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * wave + 4 * kq + i;
+                if (a.gbias) {
+                    const int ch = row < 32 ? 32 * j + row : a.GH + 32 * j + (row - 32);
+                    bias0[i] = n < B ? a.gbias[((int64_t)l * Bn + s0 + n) * a.G + ch] : 0.0f;
+                    bias1[i] = two && 16 + n < B ? a.gbias[((int64_t)l * Bn + s0 + 16 + n) * a.G + ch] : 0.0f;      // (never a load whose value no path consumes: it would stay
+                                                                                                                     // pending in the compiler's count and every later wait would drain the queue)
+                } else bias0[i] = bias1[i] = zb[row];
+            }
+            lds_barrier();                                                    // wave 3 parked the last stream's vector
+            PIPE_SVC_T(13);
+            f32x4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            const char* wa = W1p + (size_t)(16 * wave + n) * 16;
+            const char* vb0 = Vb + n * VSTR; const char* vb1 = Vb + (16 + n) * VSTR;
+            // four k-steps (16 chunks) per pass, all LDS reads of a pass issued before its first MFMA, addresses = one pointer per operand + immediates (a
+            // k-step at a time with per-k-step address arithmetic and masking was issue-bound: 2.0 us per sample, profiles/r8c_pipe_svc_trace.txt)
+            typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+            typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+            auto mm = [&](const uint4& A, const uint4& Bv, f32x4_t c) __attribute__((always_inline)) {
+                if constexpr (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, A), __builtin_bit_cast(f16x8_t, Bv), c, 0, 0, 0);
+                else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, Bv), c, 0, 0, 0);
+            };
+            const char* pa = wa + kq * 1024; const char* pb0 = vb0 + kq * 16; const char* pb1 = vb1 + kq * 16;
+            if (two) {
+                for (int kc0 = 0; kc0 < KPAD; kc0 += 16, pa += 16 * 1024, pb0 += 256, pb1 += 256) {
+                    uint4 A[4], B0[4], B1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { A[u] = *reinterpret_cast<const uint4*>(pa + u * 4096); B0[u] = *reinterpret_cast<const uint4*>(pb0 + u * 64); B1[u] = *reinterpret_cast<const uint4*>(pb1 + u * 64); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { acc0 = mm(A[u], B0[u], acc0); acc1 = mm(A[u], B1[u], acc1); }
+                }
+            } else {
+                for (int kc0 = 0; kc0 < KPAD; kc0 += 16, pa += 16 * 1024, pb0 += 256) {
+                    uint4 A[4], B0[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { A[u] = *reinterpret_cast<const uint4*>(pa + u * 4096); B0[u] = *reinterpret_cast<const uint4*>(pb0 + u * 64); }
+#pragma unroll
+                    for (int u = 0; u < 4; u += 2) { acc0 = mm(A[u], B0[u], acc0); acc1 = mm(A[u + 1], B0[u + 1], acc1); }      // two accumulation chains, summed below
+                }
+            }
+            PIPE_SVC_T(14);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(bias0[i]), "v"(bias1[i]));      // every bias load is consumed HERE on every path: one left pending in the
+                                                                                               // compiler's count (a skipped exec-masked add) turns the next wait -- the top of every stream iteration -- into vmcnt(0)
+            {
+                const int row0 = 16 * wave + 4 * kq;
+                if (!two) acc0 += acc1;
+                if (n < B) *reinterpret_cast<float4*>(zpast + n * PIPE_ZS + row0) = make_float4(acc0[0] + bias0[0], acc0[1] + bias0[1], acc0[2] + bias0[2], acc0[3] + bias0[3]);
+                if (two && 16 + n < B) *reinterpret_cast<float4*>(zpast + (16 + n) * PIPE_ZS + row0) = make_float4(acc1[0] + bias1[0], acc1[1] + bias1[1], acc1[2] + bias1[2], acc1[3] + bias1[3]);
+            }
+            lds_barrier();
+        };
         const int NXG = R / 4;
-        // (Round 5, measured and removed: in runs of more than 10 streams, requesting the next stream's x granules and this stream's skip granule one
-        // stage early -- the polls then only test a value that is already in registers -- changes nothing: 72.0 vs 71.7 us per sample at 20 streams,
-        // profiles/r6n_pipe_batch_scaling*.txt.  The layer CUs and the head wait for EACH OTHER there, not for L2: every one of them serves a stream
-        // in 3.6 - 3.9 us, profiles/r6k_pipe_svc_trace.txt.)
+        // Early requests (runs of >= a.early_from streams).  Such runs are bound by the service time per stream of the slowest CU, and what a CU polls
+        // for was normally published long before it asks: the first-pass x granules of the NEXT stream (right after this stream's x partial left) and
+        // this stream's skip granule (before the own skip matvec) are REQUESTED one stage early and only tested where they used to be polled -- a tag
+        // that is not there yet falls back to the polling loop.  Shorter runs are latency-bound: an early poll finds nothing and slows somebody's
+        // critical hop, so they keep one poll in flight.  (With the per-stream pre-multiplication and ONE head every CU waited for the slowest one
+        // and this bought nothing: 72.0 vs 71.7 us per sample at 20 streams, profiles/r6n; it pays once those two are out of the way.)
+        const bool many = B >= a.early_from;
+        // who owns which granule of the running skip sum (3 fp32 channels each).  Fast path: every wave owns ceil(ng / 4) of them and computes ITS three
+        // rows of W_skip[:, mine] u itself -- no exchange through LDS, no barrier in the skip chain (round 5; it was matvec by row -> barrier -> add by
+        // granule -> barrier -> publish: 1.3 of a layer CU's 3.3 us per stream, profiles/r8d_pipe_svc_trace.txt).  Else: thread g owns granule g.
+        const int ng = (S + 2) / 3, SKW = (ng + 3) / 4;
+        const bool sk_en = fast_skip ? (lane < SKW && SKW * wave + lane < ng) : (tid < ng);
+        const int sk_g3 = sk_en ? (fast_skip ? SKW * wave + lane : tid) : 0;
+        u32x4 xp0 = {0, 0, 0, 0}, xp1 = {0, 0, 0, 0}, skpre = {0, 0, 0, 0}; bool xp_valid = false, skp_valid = false;
+        auto x_request = [&](int s, int t) {
+            xp_valid = false; skp_valid = false;
+            const bool wrap = s + 1 >= B;
+            if (!many || (wrap && t + 1 >= T)) return;
+            const int sn = wrap ? 0 : s + 1;
+            if (wave < nprod) {
+                const __amdgpu_buffer_rsrc_t rn0 = poll_rsrc((loc0 ? XML_ : XM_) + ((int64_t)(l * B + sn) * P) * PIPE_XG, P * PIPE_XG * 16);
+                const __amdgpu_buffer_rsrc_t rn1 = poll_rsrc((loc1 ? XML_ : XM_) + ((int64_t)(l * B + sn) * P) * PIPE_XG, P * PIPE_XG * 16);
+                const bool two = wave + 4 < nprod;
+                const int o0 = (wave * PIPE_XG + lane) * 16, o1 = two ? ((wave + 4) * PIPE_XG + lane) * 16 : o0;
+                xp0 = poll_ld(rn0, o0); xp1 = poll_ld(two ? rn1 : rn0, o1);
+                xp_valid = true;
+            }
+            // the NEXT stream's skip granule too (not this stream's a stage early: a load issued behind this stream's write-through x store returns
+            // behind that store's acknowledgement -- vmcnt retires in order --, ~1 us on the CUs whose consumers sit on another XCD)
+            if (l > 0) {
+                const __amdgpu_buffer_rsrc_t rsn = poll_rsrc((loc_skip ? SML_ : SM_) + ((int64_t)(l * B + sn) * P + j) * PIPE_SG, PIPE_SG * 16);
+                if (sk_en) skpre = poll_ld(rsn, sk_g3 * 16);
+                skp_valid = true;
+            }
+        };
         for (int t = 0; t < T; ++t) {
             const uint32_t want = (uint32_t)(t + 1);
             for (int s = 0; s < B; ++s) {
                 PIPE_SVC(0);
+                const bool xp_have = xp_valid, skp_have = skp_valid;       // a request is good for exactly ONE iteration
+                xp_valid = false; skp_valid = false;
+                const u32x4 skcur = skpre;                                 // (this iteration's x_request overwrites skpre with the NEXT stream's granule before step 4 reads this one)
                 // ---- 1. x_l(t) = sum of the partial vectors published by the previous stage (granule g = channels 4g..4g+3)
                 {
                     const __amdgpu_buffer_rsrc_t rs0 = poll_rsrc((loc0 ? XML_ : XM_) + ((int64_t)(l * B + s) * P) * PIPE_XG, P * PIPE_XG * 16);
@@ -372,9 +533,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         if (p0 < nprod) {
                             const bool two = p1 < nprod;
                             const int o0 = (p0 * PIPE_XG + g) * 16, o1 = two ? (p1 * PIPE_XG + g) * 16 : o0;
-                            u32x4 g0, g1;
+                            u32x4 g0 = xp0, g1 = xp1;
+                            bool have = false;
+                            if (xp_have && g == lane) have = __all(g0.w == want && g1.w == want) != 0;      // requested during the previous stream's iteration
                             int spins = 0;
-                            for (;;) {          // ONE poll in flight: more concurrent polls measurably slow every hop (fabric contention)
+                            while (!have) {     // ONE poll in flight: more concurrent polls measurably slow every hop (fabric contention)
                                 g0 = poll_ld(rs0, o0); g1 = poll_ld(two ? rs1 : rs0, o1);
                                 if (__all(g0.w == want && g1.w == want)) break;
                                 if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 100 + l); break; }
@@ -412,14 +575,15 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     zt += dpp_f<DPP_XOR2>(zt); zs += dpp_f<DPP_XOR2>(zs);
                     zt += dpp_f<DPP_HALF_MIRROR>(zt); zs += dpp_f<DPP_HALF_MIRROR>(zs);
                     if (k8 == 0) {
-                        zt += zpast[s * 64 + zrow_t]; zs += zpast[s * 64 + zrow_s];
+                        zt += zpast[s * PIPE_ZS + zrow_t]; zs += zpast[s * PIPE_ZS + zrow_s];
                         const float e = __expf(2.0f * zt);
                         ucur[8 * wave + pr] = f2n<H>((1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f)) * __builtin_amdgcn_rcpf(1.0f + __expf(-zs)));
                     }
                     lds_barrier();                                                                 // (B) the 32 gate outputs of this CU
                     PIPE_SVC(3);
                     // ---- 3. partial of x_{l+1}(t) = rho (W_out[:, mine] u_mine [+ x + b on CU 0]) -> granules (modules.py:512-521)
-                    if (!top) {
+                    // (the top layer multiplies too and publishes nothing: both copies disabled -- the same instruction stream for every CU)
+                    {
                         float o = 0.0f, o2 = 0.0f;
                         o = dot8n<H>(wor[0], *reinterpret_cast<const uint4*>(ucur), o); o2 = dot8n<H>(wor[1], *reinterpret_cast<const uint4*>(ucur + 8), o2);
                         o = dot8n<H>(wor[2], *reinterpret_cast<const uint4*>(ucur + 16), o); o2 = dot8n<H>(wor[3], *reinterpret_cast<const uint4*>(ucur + 24), o2);
@@ -428,11 +592,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                         const uint32_t me = f2n<H>(o * a.rho);
                         const uint32_t n1 = dpp_u<DPP_QUAD_BCAST(1)>(me), n2 = dpp_u<DPP_QUAD_BCAST(2)>(me), n3 = dpp_u<DPP_QUAD_BCAST(3)>(me);
                         if (trace_on && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
-                        if ((lane & 3) == 0) {
-                            u32x4 g = {me | (n1 << 16), n2 | (n3 << 16), 0, want};
-                            const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + (tid >> 2);
-                            st_g16_local(XML_ + gi, g); st_g16(XM_ + gi, g);
-                        }
+                        const u32x4 g = {me | (n1 << 16), n2 | (n3 << 16), 0, want};
+                        const int64_t gb = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG;              // (layer L's slots exist and nobody reads them)
+                        const int off = (lane & 3) == 0 ? (tid >> 2) * 16 : -1;
+                        st_buf16(poll_rsrc(XML_ + gb, PIPE_XG * 16), xpub_loc ? off : -1, g);
+                        st_buf16_wt(poll_rsrc(XM_ + gb, PIPE_XG * 16), xpub_rem ? off : -1, g);
                     }
                     if (tid < R) xcur_f[tid] = n2f<H>(myx[tid]);
                 } else {
@@ -448,8 +612,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     }
                     lds_barrier();
                     if (tid < 32) {
-                        const float za = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zpast[s * 64 + tid];
-                        const float zs = zpart[32 + tid] + zpart[96 + tid] + zpart[160 + tid] + zpart[224 + tid] + zpast[s * 64 + 32 + tid];
+                        const float za = zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid] + zpast[s * PIPE_ZS + tid];
+                        const float zs = zpart[32 + tid] + zpart[96 + tid] + zpart[160 + tid] + zpart[224 + tid] + zpast[s * PIPE_ZS + 32 + tid];
                         const float e = __expf(2.0f * za);
                         ucur[tid] = f2n<H>((1.0f - 2.0f / (e + 1.0f)) * (1.0f / (1.0f + __expf(-zs))));
                     }
@@ -466,12 +630,14 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                             const uint2 q = *reinterpret_cast<const uint2*>(outp + g * 4);
                             u32x4 gr = {q.x, q.y, 0, want};
                             const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_XG + g;
-                            st_g16_local(XML_ + gi, gr); st_g16(XM_ + gi, gr);
+                            if (xpub_loc) st_g16_local(XML_ + gi, gr);
+                            if (xpub_rem) st_g16(XM_ + gi, gr);
                         }
                     }
                 }
+                x_request(s, t);
                 PIPE_SVC(4);
-                lds_barrier();
+                if (!fast) lds_barrier();            // (the granules of the slow path pass through outp; the fast path shares nothing here: ucur is rewritten behind barrier A)
                 PIPE_SVC(5);
                 if (trace_on && (!fast || top) && s == 0 && j == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * l + 1] = wall_clock64();
                 if (t + 1 < T) pre_issue(s, t + 1, d == 1);          // wave 3: ring reads of this stream's NEXT sample, consumed in step 5
@@ -479,48 +645,87 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 {
                     // own contribution first (the running sum of CU (l-1, j) is published ~1 us after its x partial: no point in
                     // polling early, and every useless poll slows somebody's critical hop)
-                    for (int r = tid; r < S; r += PIPE_THREADS) skp[r] = mv_rows<H>(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
-                    if (tid < 4) skp[S + tid] = 0.0f;
-                    lds_barrier();
-                    PIPE_SVC(6);
-                    if (l > 0) {       // one poll per GRANULE (3 channels), by the first (S+2)/3 threads
-                        const __amdgpu_buffer_rsrc_t rs = poll_rsrc((loc_skip ? SML_ : SM_) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
-                        for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
-                            u32x4 g;
+                    // (-- except in runs of many streams, see `many`: requested during the previous stream's iteration)
+                    const __amdgpu_buffer_rsrc_t rs = poll_rsrc((loc_skip ? SML_ : SM_) + ((int64_t)(l * B + s) * P + j) * PIPE_SG, PIPE_SG * 16);
+                    const int64_t gb = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_SG;
+                    if (fast_skip) {
+                        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+                        {
+                            const int r0 = min(3 * sk_g3, S - 1), r1 = min(3 * sk_g3 + 1, S - 1), r2 = min(3 * sk_g3 + 2, S - 1);
+#pragma unroll
+                            for (int kc = 0; kc < 4; ++kc) {
+                                const uint4 u = *reinterpret_cast<const uint4*>(ucur + kc * 8);
+                                a0 = dot8n<H>(*reinterpret_cast<const uint4*>(Ws + ((size_t)kc * S + r0) * 16), u, a0);
+                                a1 = dot8n<H>(*reinterpret_cast<const uint4*>(Ws + ((size_t)kc * S + r1) * 16), u, a1);
+                                a2 = dot8n<H>(*reinterpret_cast<const uint4*>(Ws + ((size_t)kc * S + r2) * 16), u, a2);
+                            }
+                            if (3 * sk_g3 + 1 >= S) a1 = 0.0f;
+                            if (3 * sk_g3 + 2 >= S) a2 = 0.0f;
+                        }
+                        PIPE_SVC(6);
+                        if (l > 0 && sk_en) {
+                            u32x4 g = skcur;
                             int spins = 0;
-                            for (;;) {
-                                g = poll_ld(rs, g3 * 16);
+                            while (!(skp_have && g.w == want)) {
+                                g = poll_ld(rs, sk_g3 * 16);
                                 if (g.w == want) break;
                                 __builtin_amdgcn_s_sleep(2);
                                 if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 200 + l); break; }
                                 if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
                             }
-                            skp[g3 * 3] += __uint_as_float(g.x); skp[g3 * 3 + 1] += __uint_as_float(g.y); skp[g3 * 3 + 2] += __uint_as_float(g.z);
+                            a0 += __uint_as_float(g.x); a1 += __uint_as_float(g.y); a2 += __uint_as_float(g.z);
                         }
-                    }
-                    lds_barrier();
-                    PIPE_SVC(7);
-                    for (int g3 = tid; g3 * 3 < S; g3 += PIPE_THREADS) {
-                        u32x4 g = {__float_as_uint(skp[g3 * 3]), __float_as_uint(skp[g3 * 3 + 1]), __float_as_uint(skp[g3 * 3 + 2]), want};
-                        const int64_t gi = ((int64_t)((l + 1) * B + s) * P + j) * PIPE_SG + g3;
-                        st_g16_local(SML_ + gi, g); st_g16(SM_ + gi, g);
+                        PIPE_SVC(7);
+                        const u32x4 g = {__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), want};
+                        st_buf16(poll_rsrc(SML_ + gb, PIPE_SG * 16), sk_en && spub_loc ? sk_g3 * 16 : -1, g);
+                        st_buf16_wt(poll_rsrc(SM_ + gb, PIPE_SG * 16), sk_en && spub_rem ? sk_g3 * 16 : -1, g);
+                    } else {
+                        for (int r = tid; r < S; r += PIPE_THREADS) skp[r] = mv_rows<H>(Ws, S, r, reinterpret_cast<const char*>(ucur), 0, 4);
+                        if (tid < 4) skp[S + tid] = 0.0f;
+                        lds_barrier();
+                        PIPE_SVC(6);
+                        if (l > 0 && sk_en) {       // one poll per GRANULE (3 channels), by the first (S+2)/3 threads
+                            u32x4 g = skcur;
+                            int spins = 0;
+                            while (!(skp_have && g.w == want)) {
+                                g = poll_ld(rs, sk_g3 * 16);
+                                if (g.w == want) break;
+                                __builtin_amdgcn_s_sleep(2);
+                                if (++spins > PIPE_SPIN_LIMIT) { pipe_abort(abortf, 200 + l); break; }
+                                if ((spins & 255) == 0 && pipe_aborted(abortf)) break;
+                            }
+                            skp[sk_g3 * 3] += __uint_as_float(g.x); skp[sk_g3 * 3 + 1] += __uint_as_float(g.y); skp[sk_g3 * 3 + 2] += __uint_as_float(g.z);
+                        }
+                        lds_barrier();
+                        PIPE_SVC(7);
+                        const u32x4 g = {__float_as_uint(skp[sk_g3 * 3]), __float_as_uint(skp[sk_g3 * 3 + 1]), __float_as_uint(skp[sk_g3 * 3 + 2]), want};
+                        st_buf16(poll_rsrc(SML_ + gb, PIPE_SG * 16), sk_en && spub_loc ? sk_g3 * 16 : -1, g);
+                        st_buf16_wt(poll_rsrc(SM_ + gb, PIPE_SG * 16), sk_en && spub_rem ? sk_g3 * 16 : -1, g);
                     }
                 }
                 PIPE_SVC(8);
                 // ---- 5. queue update (private ring) and the pre-multiplication for this stream's next step
                 {
                     bf16_t* ringb = ring_ + a.ring_off[l] * B + ((int64_t)(j * B + s) * (mask + 1)) * R;
-                    for (int i = tid; i < R / 8; i += PIPE_THREADS)
-                        *reinterpret_cast<uint4*>(ringb + (int64_t)(t & mask) * R + i * 8) = *reinterpret_cast<const uint4*>(xcur_b + i * 8);
+                    {   // (R / 8 <= 48 chunks: the first lanes of wave 0; the other waves issue the same store disabled)
+                        const bool en = tid < R / 8;
+                        st_buf16(poll_rsrc(ringb + (int64_t)(t & mask) * R, R * 2), en ? tid * 16 : -1, __builtin_bit_cast(u32x4, *reinterpret_cast<const uint4*>(xcur_b + (en ? tid * 8 : 0))));
+                    }
                     PIPE_SVC(9);
                     if constexpr (H) {      // half has 5 exponent bits: a residual stream beyond 65504 became inf in the hand-off -- report it, do not synthesise garbage
                         if (tid < R && !(fabsf(xcur_f[tid]) <= 65504.0f)) pipe_abort(abortf, 400 + l);
                     }
-                    if (t + 1 < T) pre_finish(s, t + 1, d == 1);      // ring rows are read past this CU's L1 (sc1): slots are recycled
+                    if (t + 1 < T) { if (BP) pre_stash(s, t + 1, d == 1); else pre_finish(s, t + 1, d == 1); }      // ring rows are read past this CU's L1 (sc1): slots are recycled
                 }
                 PIPE_SVC(10);
-                if (pipe_aborted(abortf)) return;
+                if (a.abort_every && pipe_aborted(abortf)) return;
             }
+            // (once per sample, not per stream unless a.abort_every (WN_PIPE_ABORT_EVERY=1, A/B): the flag is a device-scope load whose wait also drains the early requests above; every spin loop tests it
+            // on its own every 256 polls)
+            if (pipe_aborted(abortf)) return;
+            PIPE_SVC_T(11);
+            if (BP && t + 1 < T) pre_batch(t);                       // z_past of every stream's next sample in one matrix product
+            PIPE_SVC_T(12);
         }
         return;
     }
@@ -546,6 +751,14 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         int* nxt_i = reinterpret_cast<int*>(p); p += 16;
         const int L = a.L, O = a.O, OP = a.OP, mode = a.mode;
         const bool hloc0 = (wave < P) && same_xcc(block_of(L - 1, wave)), hloc1 = (wave + 4 < P) && same_xcc(block_of(L - 1, wave + 4));
+        // which copy of layer 0's mailbox is read?  CU (0, jj) takes the XCD-local one iff EVERY head shares its XCD (loc0 there): the same test, made here
+        bool ipub_loc = false, ipub_rem = false;
+        for (int jj = 0; jj < P; ++jj) {
+            const int cx = xcc_of(block_of(0, jj));
+            bool l0 = true;
+            for (int h = 0; h < NH; ++h) l0 = l0 && xcc_of(btab[L * P + h]) == cx;
+            ipub_loc = ipub_loc || l0; ipub_rem = ipub_rem || !l0;
+        }
         lds_barrier();
         // fast head (S == 256, O <= 32): both head convolutions multiply from REGISTERS (128 + 16 VGPRs of weights per thread)
         const bool hfast = (S == 256 && OP == 32);
@@ -570,17 +783,18 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 const uint2 q = *reinterpret_cast<const uint2*>(outp + g * 4);
                 u32x4 gr = {q.x, q.y, 0, (uint32_t)(tn + 1)};
                 const int64_t gi = ((int64_t)(0 * B + s) * P + 0) * PIPE_XG + g;
-                st_g16_local(XML_ + gi, gr); st_g16(XM_ + gi, gr);
+                if (ipub_loc) st_g16_local(XML_ + gi, gr);
+                if (ipub_rem) st_g16(XM_ + gi, gr);
             }
             lds_barrier();
         };
         if (tid == 0) { nxt_f[0] = 0.0f; nxt_i[0] = a.start_id; }
         lds_barrier();
-        for (int s = 0; s < B; ++s) publish_input(s, 0);
+        for (int s = j; s < B; s += NH) publish_input(s, 0);          // head j of NH: the streams s = j (mod NH)
 
         for (int t = 0; t < T; ++t) {
             const uint32_t want = (uint32_t)(t + 1);
-            for (int s = 0; s < B; ++s) {
+            for (int s = j; s < B; s += NH) {
                 // (prefetch, off the critical path) this step's noise and teacher-forcing value
                 float nz_pre = 0.0f, ti_pre = 0.0f;       // nz_pre: lane i < M: -log(-log u1_i) (Gumbel); lane M: log u2 - log(1 - u2) (logistic)
                 if (mode == 0 && wave == 0) {
@@ -698,8 +912,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                 if (trace_on && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 2] = wall_clock64();
                 if (t + 1 < T) publish_input(s, t + 1);
                 if (trace_on && s == 0 && tid == 0 && t >= a.trace_t0 && t < a.trace_t0 + a.trace_n) a.trace[(size_t)(t - a.trace_t0) * 2 * (a.L + 2) + 2 * L + 3] = wall_clock64();
-                if (pipe_aborted(abortf)) return;
             }
+            if (pipe_aborted(abortf)) return;
         }
     }
 }
@@ -731,20 +945,28 @@ struct Pipe {
 // layers per XCD, the head on XCD 0, <= 30 CUs per XCD); several instances share ONE launch of 256 workgroups and are packed XCD by XCD, a layer's P CUs
 // never split.  (One launch PER instance was built first and fails: where a kernel's ids land is only modulo-8 regular WITHIN a launch, so the
 // instances' CU sets collide on some XCD, a launch stays partially resident and its hand-offs time out -- measured, profiles/r7f.)
+// Heads of a single-instance run.  Past ~10 streams a run is bound by the slowest CU's service time per stream, and the head's (wait for the P running
+// skip sums, two convolutions, the sampler, the input convolution of the next step: ~3.2 us) is longer than a layer CU's once that one multiplies its past
+// taps in one batch per sample (profiles/r8a_pipe_svc_trace.txt): streams alternate between PIPE_HEADS head CUs, all on XCD 0 next to layer 0.
+#define PIPE_HEADS 2
+#define PIPE_EARLY_FROM 18         // streams per run from which the early x / skip requests are on (WN_PIPE_EARLY_FROM); measured on the paper model: 14 / 16 streams
+                                   // 30.5 / 34.7 us per sample without, 32.0 / 35.8 with; 20 streams 43.8 without, 42.5 with (profiles/r8h_pipe_batch_scaling_ab.txt)
+static int pipe_heads(int L, int P) { const int spx = (L + 7) / 8; return std::max(1, std::min(PIPE_HEADS, 30 - spx * P)); }
 static bool pipe_layout(int L, int P, int ni, std::vector<int32_t>& role, std::vector<int32_t>& blk, int& grid) {
-    const int per = L * P + 1;
-    blk.assign((size_t)ni * per, -1);
     if (ni == 1) {
-        const int spx = (L + 7) / 8;
-        grid = 8 * (spx * P + 1);
+        const int spx = (L + 7) / 8, nh = pipe_heads(L, P);
+        blk.assign((size_t)L * P + nh, -1);
+        grid = 8 * (spx * P + nh);
         role.assign(grid, -1);
         for (int b = 0; b < grid; ++b) {
             const int xcd = b & 7, slot = b >> 3;
             if (slot < spx * P) { const int layer = spx * xcd + slot / P, j = slot % P; if (layer < L) { role[b] = (layer << 8) | j; blk[layer * P + j] = b; } }
-            else if (xcd == 0) { role[b] = 1 << 23; blk[L * P] = b; }
+            else if (xcd == 0) { const int h = slot - spx * P; role[b] = (1 << 23) | h; blk[L * P + h] = b; }
         }
         return true;
     }
+    const int per = L * P + 1;
+    blk.assign((size_t)ni * per, -1);
     grid = 256; role.assign(grid, -1);           // ONE launch for all instances: every XCD gets exactly 32 ids, any CU of the XCD takes any of them
     int xcd = 0, used = 0;
     auto place = [&](int n) { if (used + n > 32) { ++xcd; used = 0; } const int k = used; used += n; return xcd < 8 ? k : -1; };
@@ -765,7 +987,7 @@ static int pipe_ni_max(int L, int P) {
 }
 // instances a batch of B streams is cut into: runs of <= 8 streams cost the wall time of ONE stream (10: + 5 %, then + 3.6 us per stream)
 static int pipe_instances(int L, int P, int B) {
-    static const int env = [] { const char* e = getenv("WN_PIPE_INSTANCES"); return e ? atoi(e) : 0; }();      // A/B switch: 1 = one run for the whole batch
+    const char* e = getenv("WN_PIPE_INSTANCES"); const int env = e ? atoi(e) : 0;      // A/B switch: 1 = one run for the whole batch
     const int want = env > 0 ? env : (B + 7) / 8;
     return std::max(1, std::min(std::min(want, pipe_ni_max(L, P)), B));
 }
@@ -794,7 +1016,7 @@ bool wn_pipe_eligible(const wn_ctx* c, int B) {
     if (spx * P + 1 > 30) return false;                 // 32 CUs per XCD, keep slack
     const int64_t layer_static = 64LL * R * 2 + 64LL * (2 * R + C) * 2 + 32LL * R * 2 + 32LL * S * 2 + 256 + R * 4;
     const int ni = pipe_instances(L, P, B), Bi = (B + ni - 1) / ni;                  // streams of ONE run (z_past: 256 B of LDS each)
-    const int64_t layer_dyn = R * 2 + R * 4 + 16LL * R + 8LL * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 256LL * Bi + 64;
+    const int64_t layer_dyn = R * 2 + R * 4 + 16LL * R + 8LL * R + 1024 + 64 + (R + 16) * 2 + (S + 4) * 4 + (2 * R + C) * 2 + 4LL * PIPE_ZS * Bi + 64;
     const int64_t head_static = (int64_t)S * S * 2 + (int64_t)c->OP * S * 2 + S * 4 * 2 + c->OP * 4 + R * 8 + 64;
     const int64_t head_dyn = 16LL * (S + 4) + S * 4 + c->OP * 4 + (R + 16) * 2 + 64;
     return layer_static + layer_dyn <= 160 * 1024 && head_static + head_dyn <= 160 * 1024;
@@ -803,7 +1025,7 @@ bool wn_pipe_eligible(const wn_ctx* c, int B) {
 static int pipe_build(wn_ctx* c, Pipe* p) {
     const int L = c->L, R = c->R, G = c->G, GH = c->GH, S = c->S, C = c->C, O = c->O, OP = c->OP;
     const int P = GH / 32;
-    p->P = P; p->spx = (L + 7) / 8; p->grid = 8 * (p->spx * P + 1);
+    p->P = P; p->spx = (L + 7) / 8; p->grid = 8 * (p->spx * P + pipe_heads(L, P));
     PipeArgs& a = p->proto; memset(&a, 0, sizeof a);
     auto al = [](int64_t x) { return (x + 255) / 256 * 256; };
     int64_t o = 0;
@@ -1002,13 +1224,19 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     a.cbt = c->cbt; a.noise = noise; a.test_inputs = test_inputs; a.out_samples = out_samples; a.out_raw = out_raw;
     a.win_global = c->params_dev + c->first.dil_k; a.bin_global = c->params_dev + c->first.dil_b;
     unsigned long long* trace_dev = nullptr; const int trace_n = 32;
-    if (getenv("WN_PIPE_TRACE") && T > 600) {
+#ifdef WN_PIPE_SVC_BUILD
+    const bool want_trace = getenv("WN_PIPE_TRACE") != nullptr, want_svc = getenv("WN_PIPE_SVC_TRACE") != nullptr;
+#else
+    const bool want_trace = false, want_svc = false;      // (the stamp sites exist in the diagnostic build only: csrc/build.py --pipe-svc)
+    if (getenv("WN_PIPE_TRACE") || getenv("WN_PIPE_SVC_TRACE")) { static bool told = false; if (!told) { told = true; fprintf(stderr, "[pipe] WN_PIPE_TRACE / WN_PIPE_SVC_TRACE need the diagnostic build (python tacotron-2_amd/csrc/build.py --pipe-svc)\n"); } }
+#endif
+    if (want_trace && T > 600) {
         WN_HIP(c, hipMalloc((void**)&trace_dev, (size_t)trace_n * 2 * (L + 2) * 8));
         WN_HIP(c, hipMemsetAsync(trace_dev, 0, (size_t)trace_n * 2 * (L + 2) * 8, st));
         a.trace = trace_dev; a.trace_t0 = 500; a.trace_n = trace_n;
     }
     unsigned long long* svc_dev = nullptr;
-    if (getenv("WN_PIPE_SVC_TRACE") && T > 600) {
+    if (want_svc && T > 600) {
         WN_HIP(c, hipMalloc((void**)&svc_dev, (size_t)trace_n * 16 * 8));
         WN_HIP(c, hipMemsetAsync(svc_dev, 0, (size_t)trace_n * 16 * 8, st));
         a.svc = svc_dev; a.svc_l = L / 2; a.svc_s = B / 2; a.trace_t0 = 500; a.trace_n = trace_n;
@@ -1018,14 +1246,28 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
     const int ni = pipe_instances(L, P, B);
     const int per = L * P + 1, grid = p->grid_ni[ni];
     const int Bmax = (B + ni - 1) / ni;
-    const int lds_bytes = std::max(p->layer_lds + 256 * Bmax, p->head_lds);      // z_past [iB][64] fp32 per layer CU (wn_pipe_eligible checked that it fits)
-    a.ninst = ni; a.ring_unit = 0;
+    const int lds_bytes = std::max(p->layer_lds + 4 * PIPE_ZS * Bmax, p->head_lds);      // z_past [iB][64] fp32 per layer CU (wn_pipe_eligible checked that it fits)
+    a.ninst = ni; a.ring_unit = 0; a.NH = ni == 1 ? pipe_heads(L, P) : 1;
+    { const char* e = getenv("WN_PIPE_EARLY_FROM"); a.early_from = e ? atoi(e) : PIPE_EARLY_FROM; }
+    { const char* e = getenv("WN_PIPE_ABORT_EVERY"); a.abort_every = e ? atoi(e) : 0; }
     for (int l = 0; l < L; ++l) { a.ring_off[l] = a.ring_unit; a.ring_unit += (int64_t)P * (a.ring_mask[l] + 1) * R; }      // per STREAM: the kernel multiplies by its instance's stream count
     for (int i = 0, s0 = 0; i < ni; ++i) { a.iB[i] = B / ni + (i < B % ni ? 1 : 0); a.is0[i] = s0; s0 += a.iB[i]; }
     a.role_tab = p->tabs_dev[ni]; a.block_tab = a.role_tab + grid;
     (void)per;
     {
-        void (*kern)(const PipeArgs) = ni > 1 ? (p->f16 ? wn_synth_pipe_kernel<1, 1> : wn_synth_pipe_kernel<0, 1>) : (p->f16 ? wn_synth_pipe_kernel<1, 0> : wn_synth_pipe_kernel<0, 0>);
+        // batched pre-multiplication: fast-path models (R = 256: the parked vectors take the place of the register-resident tap-2 image) up to the
+        // number of vectors that image holds; WN_PIPE_BATCHPRE=0: the per-stream pre-multiplication of rounds 2-4 (A/B switch)
+        const char* bpe = getenv("WN_PIPE_BATCHPRE"); const bool bp_env = !bpe || atoi(bpe) != 0;
+        const int kpad = ((2 * R + c->C) / 8 + 15) / 16 * 16, vstr = ((kpad + 13) / 16 * 16 + 2) * 16;
+        const bool bp = bp_env && R == 256 && Bmax <= 32 && (int64_t)Bmax * vstr <= 64LL * R * 2;
+        typedef void (*kern_t)(const PipeArgs);
+        const char* spe = getenv("WN_PIPE_SPEC");
+        const bool spec = (!spe || atoi(spe) != 0) && R == 256 && c->S == 256 && P == 8;
+#define PK(h, m, b) {wn_synth_pipe_kernel<h, m, b, 0>, wn_synth_pipe_kernel<h, m, b, 1>}
+        static const kern_t kerns[2][2][2][2] = {{{PK(0, 0, 0), PK(0, 0, 1)}, {PK(0, 1, 0), PK(0, 1, 1)}}, {{PK(1, 0, 0), PK(1, 0, 1)}, {PK(1, 1, 0), PK(1, 1, 1)}}};
+#undef PK
+        kern_t kern = kerns[p->f16 ? 1 : 0][ni > 1 ? 1 : 0][bp ? 1 : 0][spec ? 1 : 0];
+        c->synth_batchpre = bp ? 1 : 0;
         WN_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     }
@@ -1048,7 +1290,12 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         for (int i = 0; i < trace_n; ++i) { const unsigned long long* r = &h[(size_t)i * 16]; if (!r[0] || !r[10]) continue; ++n; for (int k = 0; k < 10; ++k) d[k] += (double)(r[k + 1] - r[k]); tot += (double)(r[10] - r[0]); }
         fprintf(stderr, "[pipe svc] layer %d CU 0, stream %d of %d: %.2f us per stream iteration (mean of %d):", L / 2, B / 2, B, n ? tot / n / 100.0 : 0.0, n);
         for (int k = 0; k < 10; ++k) fprintf(stderr, " | %s %.2f", nm[k], n ? d[k] / n / 100.0 : 0.0);
-        fprintf(stderr, "\n");
+        double bt = 0; int bn = 0;
+        for (int i = 0; i < trace_n; ++i) { const unsigned long long* r = &h[(size_t)i * 16]; if (r[11] && r[12]) { bt += (double)(r[12] - r[11]); ++bn; } }
+        double b1 = 0, b2 = 0, b3 = 0;
+        for (int i = 0; i < trace_n; ++i) { const unsigned long long* r = &h[(size_t)i * 16]; if (r[11] && r[12] && r[13] && r[14]) { b1 += (double)(r[13] - r[11]); b2 += (double)(r[14] - r[13]); b3 += (double)(r[12] - r[14]); } }
+        fprintf(stderr, " || once per sample: batched pre-multiplication %.2f (%s) = wait for the parked vectors %.2f + matrix product %.2f + z_past store and barrier %.2f\n", bn ? bt / bn / 100.0 : 0.0,
+                c->synth_batchpre ? "on" : "off", bn ? b1 / bn / 100.0 : 0.0, bn ? b2 / bn / 100.0 : 0.0, bn ? b3 / bn / 100.0 : 0.0);
     }
     if (trace_dev) {      // per-stage latencies in units of the 100 MHz real-time counter (10 ns)   [diagnostic mode: synchronises]
         WN_HIP(c, hipStreamSynchronize(st));

@@ -100,6 +100,7 @@ def load_library():
         'wn_test_gemm8p_mask': (ctypes.c_int, [vp]),
         'wn_synth_pipe_dtype': (ctypes.c_int, [vp, i32]),
         'wn_synth_last_instances': (ctypes.c_int, [vp]),
+        'wn_synth_last_batched': (ctypes.c_int, [vp]),
         'wn_synth_pipe_eligible': (ctypes.c_int, [vp, i32]),
         'wn_sample': (ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         'wn_mulaw': (ctypes.c_int, [vp, vp, i64, vp]),

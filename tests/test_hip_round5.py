@@ -170,3 +170,40 @@ def test_pipeline_instances_serve_the_default_synthesis_batch_side_by_side():
     torch.cuda.synchronize(); eng.synth_check()
     assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_instances(eng.h) == 3 and torch.isfinite(out).all()
     eng.close()
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(gin_channels=16, use_speaker_embedding=True, n_speakers=4)])
+def test_pipe_batched_premultiplication_matches_the_per_stream_form_and_the_oracle(kw):
+    """VERDICT round 4, item 4 (several streams per iteration): on R = 256 models a layer CU no longer multiplies the past taps and the conditioning of
+    a stream's next sample per stream (one 64 x (2R + C) matvec and three workgroup barriers each: 1.3 of its 3.7 us per stream); wave 3 parks the
+    vectors and ONE [64 x K] x [K x streams] product per sample on the matrix cores serves all streams (wn_synth_pipe.hip pre_batch).  Same
+    arithmetic up to the order of the fp32 sums: every stream against the FP32 oracle in both forms, the two forms against each other, the layer bias
+    and the per-stream gate bias of global conditioning, dilation-1 layers (their tap t-d is the sample in flight), 1 / 5 / 17 / 20 / 24 streams
+    (one and two 16-stream tiles, ragged), and 25 streams = more vectors than the freed tap-2 image holds: the per-stream form runs."""
+    width = dict(residual_channels=256, gate_channels=512, skip_out_channels=256, cin_channels=80, num_mels=80)
+    for B in (1, 5, 17, 20, 24, 25):
+        hp, cfg, eng, params, wav, c, T = _setup(B, 6, layers=6, stacks=2, **width, **kw)
+        nz_dev, nz_or = _noise(cfg, T, B)
+        g = None
+        if kw:
+            g = (torch.arange(B) % 4).to(torch.int32)
+            eng.set_global_condition(g.cuda())
+        raws = {}
+        for bp in (1, 0):
+            os.environ['WN_PIPE_BATCHPRE'] = str(bp); os.environ['WN_PIPE_INSTANCES'] = '1'      # (this 6-layer model would fit the chip three times: ONE run here)
+            try:
+                out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, cfg.out_channels, T, device='cuda')
+                eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, wav.contiguous().cuda(), steps_per_graph=0)
+                torch.cuda.synchronize(); eng.synth_check()
+            finally:
+                os.environ.pop('WN_PIPE_BATCHPRE', None); os.environ.pop('WN_PIPE_INSTANCES', None)
+            assert eng.lib.wn_synth_last_instances(eng.h) == 1
+            assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_batched(eng.h) == (1 if bp and B <= 24 else 0)
+            raws[bp] = raw.cpu()
+        with torch.no_grad():
+            _, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=wav.unsqueeze(-1), formulation='ring', **({'g': g} if kw else {}))
+        per = {bp: max(rel_err(raws[bp][b], r_or[b]) for b in range(B)) for bp in (1, 0)}
+        both = max(rel_err(raws[1][b], raws[0][b]) for b in range(B))
+        print('\n%d streams%s: batched %.2e / per-stream %.2e vs the FP32 oracle; batched vs per-stream %.2e' % (B, ' + global conditioning' if kw else '', per[1], per[0], both))
+        assert per[1] < 4e-3 and per[0] < 4e-3 and both < 2e-3
+        eng.close()

@@ -73,7 +73,8 @@ for st in "$@"; do
       cd $R; tail -40 $OUT/gemm_harness.txt ;;
     chain) cd /tmp; [ -x $R/tools/chain_harness ] && timeout 90 $R/tools/chain_harness > $OUT/chain_harness.txt 2>&1; cd $R; tail -16 $OUT/chain_harness.txt ;;
     chaindbg:*) cd /tmp; for f in $(echo ${st#chaindbg:} | tr ',' ' '); do timeout 60 $R/tools/chain_harness $f 2>&1 | grep -v "^    wg" | head -30 > $OUT/chain_dbg_$f.txt; echo "== flags $f"; head -12 $OUT/chain_dbg_$f.txt; done; cd $R ;;
-    pipetrace) for b in 1 8; do WN_PIPE_TRACE=1 timeout 200 python tools/pipe_trace.py $b > $OUT/pipe_trace_b$b.txt 2>&1; tail -4 $OUT/pipe_trace_b$b.txt; done ;;
+    pipetrace) python tacotron-2_amd/csrc/build.py --pipe-svc > /dev/null 2>&1      # (the stamp sites are a diagnostic build; the box is discarded after the session)
+      for b in 1 8; do WN_PIPE_TRACE=1 timeout 200 python tools/pipe_trace.py $b > $OUT/pipe_trace_b$b.txt 2>&1; tail -4 $OUT/pipe_trace_b$b.txt; done ;;
     other) timeout 900 python - > $OUT/other_workloads.json 2> $OUT/other.err <<'PY'
 import json, sys, os
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))

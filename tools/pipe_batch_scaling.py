@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-sample time of the persistent synthesis pipeline against the number of streams in ONE run (wavenet.py:237-239 splits a batch
 over towers; here the streams of a run follow each other through the layer ring): up to which batch does a run cost the wall time of
-one stream, and what does hparams.py's wavenet_synthesis_batch_size = 20 cost?   python tools/pipe_batch_scaling.py [seconds]"""
+one stream, and what does hparams.py's wavenet_synthesis_batch_size = 20 cost?   python tools/pipe_batch_scaling.py [seconds [workload[,workload] [B,B,...]]]"""
 import json
 import os
 import sys
@@ -22,13 +22,15 @@ def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     dev = torch.device('cuda', 0)
     out = {}
-    for key in ('default_hparams', 'c2'):
+    keys = sys.argv[2].split(',') if len(sys.argv) > 2 else ('default_hparams', 'c2')
+    Bs = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (1, 4, 8, 10, 12, 16, 20, 24, 32)
+    for key in keys:
         hp, _, _ = bench.build_hparams(key)
         hop = int(np.prod(hp.upsample_scales))
         Tc = max(2, int(round(secs * hp.sample_rate / hop))); T = Tc * hop
         rows = {}
         flat = None
-        for B in (1, 4, 8, 10, 12, 16, 20, 24, 32):
+        for B in Bs:
             eng = _ext.Engine(hp, B, T, inference_only=True)
             if flat is None:
                 flat = initialize_parameters(hp, eng.layout).to(dev)
@@ -52,11 +54,11 @@ def main():
             except Exception as e:      # noqa: BLE001
                 print('%s B=%d: %s' % (key, B, e), file=sys.stderr, flush=True)
                 rows[B] = None; eng.close(); continue
-            rows[B] = {'instances': int(eng.lib.wn_synth_last_instances(eng.h)), 'us_per_step': dt / T * 1e6, 'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt, 'finite': bool(torch.isfinite(samples).all())}
+            rows[B] = {'instances': int(eng.lib.wn_synth_last_instances(eng.h)), 'batched_premultiplication': int(eng.lib.wn_synth_last_batched(eng.h)), 'us_per_step': dt / T * 1e6, 'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt, 'finite': bool(torch.isfinite(samples).all())}
             eng.close()
         out[key] = rows
         print(key, {b: (r and (r['instances'], round(r['us_per_step'], 1))) for b, r in rows.items()}, file=sys.stderr, flush=True)
-        base = rows[8]['us_per_step']
+        base = rows[min(Bs, key=lambda b: abs(b - 8))]['us_per_step']
         print('%s (R = %d, %d layers): ' % (key, hp.residual_channels, hp.layers) + '  '.join('B=%d: %.1f us (%.2fx)' % (b, r['us_per_step'], r['us_per_step'] / base) if r else 'B=%d: -' % b for b, r in rows.items()))
     print(json.dumps(out))
 
