@@ -288,6 +288,8 @@ def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8), 
             wbytes = 2.0 * sum(int(np.prod(sh)) for sh, _ in eng.layout.values())     # bf16 weights every stream-step multiplies
             out['%s_B%d' % (mode, B)] = {'seconds_of_audio_per_stream': T / hp.sample_rate, 'wall_s': dt, 'path': eng.synth_path,
                                         'instances': int(eng.lib.wn_synth_last_instances(eng.h)), 'pipeline_storage': os.environ.get('WN_PIPE_DTYPE', 'fp16'),
+                                        # 1: the layer CUs multiply every stream's past taps / conditioning in ONE matrix product per sample (R = 256 models, <= 24 streams per run)
+                                        'batched_premultiplication': int(eng.lib.wn_synth_last_batched(eng.h)), 'real_time': bool(dt / T * 1e6 <= 1e6 / hp.sample_rate),
                                         'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt,
                                         'us_per_step': dt / T * 1e6, 'deadline_us': 1e6 / hp.sample_rate,
                                         # synthesis roofline: latency-bound; the bandwidth that matters is the weight re-read rate,
@@ -363,7 +365,7 @@ def measure_other_workload(key, device, steps=10, warmup=3):
         # three pipeline instances of 7 + 7 + 6 streams side by side in one launch; 2 s of audio per stream
         try:
             syn = measure_synthesis(hp, flat, device, seconds=2.0, batches=(8,), modes=('pipe',))      # (+ wavenet_synthesis_batch_size = 20)
-            out['synthesis_pipeline'] = {k: {kk: v.get(kk) for kk in ('rtf_per_stream', 'us_per_step', 'deadline_us', 'path', 'instances', 'seconds_of_audio_per_stream', 'aggregate_samples_per_s')} for k, v in syn.items()}
+            out['synthesis_pipeline'] = {k: {kk: v.get(kk) for kk in ('rtf_per_stream', 'us_per_step', 'deadline_us', 'real_time', 'path', 'instances', 'batched_premultiplication', 'seconds_of_audio_per_stream', 'aggregate_samples_per_s')} for k, v in syn.items()}
         except Exception as e:
             out['synthesis_pipeline'] = {'error': str(e)[:200]}
     del flat, grads, m, v, ema

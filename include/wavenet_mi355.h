@@ -207,10 +207,10 @@ int wn_synth_check(wn_ctx* ctx);
 int wn_synth_last_path(const wn_ctx* ctx);
 /* 1 if wn_synthesize(steps_per_graph <= 0) would run B streams of this model on the persistent pipeline (all of a CU's weights must
  * fit its 160 KiB of LDS next to 256 B of state per stream: one CU per 32 gate pairs, <= 8 CUs per layer, R, S <= 384, B <= 32), 0 if
- * it would take the launch-per-layer hipGraph path.  Host helper: a caller sends the whole batch in one run when this says 1 for it
- * (a run of <= 8 streams costs the wall time of one -- 32 - 35 us per sample --, every stream beyond 10 adds ~3.6 us: real time at 22.05 kHz up
- * to 12 streams per run; a model whose CUs fit the chip more than once is cut into several runs side by side in the same launch,
- * wn_synth_last_instances: hparams.py's default model serves 24 streams at 32 us per sample), else groups of 8. */
+ * it would take the launch-per-layer hipGraph path.  Host helper: a caller sends the whole batch in one run when this says 1 for it.
+ * Per generated sample on the paper model (R = S = 256, 24 layers; deadline 45.35 us at 22.05 kHz): 28 us for 1 ... 12 streams, ~1.7 us per
+ * stream beyond -- 16: 36 us, 20: 42.5 us (real time), 24: 49 us; a model whose CUs fit the chip more than once is cut into several runs side by
+ * side in the same launch (wn_synth_last_instances: hparams.py's default model serves 24 streams at 32 us per sample). */
 int wn_synth_pipe_eligible(const wn_ctx* ctx, int32_t B);
 /* 16-bit storage type of the persistent pipeline's weights, hand-off granules and ring queues for the NEXT runs of this context
  * (fp32 accumulation either way): 1 = IEEE half (the default: raw outputs 1.2e-3 from the reference's fp32 loop at C4's model, 34.8 us per
