@@ -210,7 +210,7 @@ int wn_synth_last_path(const wn_ctx* ctx);
  * it would take the launch-per-layer hipGraph path.  Host helper: a caller sends the whole batch in one run when this says 1 for it.
  * Per generated sample on the paper model (R = S = 256, 24 layers; deadline 45.35 us at 22.05 kHz): 28 us for 1 ... 12 streams, ~1.7 us per
  * stream beyond -- 16: 36 us, 20: 42.5 us (real time), 24: 49 us; a model whose CUs fit the chip more than once is cut into several runs side by
- * side in the same launch (wn_synth_last_instances: hparams.py's default model serves 24 streams at 32 us per sample). */
+ * side in the same launch (wn_synth_last_instances: hparams.py's default model serves 20 streams at 26 us per sample). */
 int wn_synth_pipe_eligible(const wn_ctx* ctx, int32_t B);
 /* 16-bit storage type of the persistent pipeline's weights, hand-off granules and ring queues for the NEXT runs of this context
  * (fp32 accumulation either way): 1 = IEEE half (the default: raw outputs 1.2e-3 from the reference's fp32 loop at C4's model, 34.8 us per

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
     // SPEC: the paper model's widths as compile-time constants (R = S = 256, 8 CUs per layer).  A layer CU runs ONE wave per SIMD, so its service time per stream
     // is an instruction count (~5 cycles per issued instruction): with the widths known the slow-path code, the granule loops, most exec masking and the
     // address multiplications disappear from the stream iteration.
-    const int R = SPEC ? 256 : a.R, S = SPEC ? 256 : a.S, P = SPEC ? 8 : a.P, T = a.T, C = a.C;
+    // (SPEC 2: hparams.py's own widths, R = S = 128 with 4 CUs per layer -- the generic code path, minus its loops and multiplications)
+    const int R = SPEC == 1 ? 256 : SPEC == 2 ? 128 : a.R, S = SPEC == 1 ? 256 : SPEC == 2 ? 128 : a.S, P = SPEC == 1 ? 8 : SPEC == 2 ? 4 : a.P, T = a.T, C = a.C;
     // ---- role (host-built table: consecutive layers share an XCD -- block b runs on XCD b % 8 --; one instance: spx layers per XCD, the head on XCD 0)
     const int32_t role = a.role_tab[blockIdx.x];
     if (role < 0) return;
@@ -1262,11 +1263,11 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         const bool bp = bp_env && R == 256 && Bmax <= 32 && (int64_t)Bmax * vstr <= 64LL * R * 2;
         typedef void (*kern_t)(const PipeArgs);
         const char* spe = getenv("WN_PIPE_SPEC");
-        const bool spec = (!spe || atoi(spe) != 0) && R == 256 && c->S == 256 && P == 8;
-#define PK(h, m, b) {wn_synth_pipe_kernel<h, m, b, 0>, wn_synth_pipe_kernel<h, m, b, 1>}
-        static const kern_t kerns[2][2][2][2] = {{{PK(0, 0, 0), PK(0, 0, 1)}, {PK(0, 1, 0), PK(0, 1, 1)}}, {{PK(1, 0, 0), PK(1, 0, 1)}, {PK(1, 1, 0), PK(1, 1, 1)}}};
+        const int spec = (spe && atoi(spe) == 0) ? 0 : (R == 256 && c->S == 256 && P == 8) ? 1 : (R == 128 && c->S == 128 && P == 4) ? 2 : 0;
+#define PK(h, m, b) {wn_synth_pipe_kernel<h, m, b, 0>, wn_synth_pipe_kernel<h, m, b, 1>, wn_synth_pipe_kernel<h, m, b, 2>}
+        static const kern_t kerns[2][2][2][3] = {{{PK(0, 0, 0), PK(0, 0, 1)}, {PK(0, 1, 0), PK(0, 1, 1)}}, {{PK(1, 0, 0), PK(1, 0, 1)}, {PK(1, 1, 0), PK(1, 1, 1)}}};
 #undef PK
-        kern_t kern = kerns[p->f16 ? 1 : 0][ni > 1 ? 1 : 0][bp ? 1 : 0][spec ? 1 : 0];
+        kern_t kern = kerns[p->f16 ? 1 : 0][ni > 1 ? 1 : 0][bp ? 1 : 0][spec];
         c->synth_batchpre = bp ? 1 : 0;
         WN_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PIPE_THREADS), lds_bytes, st, a);

@@ -200,6 +200,15 @@ def test_pipe_batched_premultiplication_matches_the_per_stream_form_and_the_orac
             assert eng.lib.wn_synth_last_instances(eng.h) == 1
             assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_batched(eng.h) == (1 if bp and B <= 24 else 0)
             raws[bp] = raw.cpu()
+            if bp and B in (5, 20):      # the kernel with these widths as compile-time constants (what ran above) against the generic one: the same bits
+                os.environ['WN_PIPE_SPEC'] = '0'; os.environ['WN_PIPE_INSTANCES'] = '1'
+                try:
+                    raw0 = torch.empty_like(raw)
+                    eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw0, wav.contiguous().cuda(), steps_per_graph=0)
+                    torch.cuda.synchronize(); eng.synth_check()
+                finally:
+                    os.environ.pop('WN_PIPE_SPEC', None); os.environ.pop('WN_PIPE_INSTANCES', None)
+                assert torch.equal(raw0.cpu(), raws[bp])
         with torch.no_grad():
             _, r_or = O.incremental(params, cfg, c, noise=nz_or, test_inputs=wav.unsqueeze(-1), formulation='ring', **({'g': g} if kw else {}))
         per = {bp: max(rel_err(raws[bp][b], r_or[b]) for b in range(B)) for bp in (1, 0)}
@@ -207,3 +216,37 @@ def test_pipe_batched_premultiplication_matches_the_per_stream_form_and_the_orac
         print('\n%d streams%s: batched %.2e / per-stream %.2e vs the FP32 oracle; batched vs per-stream %.2e' % (B, ' + global conditioning' if kw else '', per[1], per[0], both))
         assert per[1] < 4e-3 and per[0] < 4e-3 and both < 2e-3
         eng.close()
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(out_channels=2, legacy=True, residual_legacy=True, upsample_type='SubPixel'),
+                                dict(gin_channels=16, use_speaker_embedding=True, n_speakers=4, layers=6, stacks=2)])
+def test_pipe_kernel_specialised_for_the_default_model_widths(kw):
+    """hparams.py's own widths (R = S = 128, gate 256: 4 CUs per layer) run the pipeline kernel that has them as compile-time constants (SPEC 2 in
+    wn_synth_pipe.hip: a layer CU's time per stream is an instruction count; 32.7 -> 27.5 us per sample on the 20-layer model).  The
+    parity tests of the generic kernel at those widths -- MoL, Gaussian / legacy, per-stream gate bias -- and the generic kernel itself (WN_PIPE_SPEC=0)
+    on the same inputs: the two must agree to the last bit (same code, constants folded)."""
+    import test_hip_round3 as T3
+    import test_hip_synth_pipe as TP
+    width = dict(residual_channels=128, gate_channels=256, skip_out_channels=128)
+    if 'gin_channels' in kw:
+        T3.test_pipe_global_conditioning_matches_oracle(dict(width, **kw))
+    else:
+        TP.test_pipe_teacher_forced_matches_oracle(dict(width, **kw))
+    B, Tc = 3, 6
+    hp, cfg, eng, params, wav, c, T = _setup(B, Tc, **dict(width, **kw))
+    nz_dev, _ = _noise(cfg, T, B)
+    if 'gin_channels' in kw:
+        eng.set_global_condition(torch.tensor([0, 3, 1], dtype=torch.int32).cuda())
+    raws = []
+    for spec in ('1', '0'):
+        os.environ['WN_PIPE_SPEC'] = spec
+        try:
+            out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, cfg.out_channels, T, device='cuda')
+            eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, wav.contiguous().cuda(), steps_per_graph=0)
+            torch.cuda.synchronize(); eng.synth_check()
+        finally:
+            os.environ.pop('WN_PIPE_SPEC', None)
+        assert eng.synth_path == 'pipeline'
+        raws.append(raw.cpu())
+    assert torch.equal(raws[0], raws[1])
+    eng.close()
