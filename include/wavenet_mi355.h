@@ -278,6 +278,11 @@ int wn_test_dropout_mask(uint64_t seed, int32_t layer, float p, int64_t first, i
 /* which launches of this context take the 8-phase kernel (csrc/wn_tile8p.h; WN_GEMM8P in the environment of wn_create -- an A/B switch,
  * default 0): bit 0 = the gate GEMM, bit 1 = d x.  A model that does not fit the kernel reports 0 whatever the switch says. */
 int wn_test_gemm8p_mask(const wn_ctx* ctx);
+/* the workgroup tables of the persistent synthesis pipeline for a model of L layers x P CUs per layer cut into ni instances (host logic only: no
+ * context, no GPU): role[b] of workgroup b = layer << 8 | j, bit 23: a head (j = its index), bits 24-25: instance, -1: none; blk = the inverse
+ * (ni = 1: [L * P + heads]; else ni x [L * P + 1]).  Block b runs on XCD b % 8: a layer's P CUs share an XCD, consecutive layers stay together.
+ * Returns how many instances of the model the chip holds (1 ... 3), WN_E_SHAPE if ni do not fit. */
+int wn_test_pipe_layout(int32_t L, int32_t P, int32_t ni, int32_t* role, int32_t cap_role, int32_t* blk, int32_t cap_blk, int32_t* grid, int32_t* heads);
 #endif /* WN_NO_TEST_HOOKS */
 
 #ifdef __cplusplus

@@ -994,6 +994,20 @@ static int pipe_instances(int L, int P, int B) {
 }
 
 
+// test hook (no context, no GPU): the role / block tables the persistent pipeline would launch with for a model of L layers and P CUs per layer cut into
+// ni instances.  role [grid], blk [ni == 1 ? L * P + heads : ni * (L * P + 1)]; returns the instance count the chip holds (pipe_ni_max) or < 0.
+#ifndef WN_NO_TEST_HOOKS
+extern "C" int wn_test_pipe_layout(int32_t L, int32_t P, int32_t ni, int32_t* role, int32_t cap_role, int32_t* blk, int32_t cap_blk, int32_t* grid, int32_t* heads) {
+    if (L <= 0 || L > 32 || P <= 0 || P > 8 || ni < 1 || ni > PIPE_MAX_INST || !role || !blk || !grid || !heads) return WN_E_ARG;
+    std::vector<int32_t> r, b; int g = 0;
+    if (!pipe_layout(L, P, ni, r, b, g)) return WN_E_SHAPE;
+    if ((int)r.size() > cap_role || (int)b.size() > cap_blk) return WN_E_ARG;
+    std::copy(r.begin(), r.end(), role); std::copy(b.begin(), b.end(), blk);
+    *grid = g; *heads = ni == 1 ? pipe_heads(L, P) : 1;
+    return pipe_ni_max(L, P);
+}
+#endif
+
 void wn_pipe_free(wn_ctx* c) {
     Pipe* p = (Pipe*)c->pipe;
     if (!p) return;

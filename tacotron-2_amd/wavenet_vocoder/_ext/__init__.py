@@ -98,6 +98,7 @@ def load_library():
         'wn_synth_check': (ctypes.c_int, [vp]),
         'wn_synth_last_path': (ctypes.c_int, [vp]),
         'wn_test_gemm8p_mask': (ctypes.c_int, [vp]),
+        'wn_test_pipe_layout': (ctypes.c_int, [i32, i32, i32, vp, i32, vp, i32, vp, vp]),
         'wn_synth_pipe_dtype': (ctypes.c_int, [vp, i32]),
         'wn_synth_last_instances': (ctypes.c_int, [vp]),
         'wn_synth_last_batched': (ctypes.c_int, [vp]),

@@ -1002,3 +1002,62 @@ def test_synthesis_driver_work_list_and_index_file(tmp_path, monkeypatch):
     assert rows[0][0] == 'hello world' and rows[1][3] == '<no_g>' and all(len(r) == 4 for r in rows)
     with pytest.raises(RuntimeError, match='Failed to load checkpoint'):
         S.wavenet_synthesize(types.SimpleNamespace(model='WaveNet', mels_dir=str(d), speaker_id=None, output_dir='o/'), hp, str(tmp_path / 'nowhere'))
+
+
+def test_pipeline_workgroup_tables_keep_layers_on_one_xcd_and_heads_next_to_layer_0():
+    """Host logic of the persistent synthesis pipeline (csrc/wn_synth_pipe.hip pipe_layout, through the no-GPU hook wn_test_pipe_layout): which
+    workgroup plays which CU.  Block b runs on XCD b % 8; a hand-off between CUs of one XCD goes through that XCD's L2 with plain stores, so the
+    tables must keep a layer's P CUs on ONE XCD and consecutive layers together, put the head(s) of a single-instance run on XCD 0 next to
+    layer 0, never exceed an XCD's 32 CUs, and be exact inverses of each other.  Paper model (24 x 8: once, two heads), hparams.py's own
+    (20 x 4: three instances in ONE launch of 256 workgroups), the 6-layer test models, and a model that does not fit three times."""
+    import ctypes
+    from wavenet_vocoder import _ext
+    lib = _ext.load_library()
+
+    def layout(L, P, ni):
+        role = np.full(1024, -7, dtype=np.int32); blk = np.full(1024, -7, dtype=np.int32)
+        grid = ctypes.c_int32(0); heads = ctypes.c_int32(0)
+        rc = lib.wn_test_pipe_layout(L, P, ni, role.ctypes.data, 1024, blk.ctypes.data, 1024, ctypes.byref(grid), ctypes.byref(heads))
+        return rc, role[:grid.value].copy(), blk, grid.value, heads.value
+
+    for L, P, ni_max in ((24, 8, 1), (20, 4, 3), (6, 8, 3), (6, 4, 3), (30, 2, 3), (12, 8, 2)):
+        rc, role, blk, grid, nh = layout(L, P, 1)
+        assert rc == ni_max, (L, P, rc)
+        spx = (L + 7) // 8
+        assert grid == 8 * (spx * P + nh) and nh == max(1, min(2, 30 - spx * P))
+        seen = {}
+        for b, r in enumerate(role):
+            if r < 0:
+                assert r == -1
+                continue
+            assert (r >> 24) == 0
+            if (r >> 23) & 1:
+                h = r & 0xff
+                assert b % 8 == 0 and h < nh and blk[L * P + h] == b          # heads: XCD 0, where layer 0 lives
+                seen[('h', h)] = b
+            else:
+                l, j = (r >> 8) & 0xff, r & 0xff
+                assert l < L and j < P and blk[l * P + j] == b and b % 8 == l // spx      # spx consecutive layers per XCD
+                seen[(l, j)] = b
+        assert len(seen) == L * P + nh and len(set(seen.values())) == len(seen)
+        assert max(np.bincount(np.nonzero(role >= 0)[0] % 8, minlength=8)) <= 30
+        for ni in range(2, ni_max + 1):
+            rc, role, blk, grid, nh1 = layout(L, P, ni)
+            assert rc == ni_max and grid == 256 and nh1 == 1
+            per = L * P + 1
+            used = set()
+            for i in range(ni):
+                for l in range(L):
+                    bs = [int(blk[i * per + l * P + j]) for j in range(P)]
+                    assert all(0 <= b < 256 for b in bs) and len({b % 8 for b in bs}) == 1          # a layer never splits over XCDs
+                    for j, b in enumerate(bs):
+                        assert role[b] == (i << 24) | (l << 8) | j and b not in used
+                        used.add(b)
+                hb = int(blk[i * per + L * P])
+                assert role[hb] == (i << 24) | (1 << 23) and hb not in used
+                used.add(hb)
+            assert len(used) == ni * per == int((role >= 0).sum())
+            assert max(np.bincount(np.array(sorted(used)) % 8, minlength=8)) <= 32
+        if ni_max < 3:
+            assert layout(L, P, ni_max + 1)[0] == -3 or layout(L, P, ni_max + 1)[0] < 0          # WN_E_SHAPE: does not fit
+    assert layout(0, 8, 1)[0] < 0 and layout(24, 9, 1)[0] < 0 and layout(24, 8, 4)[0] < 0
