@@ -22,6 +22,11 @@
 //   * queues are ring buffers in HBM (one private copy per CU, 4d slots per layer, zero-initialised == the reference's
 //     zero queues, wavenet.py:815-816), touched off the critical path only.
 // Every spin loop is bounded; a timeout raises a device flag that makes all workgroups leave.
+// Round 5: a run of more than ~12 streams is bound by a layer CU's service time per stream, and with ONE wave per SIMD that time is an
+// instruction count.  The pre-multiplication of every stream's next sample is one matrix product per sample on the matrix cores (pre_stash / pre_batch),
+// streams alternate between two head CUs, the mailbox copy nobody reads is not written, the publishing stores are builtins the compiler's waitcnt
+// pass can count (st_buf16), the skip chain needs no barrier, and the paper model's / hparams.py's widths are compile-time constants (SPEC 1 / 2):
+// 28 us per sample for 1 ... 12 streams of the paper model, 42.5 us at hparams.py's synthesis batch of 20 (real time at 22.05 kHz; was 72).
 #include "wn_common.h"
 #include <algorithm>
 #include <stdlib.h>
