@@ -288,7 +288,7 @@ def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8), 
             wbytes = 2.0 * sum(int(np.prod(sh)) for sh, _ in eng.layout.values())     # bf16 weights every stream-step multiplies
             out['%s_B%d' % (mode, B)] = {'seconds_of_audio_per_stream': T / hp.sample_rate, 'wall_s': dt, 'path': eng.synth_path,
                                         'instances': int(eng.lib.wn_synth_last_instances(eng.h)), 'pipeline_storage': os.environ.get('WN_PIPE_DTYPE', 'fp16'),
-                                        # 1: the layer CUs multiply every stream's past taps / conditioning in ONE matrix product per sample (R = 256 models, <= 24 streams per run)
+                                        # 1: the layer CUs multiply every stream's past taps / conditioning in ONE matrix product per sample (R = 256 models, every eligible run of <= 32 streams)
                                         'batched_premultiplication': int(eng.lib.wn_synth_last_batched(eng.h)), 'real_time': bool(dt / T * 1e6 <= 1e6 / hp.sample_rate),
                                         'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt,
                                         'us_per_step': dt / T * 1e6, 'deadline_us': 1e6 / hp.sample_rate,

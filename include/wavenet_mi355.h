@@ -221,7 +221,7 @@ int wn_synth_pipe_dtype(wn_ctx* ctx, int32_t half);
 /* how many pipeline INSTANCES the last wn_synthesize ran side by side (1 for a run of <= 10 streams or a model whose CUs fit the chip once:
  * the paper model takes 193 of 256; hparams.py's default model 81: up to three instances of <= 10 streams each). */
 int wn_synth_last_instances(const wn_ctx* ctx);
-/* 1 if the last wn_synthesize ran the persistent pipeline with the BATCHED pre-multiplication (R = 256 models, <= 24 streams per run: the
+/* 1 if the last wn_synthesize ran the persistent pipeline with the BATCHED pre-multiplication (R = 256 models, any eligible run of <= 32 streams: the
  * past taps and conditioning of every stream's next sample are multiplied in one [64 x K] x [K x streams] matrix product per sample and CU
  * instead of one matvec per stream), 0 otherwise.  Environment: WN_PIPE_BATCHPRE=0 keeps the per-stream form (A/B switch). */
 int wn_synth_last_batched(const wn_ctx* ctx);

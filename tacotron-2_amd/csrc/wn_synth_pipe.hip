@@ -407,15 +407,17 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
         // follows them -- by zeros), at a pitch of 2 (mod 16) chunks: the 16-lane groups of a ds_read_b128 then hit 16 different 16-B slots
         const int KPAD = (KP + 15) / 16 * 16;
         const int VSTR = ((KPAD + 13) / 16 * 16 + 2) * 16;
-        char* const Vb = lds + a.off_w1c;
+        // vectors 0 ... VCAP1 - 1 live where the tap-2 image was (64 R x 2 bytes), the rest where W_out's was (32 R x 2 bytes): both are register-resident on this path
+        const int VCAP1 = 64 * R * 2 / VSTR;
+        auto vrow = [&](int sidx) -> char* { return sidx < VCAP1 ? lds + a.off_w1c + sidx * VSTR : lds + a.off_wo + (sidx - VCAP1) * VSTR; };
         if (BP) {
             lds_barrier();                                                    // every wave holds its W1c registers before the image is overwritten
-            for (int i = tid; i < B * (KPAD - KP); i += PIPE_THREADS) *reinterpret_cast<uint4*>(Vb + (i / (KPAD - KP)) * VSTR + (KP + i % (KPAD - KP)) * 16) = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < B * (KPAD - KP); i += PIPE_THREADS) *reinterpret_cast<uint4*>(vrow(i / (KPAD - KP)) + (KP + i % (KPAD - KP)) * 16) = make_uint4(0, 0, 0, 0);
         }
         auto pre_stash = [&](int s, int tn, bool tap1_is_cur) {
             if (wave != 3) return;
             pf_wait(pf0, pf1);
-            char* vb = Vb + s * VSTR;
+            char* vb = vrow(s);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int i = lane + 64 * q, k = i * 8;
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
             PIPE_SVC_T(13);
             f32x4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
             const char* wa = W1p + (size_t)(16 * wave + n) * 16;
-            const char* vb0 = Vb + n * VSTR; const char* vb1 = Vb + (16 + n) * VSTR;
+            const char* vb0 = vrow(n); const char* vb1 = vrow(min(16 + n, two ? B - 1 : n));      // (lanes of a column past the last stream re-read a parked vector: their results are not stored)
             // four k-steps (16 chunks) per pass, all LDS reads of a pass issued before its first MFMA, addresses = one pointer per operand + immediates (a
             // k-step at a time with per-k-step address arithmetic and masking was issue-bound: 2.0 us per sample, profiles/r8c_pipe_svc_trace.txt)
             typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -1279,7 +1281,7 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
         // number of vectors that image holds; WN_PIPE_BATCHPRE=0: the per-stream pre-multiplication of rounds 2-4 (A/B switch)
         const char* bpe = getenv("WN_PIPE_BATCHPRE"); const bool bp_env = !bpe || atoi(bpe) != 0;
         const int kpad = ((2 * R + c->C) / 8 + 15) / 16 * 16, vstr = ((kpad + 13) / 16 * 16 + 2) * 16;
-        const bool bp = bp_env && R == 256 && Bmax <= 32 && (int64_t)Bmax * vstr <= 64LL * R * 2;
+        const bool bp = bp_env && R == 256 && Bmax <= 32 && Bmax <= (64 * R * 2) / vstr + (32 * R * 2) / vstr;      // parked vectors: the tap-2 image's place, then W_out's
         typedef void (*kern_t)(const PipeArgs);
         const char* spe = getenv("WN_PIPE_SPEC");
         const int spec = (spe && atoi(spe) == 0) ? 0 : (R == 256 && c->S == 256 && P == 8) ? 1 : (R == 128 && c->S == 128 && P == 4) ? 2 : 0;

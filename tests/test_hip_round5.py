@@ -179,9 +179,9 @@ def test_pipe_batched_premultiplication_matches_the_per_stream_form_and_the_orac
     vectors and ONE [64 x K] x [K x streams] product per sample on the matrix cores serves all streams (wn_synth_pipe.hip pre_batch).  Same
     arithmetic up to the order of the fp32 sums: every stream against the FP32 oracle in both forms, the two forms against each other, the layer bias
     and the per-stream gate bias of global conditioning, dilation-1 layers (their tap t-d is the sample in flight), 1 / 5 / 17 / 20 / 24 streams
-    (one and two 16-stream tiles, ragged), and 25 streams = more vectors than the freed tap-2 image holds: the per-stream form runs."""
+    (one and two 16-stream tiles, ragged), and 25 / 32 streams = more vectors than the freed tap-2 image holds: the rest is parked where W_out's was."""
     width = dict(residual_channels=256, gate_channels=512, skip_out_channels=256, cin_channels=80, num_mels=80)
-    for B in (1, 5, 17, 20, 24, 25):
+    for B in (1, 5, 17, 20, 24, 25, 32):
         hp, cfg, eng, params, wav, c, T = _setup(B, 6, layers=6, stacks=2, **width, **kw)
         nz_dev, nz_or = _noise(cfg, T, B)
         g = None
@@ -198,9 +198,9 @@ def test_pipe_batched_premultiplication_matches_the_per_stream_form_and_the_orac
             finally:
                 os.environ.pop('WN_PIPE_BATCHPRE', None); os.environ.pop('WN_PIPE_INSTANCES', None)
             assert eng.lib.wn_synth_last_instances(eng.h) == 1
-            assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_batched(eng.h) == (1 if bp and B <= 24 else 0)
+            assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_batched(eng.h) == (1 if bp else 0)
             raws[bp] = raw.cpu()
-            if bp and B in (5, 20):      # the kernel with these widths as compile-time constants (what ran above) against the generic one: the same bits
+            if bp and B in (5, 20, 32):      # the kernel with these widths as compile-time constants (what ran above) against the generic one: the same bits
                 os.environ['WN_PIPE_SPEC'] = '0'; os.environ['WN_PIPE_INSTANCES'] = '1'
                 try:
                     raw0 = torch.empty_like(raw)
