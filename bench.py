@@ -263,7 +263,9 @@ def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8), 
         Tc = max(2, int(round(secs * hp.sample_rate / hop)))
         T = Tc * hop
         # the pipeline also at hparams.py's wavenet_synthesis_batch_size (20): ONE run, streams pipelined through the layer ring
-        for B in (tuple(batches) + ((int(hp.wavenet_synthesis_batch_size),) if mode == 'pipe' and int(hp.wavenet_synthesis_batch_size) not in batches else ())):
+        # (+ 16 streams: the knee of the curve -- a run costs the wall time of one stream up to ~12 streams, then ~1.7 us per stream)
+        extra = tuple(b for b in (16, int(hp.wavenet_synthesis_batch_size)) if b not in batches) if mode == 'pipe' else ()
+        for B in tuple(batches) + extra:
             _log('synthesis %s B=%d T=%d' % (mode, B, T))
             eng = _ext.Engine(hp, B, T, inference_only=True)       # synthesis-only context: pre-sized, ~1.5 KB of HBM per (stream x sample)
             eng.pack_weights(eng_params_flat)
