@@ -250,6 +250,57 @@ def cpu_baseline_subprocess(workload, hard_timeout=150, fn='cpu_baseline'):
         return {'value': None, 'unit': 'audio_samples/s', 'cores': None, 'kind': 'port', 'sample': 'timed out after %d s' % hard_timeout}
 
 
+def synth_latency_budget(hp, scfg, B, measured_us):
+    """Latency budget of ONE generated sample on the persistent pipeline (replaces round 5's `weight_reread_GBps`, which over-counted LDS
+    reads under the batched pre-multiplication).  A sample is a chain of L + 1 dependent hand-offs (layer l -> l + 1 ... -> head -> layer 0):
+        budget = L * (hop + layer critical path) + cross-XCD surcharge * (hops that change XCD) + head service + head -> layer-0 hop
+                 + per-stream service * max(0, streams of one instance - knee)
+    with the hop priced by the chip, not by this kernel: MI355X_MICROARCH.md "handoff-1to1" (one producer -> one consumer, data-tagged
+    granules <= 4 KB, idle endpoints: 0.8 us; cross-XCD + 0.1 ... 0.3) -- the layer's P CUs gather P x 688 B, the same class.  The other
+    terms are this pipeline's own stage traces: critical path through a layer CU (rebuild x, current-tap matvec, gate, out matvec: 0.2 us with
+    the widths as compile-time constants, profiles/r8h), head (two convolutions + sampler + publish: 2.05 us, profiles/r4c_pipe_trace_b1.txt),
+    per-stream service past the knee (1.7 us on the paper model, knee 12 streams; hparams.py's widths 0.6 us, knee 8: profiles/r8h, r8j).
+    frac = budget / measured: 1.0 = nothing left but the chip's hand-off price."""
+    L = int(hp.layers)
+    P = int(hp.gate_channels) // 64
+    spx = (L + 7) // 8
+    paper = int(hp.residual_channels) >= 256
+    hop, xcd_extra, layer_cp, head = 0.8, 0.2, 0.2, 2.05
+    per_stream, knee = (1.7, 12) if paper else (0.6, 8)
+    bi = int(scfg.get('streams_per_instance') or B)
+    cross = max(0, -(-L // spx) - 1) + 1                    # layer groups on different XCDs + the way back to layer 0's XCD
+    budget = L * (hop + layer_cp) + cross * xcd_extra + head + hop + per_stream * max(0, bi - knee)
+    return {'hops': L + 1, 'hop_us': hop, 'cross_xcd_hops': cross, 'cross_xcd_extra_us': xcd_extra, 'layer_critical_path_us': layer_cp, 'head_us': head,
+            'per_stream_us_past_knee': per_stream, 'knee_streams': knee, 'streams_per_instance': bi, 'cus_per_layer': P,
+            'budget_us': budget, 'measured_us': measured_us, 'frac': budget / measured_us if measured_us else None,
+            'source': 'MI355X_MICROARCH.md price list (handoff-1to1) + profiles/r4c_pipe_trace_b1.txt, r8h_pipe_batch_scaling.txt, r8j_pipe_default_model_spec2.txt'}
+
+
+def synthesis_summary(res):
+    """The RTF half of BASELINE's metric in a dozen numbers, LAST key of the JSON line (the driver keeps the tail of long lines)."""
+    syn = res.get('synthesis') or {}
+    out = {'sample_rate': None, 'deadline_us': None}
+    for b in (1, 8, 16, 20):
+        leg = syn.get('pipe_B%d' % b) or {}
+        if 'rtf_per_stream' in leg:
+            out['rtf_b%d' % b] = round(leg['rtf_per_stream'], 4); out['us_per_step_b%d' % b] = round(leg['us_per_step'], 2)
+            out['deadline_us'] = round(leg['deadline_us'], 2)
+            out['budget_frac_b%d' % b] = round((leg.get('latency_budget') or {}).get('frac') or 0.0, 3)
+    leg = syn.get('pipe_B20') or syn.get('pipe_B8') or {}
+    out['storage'] = leg.get('pipeline_storage'); out['path'] = leg.get('path'); out['real_time_b20'] = (syn.get('pipe_B20') or {}).get('real_time')
+    out['switches_live'] = leg.get('switches_live')
+    g = syn.get('graph_B1') or {}
+    if 'rtf_per_stream' in g:
+        out['rtf_graph_path_b1'] = round(g['rtf_per_stream'], 3)
+    d = ((res.get('other_workloads') or {}).get('default_hparams') or {}).get('synthesis_pipeline') or {}
+    if 'rtf_per_stream' in (d.get('pipe_B20') or {}):
+        out['default_hparams_rtf_b20'] = round(d['pipe_B20']['rtf_per_stream'], 4)
+    if 'synthesis_parity_gate' in res:
+        out['parity_gate'] = res['synthesis_parity_gate'].get('ok')
+    out.pop('sample_rate')
+    return out
+
+
 def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8), modes=('pipe', 'graph')):
     """Autoregressive synthesis RTF at hp.sample_rate (BASELINE configs[3]: batch {1, 8} x 5 s from fixed mel conditioning).
     'pipe' = the persistent dataflow pipeline (steps_per_graph=0), timed on the full 5 s clip; 'graph' = the
@@ -287,20 +338,60 @@ def measure_synthesis(hp, eng_params_flat, device, seconds=5.0, batches=(1, 8), 
             torch.cuda.synchronize()
             dt = time.time() - t0
             eng.synth_check()
-            wbytes = 2.0 * sum(int(np.prod(sh)) for sh, _ in eng.layout.values())     # bf16 weights every stream-step multiplies
+            scfg = eng.synth_config()                       # how the library configured the run it just timed (wn_synth_last_config), not what the environment asked for
+            us = dt / T * 1e6
             out['%s_B%d' % (mode, B)] = {'seconds_of_audio_per_stream': T / hp.sample_rate, 'wall_s': dt, 'path': eng.synth_path,
-                                        'instances': int(eng.lib.wn_synth_last_instances(eng.h)), 'pipeline_storage': os.environ.get('WN_PIPE_DTYPE', 'fp16'),
+                                        'instances': scfg.get('instances'), 'pipeline_storage': ('fp16' if scfg.get('half_storage') else 'bf16') if mode == 'pipe' else None,
                                         # 1: the layer CUs multiply every stream's past taps / conditioning in ONE matrix product per sample (R = 256 models, every eligible run of <= 32 streams)
-                                        'batched_premultiplication': int(eng.lib.wn_synth_last_batched(eng.h)), 'real_time': bool(dt / T * 1e6 <= 1e6 / hp.sample_rate),
+                                        'batched_premultiplication': scfg.get('batched_premultiplication'), 'run_config': scfg,
+                                        'switches_live': {k: v for k, v in sorted(os.environ.items()) if k.startswith('WN_PIPE_') or k in ('WN_SYNTH_MODE',)},
+                                        'real_time': bool(us <= 1e6 / hp.sample_rate),
                                         'rtf_per_stream': dt / (T / hp.sample_rate), 'aggregate_samples_per_s': B * T / dt,
-                                        'us_per_step': dt / T * 1e6, 'deadline_us': 1e6 / hp.sample_rate,
-                                        # synthesis roofline: latency-bound; the bandwidth that matters is the weight re-read rate,
-                                        # served from LDS (pipeline: weights stay resident in 8 x 24 + 1 CUs) or L2 (graph path)
-                                        'weight_reread_GBps': wbytes * B * T / dt / 1e9, 'stream_tflops': 2.0 * mac_per_sample(hp) * B * T / dt / 1e12,
+                                        'us_per_step': us, 'deadline_us': 1e6 / hp.sample_rate,
+                                        # synthesis roofline: latency-bound -- a budget of dependent hand-offs, not a bandwidth
+                                        'latency_budget': synth_latency_budget(hp, scfg, B, us) if mode == 'pipe' else None,
+                                        'stream_tflops': 2.0 * mac_per_sample(hp) * B * T / dt / 1e12,
                                         'workspace_MB': eng.lib.wn_workspace_bytes(eng.h) / 1e6,
                                         'finite': bool(torch.isfinite(samples).all().item())}
             eng.close()
     return out
+
+
+def synthesis_parity_gate(hp, eng_params_flat, device, B=None, frames=2, tol=4e-3):
+    """a parity gate in front of the timed synthesis legs, on the switches that are live NOW.  No oracle here (only the
+    cpu_baseline legs may touch oracle/): the persistent pipeline at hparams.py's synthesis batch against the PRODUCT's own fp32 synthesis
+    mode (csrc/wn_synth_f32.hip: fp32 weights, queues and accumulation, pinned to the oracle at 2e-7 ... 6e-7 by tests/test_hip_round4.py) on
+    the same weights, conditioning, teacher-forced inputs and noise: `frames` conditioning frames of every stream, raw outputs, rel-L2 per
+    stream.  Bound 4e-3 = the bound of every half-storage pipeline test (measured 1.2e-3 ... 2.1e-3).  The full-length checks -- 20 streams x
+    27 500 steps, 8 x 110 275 -- are tests/test_hip_round6.py / test_hip_round4.py; this gate catches a switch combination no test has seen."""
+    import copy
+    from wavenet_vocoder import _ext
+    B = B or int(hp.wavenet_synthesis_batch_size)
+    hop = int(np.prod(hp.upsample_scales)); T = frames * hop
+    g = torch.Generator().manual_seed(77)
+    c = torch.rand(B, hp.cin_channels, frames, generator=g).to(device)
+    wav = (torch.rand(B, T, generator=g) * 1.6 - 0.8).to(device)
+    eng = _ext.Engine(hp, B, T, inference_only=True)
+    if hp.input_type == 'mulaw-quantize' or not eng.pipeline_eligible(B):
+        eng.close()
+        return {'ok': None, 'skipped': 'model not pipeline-eligible at B = %d (or class-id input)' % B}
+    nps = eng.noise_per_step
+    noise = (torch.randn(T, B, nps, generator=g) if hp.out_channels == 2 else torch.rand(T, B, nps, generator=g) * 0.98 + 0.01).to(device)
+    raws = {}
+    hp32 = copy.deepcopy(hp); hp32.set_hparam('mi355_compute_dtype', 'fp32')
+    for name, h in (('pipeline', hp), ('fp32', hp32)):
+        e = eng if name == 'pipeline' else _ext.Engine(h, B, T, inference_only=True)
+        e.pack_weights(eng_params_flat)
+        out = torch.empty(B, T, device=device); raw = torch.empty(B, hp.out_channels, T, device=device)
+        e.synthesize(c, noise, out, raw, wav, steps_per_graph=0 if name == 'pipeline' else 16)
+        torch.cuda.synchronize(); e.synth_check()
+        raws[name] = (raw.double().cpu(), e.synth_path, e.synth_config() if name == 'pipeline' else None)
+        e.close()
+    a, b = raws['pipeline'][0], raws['fp32'][0]
+    per = [float((a[i] - b[i]).norm() / (b[i].norm() + 1e-30)) for i in range(B)]
+    return {'ok': bool(max(per) < tol and raws['pipeline'][1] == 'pipeline' and raws['fp32'][1] == 'graph-fp32'), 'tolerance': tol, 'streams': B, 'steps': T,
+            'rel_l2_vs_fp32_mode_worst_stream': max(per), 'rel_l2_vs_fp32_mode_best_stream': min(per), 'paths': [raws['pipeline'][1], raws['fp32'][1]],
+            'run_config': raws['pipeline'][2], 'what': 'pipeline (default switches as live) vs the product fp32 synthesis mode, teacher forced, same noise; see docstring'}
 
 
 def measure_other_workload(key, device, steps=10, warmup=3):
@@ -335,6 +426,7 @@ def measure_other_workload(key, device, steps=10, warmup=3):
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps
     k_ms, k_n = eng.profile_kernel_result()
+    k_mhz, _ = eng.profile_kernel_clock()
     rows = eng.profile_rows_per_launch() or B * T
     eng.profile(False)
     R, G, C = hp.residual_channels, hp.gate_channels, hp.cin_channels
@@ -352,7 +444,7 @@ def measure_other_workload(key, device, steps=10, warmup=3):
            'mfma_whole_step_frac': 6.0 * mac_per_sample(hp) * value / 1e12 / peak_tf,
            'hbm_whole_step_frac': alg_bytes_per_sample(hp, e_act) * value / 8e12, 'alg_bytes_per_sample': alg_bytes_per_sample(hp, e_act),
            'gate_kernel': {'achieved_TFLOPs': gate_tf, 'frac_of_peak': (gate_tf / peak_tf) if gate_tf else None, 'launches_timed': int(k_n),
-                           'rows_per_launch': rows, 'timing': 'in-kernel stamps (pure kernel time), live in the two-stream step'},
+                           'rows_per_launch': rows, 'sclk_in_kernel_mhz': k_mhz or None, 'timing': 'in-kernel stamps (pure kernel time), live in the two-stream step'},
            'bound': 'hbm' if alg_bytes_per_sample(hp, e_act) * peak_tf * 1e12 > 6.0 * mac_per_sample(hp) * 8e12 else 'mfma'}
     eng.close()
     if key == 'c5_stress':
@@ -367,7 +459,7 @@ def measure_other_workload(key, device, steps=10, warmup=3):
         # three pipeline instances of 7 + 7 + 6 streams side by side in one launch; 2 s of audio per stream
         try:
             syn = measure_synthesis(hp, flat, device, seconds=2.0, batches=(8,), modes=('pipe',))      # (+ wavenet_synthesis_batch_size = 20)
-            out['synthesis_pipeline'] = {k: {kk: v.get(kk) for kk in ('rtf_per_stream', 'us_per_step', 'deadline_us', 'real_time', 'path', 'instances', 'batched_premultiplication', 'seconds_of_audio_per_stream', 'aggregate_samples_per_s')} for k, v in syn.items()}
+            out['synthesis_pipeline'] = {k: {kk: v.get(kk) for kk in ('rtf_per_stream', 'us_per_step', 'deadline_us', 'real_time', 'path', 'instances', 'batched_premultiplication', 'seconds_of_audio_per_stream', 'aggregate_samples_per_s', 'run_config', 'latency_budget', 'switches_live')} for k, v in syn.items()}
         except Exception as e:
             out['synthesis_pipeline'] = {'error': str(e)[:200]}
     del flat, grads, m, v, ema
@@ -552,6 +644,16 @@ def dry_run(args):
     dist.barrier()
     dt = time.time() - t0
     per_rank = gather_per_rank(dist, rank, world, dt / (args.warmup + args.steps) * 1e3, timer)
+    # the N = 1 leg of the real run, rehearsed: rank 0 alone walks the same loop with the exchange off while the others wait at a barrier
+    # (`n1_reference` / `scaling_vs_n1` of the JSON line: weak scaling, so N ranks at the N = 1 step time read N.0)
+    n1_wall = None
+    if rank == 0:
+        t1 = time.time()
+        f1 = torch.zeros(eng.n_params)
+        for i in range(args.warmup + args.steps):
+            f1 -= 0.1 * torch.full((eng.n_params,), float(1 + i))
+        n1_wall = max(time.time() - t1, 1e-9)
+    dist.barrier()
     cs = flat.sum().reshape(1).double()
     lo, hi = cs.clone(), cs.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -561,6 +663,8 @@ def dry_run(args):
                           'collective': {'backend': 'gloo', 'world_size': dist.get_world_size(), 'ranks_counted_by_allreduce': int(round(ones.item())),
                                          'self_launched': os.environ.get('WN_SELF_LAUNCHED') == '1'},
                           'tower_mean_correct': ok, 'replicas_identical': bool(lo.item() == hi.item()), 'wall_s': dt, 'per_rank': per_rank,
+                          'n1_reference': {'what': 'rank 0 alone, same loop, exchange off (rehearsal: CPU tensors, not a measurement)', 'wall_s': n1_wall},
+                          'scaling_vs_n1': (world * n1_wall / dt) if n1_wall else None,
                           'config': {'workload_key': args.workload},
                           'note': 'launch rehearsal on CPU: no kernel ran, nothing here is a measurement'}), flush=True)
     dist.barrier()
@@ -724,6 +828,7 @@ def main():
     _log('timed region done: %.1f ms/step' % (dt / args.steps * 1e3))
     prof_ms, prof_n = eng.profile_result()
     kern_ms, kern_n = eng.profile_kernel_result()
+    kern_mhz, kern_mhz_n = eng.profile_kernel_clock()        # mean shader clock inside the timed gate launches (in-kernel cycle counter / wall clock)
     rows_launch = eng.profile_rows_per_launch()
     eng.profile(False)
     # ---- sustained view (>= 20 warm-up, >= 100 timed steps, median of 3): the contract's timed region above may be a
@@ -745,8 +850,12 @@ def main():
                     dist.barrier()
                 blocks.append((time.time() - tb) / args.sustained * 1e3)
         med = float(np.median(blocks))
+        sm = smi.summary()
         sustained = {'what': '3 blocks x %d steps right after the timed region, same step function; median block' % args.sustained,
-                     'ms_per_step_blocks': blocks, 'ms_per_step': med, 'value': world * B * T / (med * 1e-3), 'unit': 'audio_samples/s', 'smi': smi.summary()}
+                     'ms_per_step_blocks': blocks, 'ms_per_step': med, 'value': world * B * T / (med * 1e-3), 'unit': 'audio_samples/s', 'smi': sm,
+                     # energy as a design axis: joules one training step costs at the sustained power draw, and per algorithmic byte / flop
+                     'joules_per_step': (sm['power_w_mean'] * med * 1e-3) if sm.get('power_w_mean') else None,
+                     'picojoules_per_alg_flop': (sm['power_w_mean'] * med * 1e-3 / (6.0 * mac_per_sample(hp) * B * T) * 1e12) if sm.get('power_w_mean') else None}
         _log('sustained: %s ms/step' % ', '.join('%.2f' % b for b in blocks))
     # untimed extra: the same step fed by the PRODUCT's feeder (wavenet_vocoder/feeder.py, reference feeder.py:266-340): .npy utterances
     # on disk -> background thread (length bucketing, hop-aligned crop, mel normalisation) -> pinned host batch -> non_blocking H2D ->
@@ -789,7 +898,7 @@ def main():
                         'host_ms': float(np.median(hs)), 'step_ms': float(np.median(ds))}
         _log('host enqueue %.2f ms of a %.2f ms step' % (host_enqueue['host_ms'], host_enqueue['step_ms']))
     # untimed extra: the same kernel with the GPU to itself (whole batch on one stream), for the kernel-quality view
-    excl_ms, excl_n, excl_rows, exk_ms, exk_n = 0.0, 0, 0, 0.0, 0
+    excl_ms, excl_n, excl_rows, exk_ms, exk_n, exk_mhz = 0.0, 0, 0, 0.0, 0, 0.0
     if not args.no_exclusive:
         eng.set_batch_parts(1)
         one_step(args.warmup + args.steps)
@@ -798,6 +907,7 @@ def main():
             one_step(args.warmup + args.steps + 1 + i)
         excl_ms, excl_n = eng.profile_result()
         exk_ms, exk_n = eng.profile_kernel_result()
+        exk_mhz, _ = eng.profile_kernel_clock()
         excl_rows = eng.profile_rows_per_launch()
         eng.profile(False)
         eng.set_batch_parts(0)
@@ -882,6 +992,10 @@ def main():
             'final_loss': final_loss,
             'roofline': {'bound': 'mfma', 'kernel': 'wn_gemm_lds_kernel<2,2,4,2,32,3,EPI_GATE,1,3> (dilated conv + cond GEMM + gate, fwd)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (achieved / peak) if achieved else None,
+                         # power as a bound: the step draws ~1.35 kW and the shader clock sits well under the 2400 MHz the 2.5 PFLOP/s peak assumes.  sclk_in_kernel_mhz =
+                         # workgroup 0 of every timed launch reads the shader-cycle counter over the 100 MHz wall clock; peak_at_clock = peak x sclk / 2400
+                         'sclk_in_kernel_mhz': kern_mhz or None, 'peak_at_clock': (peak * kern_mhz / 2400.0) if kern_mhz else None,
+                         'frac_of_peak_at_clock': (achieved / (peak * kern_mhz / 2400.0)) if (achieved and kern_mhz) else None,
                          'frac_incl_queue_wait': (achieved_ev / peak) if achieved_ev else None,
                          'timing': 'achieved / frac: in-kernel start..end stamps of every timed launch (the kernel duration rocprofv3 reports); '
                                    'frac_incl_queue_wait: HIP events around the same launches on their stream (adds the wait behind the other stream)',
@@ -896,6 +1010,7 @@ def main():
                          'note': 'each launch covers one half-batch and shares the GPU with the HBM-bound out-conv launches of the other half-batch on a second stream'},
             'roofline_exclusive': {'what': 'same kernel, whole batch on one stream (no concurrent kernels), 2 untimed steps after the timed region; in-kernel stamps',
                                    'avg_launch_ms': ex_avg, 'avg_launch_ms_event_bracket': excl_ms / max(excl_n, 1), 'rows_per_launch': excl_rows,
+                                   'sclk_in_kernel_mhz': exk_mhz or None, 'peak_at_clock': (peak * exk_mhz / 2400.0) if exk_mhz else None,
                                    'achieved': (2.0 * G * (3 * R + C) * excl_rows / (ex_avg * 1e-3) / 1e12) if excl_n else None,
                                    'frac': (2.0 * G * (3 * R + C) * excl_rows / (ex_avg * 1e-3) / 1e12 / peak) if excl_n else None},
             # whole-step view asked for by the north star: SURVEY 8d algorithmic HBM bytes per audio sample (bf16) x samples/s vs 8 TB/s
@@ -918,6 +1033,11 @@ def main():
         }
         if not args.no_synth and world == 1:      # replicas-only path: measured on one GPU, not while the other ranks wait
             _log('synthesis measurement ...')
+            try:
+                res['synthesis_parity_gate'] = synthesis_parity_gate(hp, flat, device)
+                _log('synthesis parity gate: %s' % json.dumps({k: res['synthesis_parity_gate'].get(k) for k in ('ok', 'rel_l2_vs_fp32_mode_worst_stream', 'streams', 'steps')}))
+            except Exception as e:
+                res['synthesis_parity_gate'] = {'ok': None, 'error': str(e)[:300]}
             try:
                 res['synthesis'] = measure_synthesis(hp, flat, device)
             except Exception as e:          # never lose the training number to a synthesis problem
@@ -946,6 +1066,7 @@ def main():
                     res['cpu_baseline_synthesis'] = {'value': None, 'sample': 'failed: ' + str(e)[:200]}
         else:
             res['cpu_baseline'] = None
+        res['synthesis_summary'] = synthesis_summary(res)      # LAST key on purpose
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(res) + '\n').encode())
     if use_dist:

@@ -216,8 +216,15 @@ int wn_synth_pipe_eligible(const wn_ctx* ctx, int32_t B);
  * (fp32 accumulation either way): 1 = IEEE half (the default: raw outputs 1.2e-3 from the reference's fp32 loop at C4's model, 34.8 us per
  * sample), 0 = bf16 (8.7e-3, 35.0 us; 8 exponent bits).  A half run whose residual stream leaves the half range (|x| > 65504) is
  * reported by wn_synth_check / the next wn_synthesize as WN_E_HIP ("left the half-precision range"): switch to bf16 and run again.
- * Environment at wn_create: WN_PIPE_DTYPE=fp16|bf16. */
+ * Environment at wn_create: WN_PIPE_DTYPE=fp16|bf16 (case-insensitive; also f16 / half / float16 / bfloat16; anything else fails wn_create). */
 int wn_synth_pipe_dtype(wn_ctx* ctx, int32_t half);
+/* How the LAST wn_synthesize of this context ran, as the library configured it (not as the environment asked): fills up to `cap` of
+ * out[0] path (as wn_synth_last_path) and, for a pipeline run, out[1] instances, [2] batched pre-multiplication, [3] kernel specialisation
+ * (0 generic, 1 paper widths R = S = 256, 2 hparams.py widths R = S = 128), [4] storage (1 IEEE half, 0 bf16), [5] head CUs, [6] early
+ * requests from this many streams, [7] abort word tested every n streams (0: once per sample), [8] workgroups launched, [9] streams of the
+ * largest instance; zeros for the other paths.  Returns the number of entries written (10) or WN_E_ARG.  bench.py records it next to
+ * every timed synthesis leg. */
+int wn_synth_last_config(const wn_ctx* ctx, int32_t* out, int32_t cap);
 /* how many pipeline INSTANCES the last wn_synthesize ran side by side (1 for a run of <= 10 streams or a model whose CUs fit the chip once:
  * the paper model takes 193 of 256; hparams.py's default model 81: up to three instances of <= 10 streams each). */
 int wn_synth_last_instances(const wn_ctx* ctx);
@@ -258,6 +265,9 @@ int wn_profile_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
 /* the same launches by IN-KERNEL stamps (first workgroup's start .. last workgroup's end on the 100 MHz wall clock): the kernel's own
  * duration, as rocprofv3's kernel trace reports it -- without the wait behind the other stream's kernels the event bracket includes */
 int wn_profile_kernel_result(wn_ctx* ctx, double* total_ms, int64_t* launches);
+/* mean shader clock (MHz) INSIDE the same launches: workgroup 0 of each reads the shader-cycle counter and the 100 MHz wall clock at its start
+ * and end.  The step runs at the chip's power limit (~1.35 kW), so the matrix peak that applies is 2500 TFLOP/s x clock / 2400 MHz. */
+int wn_profile_kernel_clock(wn_ctx* ctx, double* mhz, int64_t* launches);
 /* time rows (utterances x samples) one timed launch processed: the layer chain runs per half-batch on two streams */
 int64_t wn_profile_rows_per_launch(const wn_ctx* ctx);
 /* Device timeline of ONE training step from in-kernel stamps, no profiler attached (a profiler slows the host's enqueue enough to change

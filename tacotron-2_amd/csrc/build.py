@@ -96,5 +96,10 @@ def sanitizer_runtime():
 if __name__ == '__main__':
     if '--pipe-svc' in sys.argv:      # diagnostic build: the synthesis pipeline with its service-time stamps compiled in (tools/pipe_svc_trace.py)
         FLAGS.append('-DWN_PIPE_SVC_BUILD')
+    if '--ablate' in sys.argv:        # diagnostic build: WN_ABLATE skips whole launch classes of the training step (wn_train.hip; results are wrong by construction)
+        FLAGS.append('-DWN_ABLATE_BUILD')
+        o = os.path.join(HERE, 'wn_train.o')
+        if os.path.exists(o):
+            os.remove(o)
     print(build_sanitized() if '--sanitize' in sys.argv else build(force='--force' in sys.argv or '--pipe-svc' in sys.argv))
     print('build mode: ' + ', '.join('%s %s' % kv for kv in sorted(LAST_BUILD.items())))

@@ -220,7 +220,13 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
     c->lbias = cfg->use_bias != 0;
     c->wnorm = cfg->weight_normalization != 0;
     c->inference = cfg->inference_only != 0;
-    { const char* ed = getenv("WN_PIPE_DTYPE"); c->pipe_f16 = ed ? (strcmp(ed, "fp16") == 0 || strcmp(ed, "f16") == 0) : WN_PIPE_F16_DEFAULT; }
+    c->pipe_f16 = WN_PIPE_F16_DEFAULT;
+    if (const char* ed = getenv("WN_PIPE_DTYPE")) {      // case-insensitive; an unknown spelling is an error, not a silent bf16
+        std::string v(ed); for (char& ch : v) ch = (char)tolower((unsigned char)ch);
+        if (v == "fp16" || v == "f16" || v == "half" || v == "float16") c->pipe_f16 = true;
+        else if (v == "bf16" || v == "bfloat16") c->pipe_f16 = false;
+        else { delete c; WN_FAIL(z, WN_E_ARG, "WN_PIPE_DTYPE='%s': expected fp16 (f16, half, float16) or bf16 (bfloat16)", ed); }
+    }
     { const char* e8 = getenv("WN_GEMM8P"); c->gemm8p = e8 ? atoi(e8) : 0; }      // bit 0: gate, bit 1: d x on the 8-phase kernel (wn_tile8p.h; measured: not faster on any shipped workload)
     c->gin = cfg->gin_channels > 0 ? cfg->gin_channels : 0;
     c->OP = (int)align_up(c->O, 32); c->CP = (int)align_up(c->C, 32);
@@ -277,6 +283,7 @@ extern "C" void wn_destroy(wn_ctx* c) {
     if (c->skip_bias_total) hipFree(c->skip_bias_total);
     if (c->tensor_offsets_dev) hipFree(c->tensor_offsets_dev);
     if (c->kprof_dev) hipFree(c->kprof_dev);
+    if (c->kclk_dev) hipFree(c->kclk_dev);
     if (c->trace_dev) hipFree(c->trace_dev);
     if (c->norm2_dev) hipFree(c->norm2_dev);
     if (c->norm_spans_dev) hipFree(c->norm_spans_dev);
@@ -325,6 +332,7 @@ extern "C" const char* wn_dominant_kernel_name(void) { return "wn_gemm_lds_kerne
 // rocTX ranges around the host side of the drop-in entry points (tracing): `rocprofv3 --marker-trace --kernel-trace` then
 // shows which call enqueued which kernels.  The marker library is looked up at run time (dlopen of libroctx64.so / the SDK's
 // librocprofiler-sdk-roctx.so; no link dependency) and only when WN_ROCTX=1: otherwise a range costs one predictable branch.
+#include <ctype.h>
 #include <dlfcn.h>
 struct WnRoctx {
     int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
@@ -449,6 +457,14 @@ extern "C" int wn_synth_last_path(const wn_ctx* c) { return c ? c->synth_path : 
 extern "C" int wn_synth_last_instances(const wn_ctx* c) { return c ? c->synth_instances : WN_E_ARG; }
 extern "C" int wn_synth_last_batched(const wn_ctx* c) { return c ? (c->synth_path == 2 ? c->synth_batchpre : 0) : WN_E_ARG; }
 extern "C" int wn_synth_pipe_dtype(wn_ctx* c, int32_t half) { if (!c) return WN_E_ARG; c->pipe_f16 = half != 0; return WN_OK; }
+extern "C" int wn_synth_last_config(const wn_ctx* c, int32_t* out, int32_t cap) {
+    if (!c || !out || cap < 0) return WN_E_ARG;
+    int32_t v[WN_SYNTH_CFG_N] = {c->synth_path, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (c->synth_path == 2) for (int i = 1; i < WN_SYNTH_CFG_N; ++i) v[i] = c->synth_cfg[i];
+    const int n = cap < WN_SYNTH_CFG_N ? cap : WN_SYNTH_CFG_N;
+    for (int i = 0; i < n; ++i) out[i] = v[i];
+    return n;
+}
 extern "C" int wn_test_gemm8p_mask(const wn_ctx* c) {
     if (!c) return WN_E_ARG;
     if (c->packs.empty()) return 0;

@@ -168,6 +168,7 @@ struct wn_ctx {
 #define WN_TRACE_MAX 1024
     struct { int epi; void* st; int rows; } trace_tag[WN_TRACE_MAX];
     unsigned long long* kprof_dev = nullptr;      // [WN_KPROF_MAX][2] in-kernel {first start, last end} stamps of the timed gate launches
+    unsigned long long* kclk_dev = nullptr;       // [WN_KPROF_MAX][2] {shader cycles, 100 MHz ticks} of workgroup 0 of the same launches (wn_profile_kernel_clock)
 #define WN_KPROF_MAX 8192
     // batch parts: the serial layer chain of the two half-batches runs on two streams so that the MFMA/power-bound GEMMs of
     // one half overlap the HBM-bound kernels of the other (fwd: gate | out conv, bwd: dx | dgate); joined before the loss / wgrads
@@ -192,6 +193,10 @@ struct wn_ctx {
     bool pipe_f16 = false;                // persistent pipeline: IEEE-half weights / hand-offs / queues instead of bf16 (WN_PIPE_DTYPE=fp16|bf16 at wn_create, wn_synth_pipe_dtype)
     int synth_instances = 0;              // pipeline instances the last wn_synthesize ran side by side (wn_synth_last_instances)
     int synth_batchpre = 0;               // the last pipeline run multiplied every stream's past taps / conditioning in ONE matrix product per sample (wn_synth_last_batched)
+#define WN_SYNTH_CFG_N 10
+    int32_t synth_cfg[WN_SYNTH_CFG_N] = {};   // how the last pipeline run was configured (wn_synth_last_config): [1] instances [2] batched pre-multiplication [3] kernel specialisation
+                                          // (0 generic, 1 paper widths, 2 hparams.py widths) [4] 1 = IEEE-half storage [5] head CUs [6] early requests from n streams [7] abort test every
+                                          // n streams (0: once per sample) [8] workgroups launched [9] streams of the largest instance
     int pipe_cap = 0;                     // inference-only contexts: streams of ONE pipeline run the pre-sized buffers hold (0: pipeline not used / not limited)
     void* f32 = nullptr;                  // fp32-forward state (wn_f32.hip), allocated on the first forward of a cfg.compute_dtype = WN_COMPUTE_F32 context
     bool fwd_was_f32 = false;

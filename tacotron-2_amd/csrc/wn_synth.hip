@@ -347,7 +347,10 @@ int wn_synth_impl(wn_ctx* c, const float* cin, int B, int Tc, const float* noise
         // WN_SYNTH_MODE=graph|pipe overrides
         const char* m = getenv("WN_SYNTH_MODE");
         const bool want_pipe = m ? (strcmp(m, "pipe") == 0) : (steps_per_graph <= 0);
-        if (want_pipe && wn_pipe_eligible(c, B)) return wn_pipe_synthesize(c, cin, B, Tc, noise, test_inputs, out_samples, out_raw, caller_st);
+        // (an inference-only context never grows its pre-sized pipeline: a batch beyond pipe_cap takes the launch-per-layer path, as
+        // wn_synth_pipe_eligible tells the caller -- ADVICE round 5: this dispatch used to ignore pipe_cap and fail in wn_pipe_reserve)
+        const bool over_cap = c->inference && c->pipe_cap > 0 && B > c->pipe_cap;
+        if (want_pipe && !over_cap && wn_pipe_eligible(c, B)) return wn_pipe_synthesize(c, cin, B, Tc, noise, test_inputs, out_samples, out_raw, caller_st);
         if (steps_per_graph <= 0) steps_per_graph = 32;
     }
     int rc0 = wn_synth_reserve(c);

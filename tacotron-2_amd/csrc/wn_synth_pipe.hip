@@ -721,7 +721,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void wn_synth_pipe_kernel(const PipeA
                     }
                     PIPE_SVC(9);
                     if constexpr (H) {      // half has 5 exponent bits: a residual stream beyond 65504 became inf in the hand-off -- report it, do not synthesise garbage
-                        if (tid < R && !(fabsf(xcur_f[tid]) <= 65504.0f)) pipe_abort(abortf, 400 + l);
+                        for (int r = tid; r < R; r += PIPE_THREADS)      // (R <= 384 on the generic path: more channels than threads)
+                            if (!(fabsf(xcur_f[r]) <= 65504.0f)) pipe_abort(abortf, 400 + l);
                     }
                     if (t + 1 < T) { if (BP) pre_stash(s, t + 1, d == 1); else pre_finish(s, t + 1, d == 1); }      // ring rows are read past this CU's L1 (sc1): slots are recycled
                 }
@@ -1290,6 +1291,8 @@ int wn_pipe_synthesize(wn_ctx* c, const float* cin, int B, int Tc, const float* 
 #undef PK
         kern_t kern = kerns[p->f16 ? 1 : 0][ni > 1 ? 1 : 0][bp ? 1 : 0][spec];
         c->synth_batchpre = bp ? 1 : 0;
+        const int32_t cfgv[WN_SYNTH_CFG_N] = {2, ni, bp ? 1 : 0, spec, p->f16 ? 1 : 0, a.NH, a.early_from, a.abort_every, grid, Bmax};
+        for (int i = 0; i < WN_SYNTH_CFG_N; ++i) c->synth_cfg[i] = cfgv[i];
         WN_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PIPE_THREADS), lds_bytes, st, a);
     }

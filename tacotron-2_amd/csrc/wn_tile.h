@@ -52,6 +52,8 @@ struct GemmArgs {
     uint32_t key_lo, key_hi, thresh16; float keep_scale; int32_t drop_ld;   // dropout mask spec (row pitch of the dropped tensor)
     const bf16_t* zero;         // >= 16 B of zeros in device memory (source of out-of-range rows for the LDS-DMA kernel)
     unsigned long long* kprof;  // wn_profile: {min over workgroups of the start, max of the end} of THIS launch in 100 MHz wall-clock ticks (null: off)
+    unsigned long long* kclk;   // wn_profile: {shader cycles (s_memtime), 100 MHz ticks} workgroup 0 of THIS launch spent in the kernel: the shader clock
+                                // the launch actually ran at = 100 MHz x cycles / ticks (null: off) -- the chip runs this step at its power limit
     int32_t stagger;            // shader cycles the second-resident workgroups of the first round wait before starting (0: off)
     int32_t xcd_span;           // LDS-DMA kernels: > 0 = XCD x owns the contiguous tiles [x * xcd_span, (x + 1) * xcd_span); 0 = tiles interleaved over XCDs
     int32_t kil;                // block size of the K-interleaved pack (32: this header's TAPS kernels; 64: wn_gemm8p_kernel, wn_tile8p.h)
@@ -435,6 +437,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
     const int tile = a.xcd_span > 0 ? xcd * a.xcd_span + q / a.mblocks : (q / a.mblocks) * 8 + xcd;
     if (tile >= a.ntiles) return;
     if (a.kprof && tid == 0) atomicMin(a.kprof, (unsigned long long)wall_clock64());
+    if (a.kclk && id == 0 && tid == 0) { a.kclk[0] = __builtin_amdgcn_s_memtime(); a.kclk[1] = (unsigned long long)wall_clock64(); }
     if (a.stagger > 0 && id < 512) {
         // All tiles cost the same, so co-resident (and neighbouring) workgroups would reach their MFMA-idle, store-heavy
         // epilogues at the same moment.  First-round workgroups therefore start with a placement-dependent delay; later
@@ -905,6 +908,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         }
     }
     if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
+    if (a.kclk && id == 0 && tid == 0) { a.kclk[0] = __builtin_amdgcn_s_memtime() - a.kclk[0]; a.kclk[1] = (unsigned long long)wall_clock64() - a.kclk[1]; }
 }
 
 template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 1, int TAPS = 0>

@@ -59,6 +59,7 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
     const int tile = a.xcd_span > 0 ? xcd * a.xcd_span + q / a.mblocks : (q / a.mblocks) * 8 + xcd;
     if (tile >= a.ntiles) return;
     if (a.kprof && tid == 0) atomicMin(a.kprof, (unsigned long long)wall_clock64());
+    if (a.kclk && id == 0 && tid == 0) { a.kclk[0] = __builtin_amdgcn_s_memtime(); a.kclk[1] = (unsigned long long)wall_clock64(); }
     const int bl = tile / a.tiles_per_utt;
     const int b = bl + a.b0;
     const int t0 = (tile - bl * a.tiles_per_utt) * p8::BT;
@@ -433,6 +434,7 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
         }
     }
     if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
+    if (a.kclk && id == 0 && tid == 0) { a.kclk[0] = __builtin_amdgcn_s_memtime() - a.kclk[0]; a.kclk[1] = (unsigned long long)wall_clock64() - a.kclk[1]; }
 }
 
 template <int EPI, int ABL = 0, int SCHED = 0>

@@ -8,6 +8,16 @@ int wn_first_conv_grad(wn_ctx* c, const bf16_t* g0, float* grads, hipStream_t st
 int wn_upsample_bwd(wn_ctx* c, const float* dc_final, float* grads, hipStream_t st);
 int wn_loss_fwd_bwd(wn_ctx* c, float* loss_out, hipStream_t st);
 
+// Ablation switches of the DIAGNOSTIC build only (csrc/build.py --ablate defines WN_ABLATE_BUILD; the product library has none of this):
+// WN_ABLATE bit 0 skips the d c_up GEMM, bit 1 the d W_cin launch, bit 2 every out-conv launch, bit 3 every d z launch.  Results are
+// WRONG by construction; the step time says what that launch class costs the LIVE two-stream step, i.e. the most any fusion / speed-up of
+// it could return ("measure it rather than price it").
+#ifdef WN_ABLATE_BUILD
+static int wn_ablate() { static const int v = [] { const char* e = getenv("WN_ABLATE"); return e ? atoi(e) : 0; }(); return v; }
+#else
+static constexpr int wn_ablate() { return 0; }
+#endif
+
 // ================================================================================================
 static void set_dropout(wn_ctx* c, int layer, uint32_t& klo, uint32_t& khi, uint32_t& th, float& ks, int& ld) {
     wn_layer_key(c->fseed, layer, &klo, &khi);
@@ -103,6 +113,8 @@ extern "C" int wn_profile(wn_ctx* c, int32_t enable) {
     if (c->prof) {
         if (!c->kprof_dev) WN_HIP(c, hipMalloc((void**)&c->kprof_dev, (size_t)WN_KPROF_MAX * 16));
         hipLaunchKernelGGL(wn_kprof_init_kernel, dim3(cdiv(WN_KPROF_MAX, 256)), dim3(256), 0, 0, c->kprof_dev, WN_KPROF_MAX);
+        if (!c->kclk_dev) WN_HIP(c, hipMalloc((void**)&c->kclk_dev, (size_t)WN_KPROF_MAX * 16));
+        WN_HIP(c, hipMemset(c->kclk_dev, 0, (size_t)WN_KPROF_MAX * 16));
         WN_HIP(c, hipDeviceSynchronize());
     }
     return WN_OK;
@@ -119,6 +131,23 @@ extern "C" int wn_profile_kernel_result(wn_ctx* c, double* total_ms, int64_t* la
     WN_HIP(c, hipMemcpy(h.data(), c->kprof_dev, 16 * n, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; ++i)
         if (h[2 * i] != ~0ull && h[2 * i + 1] >= h[2 * i]) { *total_ms += (double)(h[2 * i + 1] - h[2 * i]) * 1e-5; ++*launches; }
+    return WN_OK;
+}
+// mean shader clock INSIDE the timed gate launches: workgroup 0 of every launch reads s_memtime (shader cycles) and the 100 MHz wall clock at its
+// start and end (GemmArgs::kclk); MHz = 100 x sum(cycles) / sum(ticks).  The step runs at the chip's power limit, so the matrix peak that applies is
+// 2500 TFLOP/s x this / 2400 (bench.py: roofline.peak_at_clock).
+extern "C" int wn_profile_kernel_clock(wn_ctx* c, double* mhz, int64_t* launches) {
+    if (!c || !mhz || !launches) return WN_E_ARG;
+    *mhz = 0.0; *launches = 0;
+    const size_t n = std::min<size_t>(c->pev_used / 2, WN_KPROF_MAX);
+    if (!c->kclk_dev || n == 0) return WN_OK;
+    for (size_t i = 0; i + 1 < c->pev_used; i += 2) WN_HIP(c, hipEventSynchronize(c->pev[i + 1]));
+    std::vector<unsigned long long> h(2 * n);
+    WN_HIP(c, hipMemcpy(h.data(), c->kclk_dev, 16 * n, hipMemcpyDeviceToHost));
+    double cyc = 0.0, ticks = 0.0;
+    for (size_t i = 0; i < n; ++i)
+        if (h[2 * i + 1] > 0 && h[2 * i + 1] < (1ull << 40) && h[2 * i] < (1ull << 48)) { cyc += (double)h[2 * i]; ticks += (double)h[2 * i + 1]; ++*launches; }
+    if (ticks > 0.0) *mhz = 100.0 * cyc / ticks;
     return WN_OK;
 }
 // total milliseconds and number of launches of the dominant kernel (gate GEMM) since wn_profile(ctx, 1); synchronises.
@@ -343,6 +372,7 @@ static void mk_out(wn_ctx* c, int l, int b0, int nb, GemmArgs& o) {
 }
 static void prof_gate(wn_ctx* c, GemmArgs& a, hipStream_t st) {
     a.kprof = (c->kprof_dev && c->pev_used / 2 < WN_KPROF_MAX) ? c->kprof_dev + 2 * (c->pev_used / 2) : nullptr;
+    a.kclk = (c->kclk_dev && c->pev_used / 2 < WN_KPROF_MAX) ? c->kclk_dev + 2 * (c->pev_used / 2) : nullptr;
     prof_mark(c, st);
 }
 static int fwd_gate(wn_ctx* c, int l, int b0, int nb, hipStream_t st, bool prof) {
@@ -354,6 +384,7 @@ static int fwd_gate(wn_ctx* c, int l, int b0, int nb, hipStream_t st, bool prof)
 }
 static int fwd_out(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
     if (l + 1 >= c->L) return WN_OK;      // the residual output of the last layer is never consumed (wavenet.py:716)
+    if (wn_ablate() & 4) return WN_OK;
     GemmArgs o; mk_out(c, l, b0, nb, o);
     return wn_launch_gemm<EPI_STORE_BF16>(c, o, c->packs[l].wo.M, st);
 }
@@ -501,6 +532,7 @@ static void mk_dx(wn_ctx* c, int l, int b0, int nb, GemmArgs& a) {
     a.e.out0 = c->GXall + (size_t)l * NT * R; a.e.ld_out0 = R;
 }
 static int bwd_dgate(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
+    if (wn_ablate() & 8) return WN_OK;
     GemmArgs a; mk_dgate(c, l, b0, nb, a);
     return wn_launch_gemm<EPI_DGATE>(c, a, c->packs[l].w2T.M, st);
 }
@@ -606,7 +638,7 @@ static int stack_wgrads(wn_ctx* c, float* grads, int l0, int ng, bool fused, hip
             WgBatchArgs w; wgrad_taps_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
             if ((rc = launch_wgrad_batch(c, w, st))) return rc;
         }
-        {   // d W_cin:  A = c(t),  B = d z
+        if (!(wn_ablate() & 2)) {   // d W_cin:  A = c(t),  B = d z
             WgBatchArgs w; wgrad_cin_args(c, w, l0, ng, c->fB, c->fT); w.grads = grads;
             if ((rc = launch_wgrad_batch(c, w, st))) return rc;
         }
@@ -763,7 +795,7 @@ static int wn_bwd_eff(wn_ctx* c, float* grads, hipStream_t st) {
         GemmArgs a; base_args(c, a, c->wcT);
         a.nseg = 1; a.seg[0] = seg(c->DZ, G, 0, G, 0, 0); a.nrep = L; a.rep_stride = NT * G;
         a.e.out0 = c->DC; a.e.M_valid = C;
-        if ((rc = wn_launch_gemm<EPI_STORE_F32_BOT>(c, a, c->wcT.M, side))) return rc;
+        if (!(wn_ablate() & 1)) if ((rc = wn_launch_gemm<EPI_STORE_F32_BOT>(c, a, c->wcT.M, side))) return rc;
         if ((rc = wn_upsample_bwd(c, c->DC, grads, side))) return rc;
     }
     if (side != st) {

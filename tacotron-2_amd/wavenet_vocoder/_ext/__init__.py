@@ -101,6 +101,7 @@ def load_library():
         'wn_test_pipe_layout': (ctypes.c_int, [i32, i32, i32, vp, i32, vp, i32, vp, vp]),
         'wn_synth_pipe_dtype': (ctypes.c_int, [vp, i32]),
         'wn_synth_last_instances': (ctypes.c_int, [vp]),
+        'wn_synth_last_config': (ctypes.c_int, [vp, ctypes.POINTER(i32), i32]),
         'wn_synth_last_batched': (ctypes.c_int, [vp]),
         'wn_synth_pipe_eligible': (ctypes.c_int, [vp, i32]),
         'wn_sample': (ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]),
@@ -113,6 +114,7 @@ def load_library():
         'wn_profile': (ctypes.c_int, [vp, i32]),
         'wn_profile_result': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]),
         'wn_profile_kernel_result': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]),
+        'wn_profile_kernel_clock': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]),
         'wn_profile_rows_per_launch': (i64, [vp]),
         'wn_set_batch_parts': (ctypes.c_int, [vp, i32]),
         'wn_debug_copy': (ctypes.c_int, [vp, ctypes.c_char_p, i32, vp, i64, vp]),
@@ -345,6 +347,17 @@ class Engine:
         """16-bit storage type of the persistent pipeline for the next runs: True = IEEE half (default), False = bf16."""
         self._ok(self.lib.wn_synth_pipe_dtype(self.h, 1 if half else 0))
 
+    def synth_config(self):
+        """How the last synthesize() ran, as the library configured it (wn_synth_last_config)."""
+        v = (ctypes.c_int32 * 10)()
+        n = int(self.lib.wn_synth_last_config(self.h, v, 10))
+        if n < 0:
+            self._ok(n)
+        keys = ('path', 'instances', 'batched_premultiplication', 'kernel_spec', 'half_storage', 'head_cus', 'early_from', 'abort_every', 'workgroups', 'streams_per_instance')
+        d = dict(zip(keys, (int(v[i]) for i in range(n))))
+        d['path'] = {0: None, 1: 'graph', 2: 'pipeline', 3: 'graph-fp32'}.get(d.get('path'))
+        return d
+
     @property
     def synth_path(self):
         return {0: None, 1: 'graph', 2: 'pipeline', 3: 'graph-fp32'}.get(int(self.lib.wn_synth_last_path(self.h)))
@@ -366,6 +379,12 @@ class Engine:
         ms, n = ctypes.c_double(), ctypes.c_int64()
         self._ok(self.lib.wn_profile_kernel_result(self.h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def profile_kernel_clock(self):
+        """(MHz, launches): mean shader clock inside the timed gate launches (workgroup 0's cycle counter over the 100 MHz wall clock)."""
+        mhz, n = ctypes.c_double(), ctypes.c_int64()
+        self._ok(self.lib.wn_profile_kernel_clock(self.h, ctypes.byref(mhz), ctypes.byref(n)))
+        return mhz.value, n.value
 
     def set_batch_parts(self, parts):
         self._ok(self.lib.wn_set_batch_parts(self.h, int(parts)))

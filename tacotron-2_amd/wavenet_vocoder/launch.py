@@ -50,12 +50,24 @@ def require_gpus(n):
                          % (n, have, n))
 
 
+# libc's prctl is resolved ONCE, at import: the preexec_fn below runs in the forked child of a multi-threaded parent (torch is already
+# imported by then), where dlopen / a Python-level allocation can deadlock on a lock some other thread held at fork() (subprocess docs;
+# ADVICE round 5).  The child then only calls the pre-bound C function.
+try:
+    _PRCTL = ctypes.CDLL('libc.so.6', use_errno=True).prctl
+    _PRCTL.argtypes = [ctypes.c_int, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong]
+    _PRCTL.restype = ctypes.c_int
+except (OSError, AttributeError):      # not Linux / no libc.so.6: the SIGTERM forwarding of spawn_ranks is the portable path
+    _PRCTL = None
+_PR_SET_PDEATHSIG = 1
+
+
 def _die_with_parent():
-    """preexec_fn of every rank (Linux): SIGTERM when the launching process dies, however it dies (a SIGKILLed parent cannot forward anything)."""
-    try:
-        ctypes.CDLL('libc.so.6', use_errno=True).prctl(1, signal.SIGTERM)      # PR_SET_PDEATHSIG
-    except Exception:       # noqa: BLE001 -- best effort: the SIGTERM handler below is the portable path
-        pass
+    """preexec_fn of every rank (Linux): SIGTERM when the launching THREAD dies, however it dies (a SIGKILLed parent cannot forward
+    anything).  PR_SET_PDEATHSIG is tied to the thread that forked: spawn_ranks must therefore be called from a thread that outlives the
+    ranks -- the main thread in bench.py / train.py (spawn_ranks says so when it is not)."""
+    if _PRCTL is not None:
+        _PRCTL(_PR_SET_PDEATHSIG, int(signal.SIGTERM), 0, 0, 0)
 
 
 class _Terminated(BaseException):
@@ -82,28 +94,36 @@ EADDRINUSE_RC = 98      # a rank whose rendezvous failed with "address already i
 
 
 def _spawn_once(argv, n, env_extra, poll_s):
+    import threading
     port = free_port()
     procs = []
 
     def on_term(signum, frame):
         raise _Terminated(signum)
     old = {}
-    for sg in (signal.SIGTERM, signal.SIGINT):
-        try:
-            old[sg] = signal.signal(sg, on_term)
-        except ValueError:          # not the main thread: the caller owns signal handling
-            pass
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(n), 'LOCAL_WORLD_SIZE': str(n),
-                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'WN_SELF_LAUNCHED': '1'})
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this driver (RCCL needs it across processes)
-        env.setdefault('GPU_MAX_HW_QUEUES', '8')
-        if env_extra:
-            env.update(env_extra)
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if r == 0 else sys.stderr, preexec_fn=_die_with_parent))
+    main_thread = threading.current_thread() is threading.main_thread()
+    if not main_thread:
+        sys.stderr.write('launch: spawn_ranks called from a non-main thread: signals are not forwarded by this call, and the ranks receive '
+                         'SIGTERM when THIS thread exits (PR_SET_PDEATHSIG follows the forking thread) -- keep it alive until they are done\n')
     rc = 0
+    # everything from the first handler installed to the last rank reaped is inside ONE try: a signal that arrives while the ranks are
+    # still being started terminates the ones already running and restores the handlers (the Popen loop used to sit
+    # in front of the try block)
     try:
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            try:
+                old[sg] = signal.signal(sg, on_term)
+            except ValueError:          # not the main thread: the caller owns signal handling
+                pass
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(n), 'LOCAL_WORLD_SIZE': str(n),
+                        'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'WN_SELF_LAUNCHED': '1'})
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this driver (RCCL needs it across processes)
+            env.setdefault('GPU_MAX_HW_QUEUES', '8')
+            if env_extra:
+                env.update(env_extra)
+            procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if r == 0 else sys.stderr, preexec_fn=_die_with_parent))
         live = list(procs)
         while live:
             for p in list(live):

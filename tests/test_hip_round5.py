@@ -155,21 +155,7 @@ def test_pipeline_instances_serve_the_default_synthesis_batch_side_by_side():
         print('\n%d streams as %d pipeline instances: worst stream %.2e' % (B, want_ni, max(per)))
         assert max(per) < 4e-3 and torch.allclose(out.cpu(), exp, atol=2e-5)
         eng.close()
-    # hparams.py's own model (20 layers, 4 CUs per layer: 81 CUs) at hparams.py's own synthesis batch: three instances of 7 + 7 + 6 streams in ONE
-    # launch of 256 workgroups (243 resident); residency of all of them = no hand-off timeout, also on a run long enough for a partially
-    # resident launch to hit its spin limit (a launch per instance did, profiles/r7f)
-    import hparams as H
-    from wavenet_vocoder import _ext
-    from wavenet_vocoder.models.modules import initialize_parameters
-    hp = H._build()
-    hop = int(np.prod(hp.upsample_scales)); Tc = 80
-    eng = _ext.Engine(hp, 20, Tc * hop, inference_only=True)
-    eng.pack_weights(initialize_parameters(hp, eng.layout).cuda())
-    out = torch.empty(20, Tc * hop, device='cuda')
-    eng.synthesize(torch.rand(20, hp.cin_channels, Tc, device='cuda'), None, out, None, None, steps_per_graph=0, seed=3)
-    torch.cuda.synchronize(); eng.synth_check()
-    assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_instances(eng.h) == 3 and torch.isfinite(out).all()
-    eng.close()
+    # (hparams.py's own 20-layer model at hparams.py's own synthesis batch of 20 on three instances, against the oracle: tests/test_hip_round6.py)
 
 
 @pytest.mark.parametrize('kw', [dict(), dict(gin_channels=16, use_speaker_embedding=True, n_speakers=4)])

@@ -1,0 +1,117 @@
+"""Round-6 GPU tests: parity AT THE SYNTHESIS GEOMETRIES bench.py TIMES ("Next round" item 1).
+
+bench.py's `pipe_B16` / `pipe_B20` legs run the 24-layer paper model with 16 / 20 streams in ONE pipeline run on the default switches
+(two head CUs, early requests from 18 streams, the kernel with the paper widths as compile-time constants, batched pre-multiplication)
+and hparams.py's own 20-layer model with 20 streams on three side-by-side instances.  Until this round those code paths were checked
+on 6-layer stand-ins only (tests/test_hip_round5.py, test_hip_round4.py); the 24-layer model at 2 and 8 streams.  Reference loop:
+wavenet.py:724-911 (incremental), hparams.py:301-304 (wavenet_synthesis_batch_size = 20)."""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from hip_util import make_hp, oracle_cfg, rel_err, upload_params
+from oracle import wavenet_oracle as O
+from test_hip_bench_geometry import PAPER
+from test_hip_synth import _noise, _setup
+
+pytestmark = pytest.mark.gpu
+
+PIPE_SWITCHES = ('WN_PIPE_BATCHPRE', 'WN_PIPE_SPEC', 'WN_PIPE_EARLY_FROM', 'WN_PIPE_INSTANCES', 'WN_PIPE_ABORT_EVERY', 'WN_PIPE_DTYPE', 'WN_PIPE_HEADS')
+
+
+def _assert_default_switches():
+    live = {k: os.environ[k] for k in PIPE_SWITCHES if k in os.environ}
+    assert not live, 'this test pins the DEFAULT pipeline configuration; unset %s' % live
+
+
+@pytest.mark.parametrize('B', [20, 16])
+def test_pipe_paper_model_at_the_benched_stream_counts_vs_the_fp32_oracle(B):
+    """The paper model (24 layers / 2 stacks, R = S = 256, 10-MoL: 193 CUs, SPEC 1 kernel) with 20 (and 16) streams in ONE pipeline run,
+    27 500 teacher-forced steps (the d = 2048 rings -- 4097 rows -- wrap six times), default switches.  EVERY stream against the FP32 oracle on
+    the final 5 500 samples: the oracle's batch forward runs on the window [T - 5 500 - receptive field, T) (hop aligned) and is exact from
+    one receptive field in (the windowed scheme of test_pipe_c4_at_the_benched_batch_8x110275, which covers 8 streams x 110 275).  Bound
+    4e-3 as in every half-storage pipeline test (measured at 2 / 8 streams: 1.2e-3)."""
+    _assert_default_switches()
+    Tc = 100
+    hp, cfg, eng, params, wav, c, T = _setup(B, Tc, **dict(PAPER, wavenet_dropout=0.0))
+    assert T == 27500 and eng.pipeline_eligible(B)
+    nz_dev, nz_or = _noise(cfg, T, B)
+    out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, cfg.out_channels, T, device='cuda')
+    t0 = time.time()
+    eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, wav.contiguous().cuda(), steps_per_graph=0)
+    torch.cuda.synchronize(); eng.synth_check()
+    dt = time.time() - t0
+    assert eng.synth_path == 'pipeline'
+    assert eng.lib.wn_synth_last_instances(eng.h) == 1 and eng.lib.wn_synth_last_batched(eng.h) == 1
+    raw = raw.cpu()
+    RF = eng.receptive_field
+    assert RF == 16381
+    tail = 5500
+    fr0 = (T - tail - RF) // cfg.hop
+    w0 = fr0 * cfg.hop
+    assert w0 > 0 and T - tail - w0 >= RF - 1
+    per = []
+    t1 = time.time()
+    with torch.no_grad():
+        for b0 in range(0, B, 4):           # four streams per oracle call (~0.5 GB per activation tensor)
+            nb = min(4, B - b0)
+            xs = torch.cat([torch.zeros(nb, 1), wav[b0:b0 + nb, :-1]], 1)[:, w0:].reshape(nb, 1, T - w0)
+            r = O.step(params, cfg, xs, c[b0:b0 + nb, :, fr0:])
+            per += [rel_err(raw[b0 + i, :, T - tail:], r[i, :, T - tail - w0:]) for i in range(nb)]
+    rec = {'B': B, 'T': T, 'wall_s_device_incl_first_run_setup': dt, 'rel_l2_final_5500_per_stream': per, 'window_start': w0, 'oracle_seconds': time.time() - t1}
+    print('\npaper model, %d streams x %d steps in one pipeline run (default switches), final %d samples of every stream vs the FP32 oracle: worst %.2e, best %.2e; oracle %.0f s'
+          % (B, T, tail, max(per), min(per), rec['oracle_seconds']))
+    d = os.environ.get('WN_PARITY_REPORT_DIR')
+    if d:
+        with open(os.path.join(d, 'parity_pipe_paper_b%d.json' % B), 'w') as f:
+            json.dump(rec, f, indent=1)
+    assert max(per) < 4e-3
+    exp = O.sample_from_discretized_mix_logistic(raw, nz_or['u1'].permute(1, 0, 2), nz_or['u2'].t(), cfg.log_scale_min)
+    assert torch.allclose(out.cpu(), exp, atol=2e-5)
+    eng.close()
+
+
+def test_pipe_default_hparams_model_20_streams_on_three_instances_vs_the_fp32_oracle():
+    """hparams.py's OWN model (20 layers / 2 stacks, R = S = 128, gate 256, Gaussian head, SubPixel [11, 25]: 81 CUs, SPEC 2 kernel) at
+    hparams.py's own wavenet_synthesis_batch_size = 20: three pipeline instances of 7 + 7 + 6 streams in one launch, 11 000 teacher-forced
+    steps (receptive field 4 093: every ring wraps).  Every stream over the WHOLE clip against the FP32 oracle -- round 5 asserted
+    `isfinite` here and took parity from a 6-layer stand-in."""
+    import hparams as H
+    from wavenet_vocoder import _ext
+    _assert_default_switches()
+    hp = H._build()
+    hp.set_hparam('wavenet_dropout', 0.0)
+    cfg = oracle_cfg(hp)
+    assert (cfg.layers, cfg.residual_channels, cfg.gate_channels, cfg.out_channels) == (20, 128, 256, 2)
+    B, Tc = int(hp.wavenet_synthesis_batch_size), 40
+    assert B == 20
+    T = Tc * cfg.hop
+    eng = _ext.Engine(hp, B, T, inference_only=True)
+    assert eng.pipeline_eligible(B)
+    params = O.init_params(cfg, seed=11, bias_scale=0.05)
+    eng.pack_weights(upload_params(eng, params))
+    from hip_util import synth_batch
+    wav, c = synth_batch(cfg, B, T, seed=3)
+    nz_dev, nz_or = _noise(cfg, T, B)
+    out = torch.empty(B, T, device='cuda'); raw = torch.empty(B, cfg.out_channels, T, device='cuda')
+    eng.synthesize(c.cuda(), nz_dev.cuda(), out, raw, wav.contiguous().cuda(), steps_per_graph=0)
+    torch.cuda.synchronize(); eng.synth_check()
+    assert eng.synth_path == 'pipeline' and eng.lib.wn_synth_last_instances(eng.h) == 3
+    raw = raw.cpu()
+    with torch.no_grad():
+        xs = torch.cat([torch.zeros(B, 1), wav[:, :-1]], 1).reshape(B, 1, T)
+        r32 = O.step(params, cfg, xs, c)
+    per = [rel_err(raw[b], r32[b]) for b in range(B)]
+    last = [rel_err(raw[b, :, -2000:], r32[b, :, -2000:]) for b in range(B)]
+    print('\nhparams.py model, 20 streams on 3 instances x %d steps vs the FP32 oracle: worst stream %.2e (final 2000 samples %.2e)' % (T, max(per), max(last)))
+    d = os.environ.get('WN_PARITY_REPORT_DIR')
+    if d:
+        with open(os.path.join(d, 'parity_pipe_default_b20.json'), 'w') as f:
+            json.dump({'B': B, 'T': T, 'rel_l2_per_stream': per, 'rel_l2_final_2000_per_stream': last}, f, indent=1)
+    assert max(per) < 4e-3 and max(last) < 4e-3
+    exp = O.sample_from_gaussian(raw, nz_or['eps'].t(), cfg.log_scale_min_gauss)
+    assert torch.allclose(out.cpu(), exp, atol=2e-5)
+    eng.close()

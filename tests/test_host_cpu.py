@@ -630,6 +630,22 @@ def test_c_abi_rejects_bad_configurations_before_touching_the_gpu():
     rc, msg = call(cfg)
     assert rc == ARG and 'abi_version' in msg
     assert lib.wn_create(None, None) == ARG
+    # WN_PIPE_DTYPE is parsed case-insensitively and an unknown spelling is an error (it used to select bf16 silently)
+    old = os.environ.get('WN_PIPE_DTYPE')
+    try:
+        os.environ['WN_PIPE_DTYPE'] = 'fp8'
+        rc, msg = create()
+        assert rc == ARG and 'WN_PIPE_DTYPE' in msg
+        for ok in ('FP16', 'half', 'Float16', 'BF16', 'bfloat16'):
+            os.environ['WN_PIPE_DTYPE'] = ok
+            rc, msg = create()
+            assert rc in (0, -3) and 'WN_PIPE_DTYPE' not in msg, (ok, rc, msg)      # accepted: fails later only for want of a GPU (WN_E_HIP)
+    finally:
+        if old is None:
+            os.environ.pop('WN_PIPE_DTYPE', None)
+        else:
+            os.environ['WN_PIPE_DTYPE'] = old
+    assert lib.wn_synth_last_config(None, None, 0) == ARG
     # a null context is an argument error on every entry point, never a crash
     lib.wn_param_count.restype = ctypes.c_int64
     assert lib.wn_receptive_field(None) == ARG and lib.wn_param_count(None) == ARG and lib.wn_num_tensors(None) == ARG

@@ -49,6 +49,10 @@ def test_bench_accepts_the_c5_workload_under_n_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert d['n_gpus'] == 2 and d['config']['workload_key'] == 'c5_stress' and len(d['per_rank']) == 2
+    # the fields the driver's 8-GPU run of this workload will carry exist and are filled by both ranks
+    assert [p['rank'] for p in d['per_rank']] == [0, 1] and all(p['exchange']['calls'] == 3 for p in d['per_rank'])
+    assert d['scaling_vs_n1'] is not None and d['scaling_vs_n1'] > 0 and d['n1_reference']['wall_s'] > 0
+    assert d['dry_run'] is True and d['value'] is None
 
 
 def test_rccl_topology_excerpt_reads_the_debug_files(tmp_path):
