@@ -1,0 +1,200 @@
+// Stand-alone check + timing of the HBM-bound 1x1-convolution launches of a layer: the whole-B kernel (csrc/wn_tile_wb.h) against what
+// wn_launch_gemm (csrc/wn_tile.h: THE product header) launches for the same arguments.
+//   out conv C2     : M = 256, K = 256, residual + scale + dropout copy (EPI_STORE_BF16)       -- 1 KB read + 1 KB written per row
+//   out conv default: M = 128, K = 128 (hparams.py widths)
+//   head mask GEMM  : M = 256, K = 256, EPI_MASK_STORE
+// Outputs must be BIT-IDENTICAL (same products, same order).  Timed alone at full and half batch, and as the step runs them: beside a gate
+// GEMM of the other half batch on a second stream.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc tools/stream_harness.hip -o tools/stream_harness
+//   tools/stream_harness [B=8] [T=11000] [rounds=3]
+#include "wn_tile_wb.h"
+#include <vector>
+#include <random>
+#include <functional>
+#include <algorithm>
+#include <cmath>
+
+std::string g_create_err;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static std::mt19937 rng(4321);
+static std::vector<bf16_t> host_bf16_random(size_t n, float scale) {
+    std::vector<bf16_t> h(n);
+    std::uniform_real_distribution<float> d(-scale, scale);
+    for (auto& v : h) v = f2bf(d(rng));
+    return h;
+}
+static bf16_t* to_dev(const std::vector<bf16_t>& h) { bf16_t* p; CK(hipMalloc(&p, h.size() * 2)); CK(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice)); return p; }
+static bf16_t* dev_bf16_random(size_t n, float scale) { return to_dev(host_bf16_random(n, scale)); }
+static float* dev_f32_random(size_t n, float scale) {
+    std::vector<float> h(n);
+    std::uniform_real_distribution<float> d(-scale, scale);
+    for (auto& v : h) v = d(rng);
+    float* p; CK(hipMalloc(&p, n * 4)); CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice)); return p;
+}
+template <class Tp> static Tp* dev_fill(size_t n) { Tp* p; CK(hipMalloc(&p, n * sizeof(Tp))); CK(hipMemset(p, 0xff, n * sizeof(Tp))); return p; }
+// fragment-ordered pack of W[M][K] (sequential K); nk_tap > 0: the first 3 * nk_tap columns K-interleaved in 32-channel blocks (gate)
+static std::vector<bf16_t> pack_frag(const std::vector<bf16_t>& W, int M, int K, int nk_tap = 0, int kil = 32) {
+    std::vector<int> kmap(K);
+    int kp = 0;
+    for (int kb = 0; kb < (nk_tap ? nk_tap / kil : 0); ++kb) for (int j = 0; j < 3; ++j) for (int i = 0; i < kil; ++i) kmap[kp++] = j * nk_tap + kb * kil + i;
+    for (int k = 3 * nk_tap; k < K; ++k) kmap[kp++] = k;
+    const int KS = K / 16;
+    std::vector<bf16_t> out((size_t)M * K);
+    for (int mt = 0; mt < M / 32; ++mt) for (int ks = 0; ks < KS; ++ks) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j)
+        out[(((size_t)mt * KS + ks) * 64 + lane) * 8 + j] = W[(size_t)(mt * 32 + (lane & 31)) * K + kmap[ks * 16 + (lane >> 5) * 8 + j]];
+    return out;
+}
+static bool same_bits(const bf16_t* da, const bf16_t* db, size_t n) {
+    std::vector<bf16_t> a(n), b(n);
+    CK(hipMemcpy(a.data(), da, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), db, n * 2, hipMemcpyDeviceToHost));
+    return memcmp(a.data(), b.data(), n * 2) == 0;
+}
+static float time_ms(const std::function<void()>& f, int iters = 20) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0)); for (int i = 0; i < iters; ++i) f(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 8, T = argc > 2 ? atoi(argv[2]) : 11000, rounds = argc > 3 ? atoi(argv[3]) : 3;
+    const int64_t NT_ = (int64_t)B * T;
+    int fails = 0;
+    wn_ctx ctx;
+    printf("stream harness: B %d T %d (rows %lld)\n", B, T, (long long)NT_);
+    bf16_t* zero; CK(hipMalloc(&zero, 4096)); CK(hipMemset(zero, 0, 4096));
+    float* bias = dev_f32_random(1024, 0.5f);
+    auto base = [&](GemmArgs& a, const bf16_t* Apk, int K, int nb, int b0) {
+        memset(&a, 0, sizeof a); a.Apk = Apk; a.ksteps_total = K / 16; a.nrep = 1; a.B = nb; a.b0 = b0; a.T = T; a.zero = zero; a.e.scale = 1.0f;
+    };
+    auto mkseg = [](const bf16_t* b, int ld, int col0, int nk, int shift) { SrcSeg s; s.base = b; s.ld = ld; s.col0 = col0; s.nk = nk; s.shift = shift; s.dropout = 0; return s; };
+    auto report = [&](const char* what, const char* kern, float ms, double bytes) { printf("%-34s %-38s %7.1f us  %5.2f TB/s\n", what, kern, ms * 1e3, bytes / ms / 1e9); };
+    {
+        hipFuncAttributes fa; int nb = -1;
+        CK(hipFuncGetAttributes(&fa, (const void*)wn_gemm_wb_kernel<4, 2, 4, EPI_STORE_BF16>));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)wn_gemm_wb_kernel<4, 2, 4, EPI_STORE_BF16>, 512, 0));
+        printf("wb<4,2,4,STORE_BF16>: %d regs, %zu B LDS, scratch %zu B, %d blocks/CU\n", fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, nb);
+        CK(hipFuncGetAttributes(&fa, (const void*)wn_gemm_wb_kernel<2, 4, 2, EPI_STORE_BF16>));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)wn_gemm_wb_kernel<2, 4, 2, EPI_STORE_BF16>, 512, 0));
+        printf("wb<2,4,2,STORE_BF16>: %d regs, %zu B LDS, scratch %zu B, %d blocks/CU\n", fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, nb);
+    }
+    // ---------------- out conv, C2 widths (modules.py:515-520 + the dropout of the next layer's input, :484)
+    {
+        const int M = 256, K = 256;
+        bf16_t* Apk = to_dev(pack_frag(host_bf16_random((size_t)M * K, 0.06f), M, K));
+        bf16_t* U = dev_bf16_random(NT_ * K, 1.0f); bf16_t* X = dev_bf16_random(NT_ * M, 1.0f);
+        bf16_t* O[2] = {dev_fill<bf16_t>(NT_ * M), dev_fill<bf16_t>(NT_ * M)}; bf16_t* D[2] = {dev_fill<bf16_t>(NT_ * M), dev_fill<bf16_t>(NT_ * M)};
+        auto mk = [&](int which, int nb, int b0) {
+            GemmArgs a; base(a, Apk, K, nb, b0); a.nseg = 1; a.seg[0] = mkseg(U, K, 0, K, 0);
+            a.e.bias = bias; a.e.in0 = X; a.e.ld_in0 = M; a.e.scale = WN_SQRT_HALF; a.e.out0 = O[which]; a.e.ld_out0 = M; a.e.out1 = D[which]; a.e.ld_out1 = M; a.e.M_valid = M;
+            a.key_lo = 0x1234567u; a.key_hi = 0x89abcdefu; a.thresh16 = 3277; a.keep_scale = 1.0f / 0.95f; a.drop_ld = M;
+            return a;
+        };
+        const double bytes = (double)NT_ * (K + 3.0 * M) * 2;
+        for (int nb : {B, B / 2, 1}) {
+            if (nb < 1) continue;
+            CK(hipMemset(O[0], 0xff, NT_ * M * 2)); CK(hipMemset(O[1], 0xff, NT_ * M * 2)); CK(hipMemset(D[0], 0xff, NT_ * M * 2)); CK(hipMemset(D[1], 0xff, NT_ * M * 2));
+            GemmArgs p = mk(0, nb, 0), w = mk(1, nb, 0);
+            wn_launch_gemm<EPI_STORE_BF16>(&ctx, p, M, 0);
+            if (!wn_gemm_wb_fits<4, 2, 4>(w, M)) { printf("out conv: wb does not fit\n"); return 1; }
+            wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, w, M, 0); CK(hipDeviceSynchronize());
+            const bool ok = same_bits(O[0], O[1], NT_ * M) && same_bits(D[0], D[1], NT_ * M);
+            printf("out conv C2, %d utterances: whole-B vs production %s\n", nb, ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+        }
+        for (int rep = 0; rep < 3; ++rep) {          // race screen: reproduces its own bits, also beside a second copy
+            GemmArgs w = mk(1, B, 0), w2 = mk(0, B, 0);
+            CK(hipMemset(O[0], 0xff, NT_ * M * 2)); CK(hipMemset(O[1], 0xff, NT_ * M * 2));
+            wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, w, M, 0); wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, w2, M, 0); CK(hipDeviceSynchronize());
+            if (!same_bits(O[0], O[1], NT_ * M)) { printf("out conv C2 race screen %d FAIL\n", rep); ++fails; }
+        }
+        for (int rnd = 0; rnd < rounds; ++rnd) {
+            for (int nb : {B, B / 2}) {
+                GemmArgs p = mk(0, nb, 0), w = mk(1, nb, 0);
+                const double by = bytes * nb / B;
+                char nm[64]; snprintf(nm, sizeof nm, "out conv C2, %d utterances", nb);
+                report(nm, "production (wn_launch_gemm)", time_ms([&] { GemmArgs q = p; wn_launch_gemm<EPI_STORE_BF16>(&ctx, q, M, 0); }), by);
+                report(nm, "whole-B <4,2,4>", time_ms([&] { GemmArgs q = w; wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, q, M, 0); }), by);
+            }
+        }
+        // as the step runs it: beside the gate GEMM of the other half batch (second stream)
+        if (B >= 2) {
+            const int R = 256, G = 512, GH = 256, C = 80, Kg = 3 * R + C, d = 64;
+            bf16_t* A32 = to_dev(pack_frag(host_bf16_random((size_t)G * Kg, 0.05f), G, Kg, R, 32));
+            bf16_t* XD = dev_bf16_random(NT_ * R, 1.0f); bf16_t* cbt = dev_bf16_random(NT_ * C, 1.0f);
+            bf16_t* TS = dev_fill<bf16_t>(NT_ * GH); bf16_t* Ug = dev_fill<bf16_t>(NT_ * GH);
+            GemmArgs g; base(g, A32, Kg, B / 2, 0); g.nseg = 4; g.taps = 3; g.kil = 32;
+            g.seg[0] = mkseg(XD, R, 0, R, -2 * d); g.seg[1] = mkseg(XD, R, 0, R, -d); g.seg[2] = mkseg(XD, R, 0, R, 0); g.seg[3] = mkseg(cbt, C, 0, C, 0);
+            g.e.bias = bias; g.e.out0 = TS; g.e.ld_out0 = GH; g.e.out1 = Ug; g.e.ld_out1 = GH; g.e.M_valid = G; g.e.GH = GH;
+            hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            GemmArgs p = mk(0, B - B / 2, B / 2), w = mk(1, B - B / 2, B / 2);
+            for (int rnd = 0; rnd < rounds; ++rnd) {
+                const float tg = time_ms([&] { GemmArgs q = g; wn_launch_gemm<EPI_GATE>(&ctx, q, G, s1); CK(hipStreamSynchronize(s1)); }, 10);
+                const float tp = time_ms([&] { GemmArgs q = g; wn_launch_gemm<EPI_GATE>(&ctx, q, G, s1); GemmArgs r = p; wn_launch_gemm<EPI_STORE_BF16>(&ctx, r, M, s2); CK(hipStreamSynchronize(s1)); CK(hipStreamSynchronize(s2)); }, 10);
+                const float tw = time_ms([&] { GemmArgs q = g; wn_launch_gemm<EPI_GATE>(&ctx, q, G, s1); GemmArgs r = w; wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, r, M, s2); CK(hipStreamSynchronize(s1)); CK(hipStreamSynchronize(s2)); }, 10);
+                // 4 gates + 4 out convs back to back per stream (the chain as the step enqueues it, no host sync inside)
+                const float cp = time_ms([&] { for (int i = 0; i < 4; ++i) { GemmArgs q = g; wn_launch_gemm<EPI_GATE>(&ctx, q, G, s1); GemmArgs r = mk(0, B / 2, 0); wn_launch_gemm<EPI_STORE_BF16>(&ctx, r, M, s1);
+                                                                        GemmArgs q2 = g; q2.b0 = B / 2; q2.B = B - B / 2; wn_launch_gemm<EPI_GATE>(&ctx, q2, G, s2); GemmArgs r2 = p; wn_launch_gemm<EPI_STORE_BF16>(&ctx, r2, M, s2); }
+                                               CK(hipStreamSynchronize(s1)); CK(hipStreamSynchronize(s2)); }, 5);
+                const float cw = time_ms([&] { for (int i = 0; i < 4; ++i) { GemmArgs q = g; wn_launch_gemm<EPI_GATE>(&ctx, q, G, s1); GemmArgs r = mk(1, B / 2, 0); wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, r, M, s1);
+                                                                        GemmArgs q2 = g; q2.b0 = B / 2; q2.B = B - B / 2; wn_launch_gemm<EPI_GATE>(&ctx, q2, G, s2); GemmArgs r2 = w; wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, r2, M, s2); }
+                                               CK(hipStreamSynchronize(s1)); CK(hipStreamSynchronize(s2)); }, 5);
+                printf("half-batch gate alone %6.1f us | gate + out conv of the other half on a second stream (host-synchronised): production %6.1f us, whole-B %6.1f us | "
+                       "4 layers of [gate, out conv] on two streams: production %7.1f us, whole-B %7.1f us\n", tg * 1e3, tp * 1e3, tw * 1e3, cp * 1e3, cw * 1e3);
+            }
+        }
+    }
+    // ---------------- out conv, hparams.py widths (R = 128, gate 256)
+    {
+        const int M = 128, K = 128;
+        bf16_t* Apk = to_dev(pack_frag(host_bf16_random((size_t)M * K, 0.08f), M, K));
+        bf16_t* U = dev_bf16_random(NT_ * K, 1.0f); bf16_t* X = dev_bf16_random(NT_ * M, 1.0f);
+        bf16_t* O[2] = {dev_fill<bf16_t>(NT_ * M), dev_fill<bf16_t>(NT_ * M)}; bf16_t* D[2] = {dev_fill<bf16_t>(NT_ * M), dev_fill<bf16_t>(NT_ * M)};
+        auto mk = [&](int which, int nb, int b0) {
+            GemmArgs a; base(a, Apk, K, nb, b0); a.nseg = 1; a.seg[0] = mkseg(U, K, 0, K, 0);
+            a.e.bias = bias; a.e.in0 = X; a.e.ld_in0 = M; a.e.scale = WN_SQRT_HALF; a.e.out0 = O[which]; a.e.ld_out0 = M; a.e.out1 = D[which]; a.e.ld_out1 = M; a.e.M_valid = M;
+            a.key_lo = 0x7654321u; a.key_hi = 0xfedcba98u; a.thresh16 = 3277; a.keep_scale = 1.0f / 0.95f; a.drop_ld = M;
+            return a;
+        };
+        const double bytes = (double)NT_ * (K + 3.0 * M) * 2;
+        for (int nb : {B, B / 2}) {
+            if (nb < 1) continue;
+            CK(hipMemset(O[0], 0xff, NT_ * M * 2)); CK(hipMemset(O[1], 0xff, NT_ * M * 2)); CK(hipMemset(D[0], 0xff, NT_ * M * 2)); CK(hipMemset(D[1], 0xff, NT_ * M * 2));
+            GemmArgs p = mk(0, nb, 0), w = mk(1, nb, 0);
+            wn_launch_gemm<EPI_STORE_BF16>(&ctx, p, M, 0);
+            if (!wn_gemm_wb_fits<2, 4, 2>(w, M)) { printf("out conv default: wb does not fit\n"); return 1; }
+            wn_launch_gemm_wb<2, 4, 2, EPI_STORE_BF16>(&ctx, w, M, 0); CK(hipDeviceSynchronize());
+            const bool ok = same_bits(O[0], O[1], NT_ * M) && same_bits(D[0], D[1], NT_ * M);
+            printf("out conv default widths, %d utterances: whole-B vs production %s\n", nb, ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+        }
+        for (int rnd = 0; rnd < rounds; ++rnd)
+            for (int nb : {B, B / 2}) {
+                GemmArgs p = mk(0, nb, 0), w = mk(1, nb, 0);
+                const double by = bytes * nb / B;
+                char nm[64]; snprintf(nm, sizeof nm, "out conv R = 128, %d utterances", nb);
+                report(nm, "production (wn_launch_gemm)", time_ms([&] { GemmArgs q = p; wn_launch_gemm<EPI_STORE_BF16>(&ctx, q, M, 0); }), by);
+                report(nm, "whole-B <2,4,2>", time_ms([&] { GemmArgs q = w; wn_launch_gemm_wb<2, 4, 2, EPI_STORE_BF16>(&ctx, q, M, 0); }), by);
+            }
+    }
+    // ---------------- head backward mask GEMM (d skip = (W1 d pre1) * (skips > 0), wavenet.py:716-719 differentiated)
+    {
+        const int M = 256, K = 256;
+        bf16_t* Apk = to_dev(pack_frag(host_bf16_random((size_t)M * K, 0.06f), M, K));
+        bf16_t* Din = dev_bf16_random(NT_ * K, 1.0f); bf16_t* Ref = dev_bf16_random(NT_ * M, 1.0f);
+        bf16_t* O[2] = {dev_fill<bf16_t>(NT_ * M), dev_fill<bf16_t>(NT_ * M)};
+        auto mk = [&](int which) {
+            GemmArgs a; base(a, Apk, K, B, 0); a.nseg = 1; a.seg[0] = mkseg(Din, K, 0, K, 0);
+            a.e.in0 = Ref; a.e.ld_in0 = M; a.e.out0 = O[which]; a.e.ld_out0 = M; a.e.M_valid = M;
+            return a;
+        };
+        GemmArgs p = mk(0), w = mk(1);
+        wn_launch_gemm<EPI_MASK_STORE>(&ctx, p, M, 0); wn_launch_gemm_wb<4, 2, 4, EPI_MASK_STORE>(&ctx, w, M, 0); CK(hipDeviceSynchronize());
+        const bool ok = same_bits(O[0], O[1], NT_ * M);
+        printf("head mask GEMM: whole-B vs production %s\n", ok ? "bitwise-ok" : "FAIL"); fails += !ok;
+        const double bytes = (double)NT_ * (K + 2.0 * M) * 2;
+        report("head mask GEMM", "production (wn_launch_gemm)", time_ms([&] { GemmArgs q = p; wn_launch_gemm<EPI_MASK_STORE>(&ctx, q, M, 0); }), bytes);
+        report("head mask GEMM", "whole-B <4,2,4>", time_ms([&] { GemmArgs q = w; wn_launch_gemm_wb<4, 2, 4, EPI_MASK_STORE>(&ctx, q, M, 0); }), bytes);
+    }
+    printf("stream harness %s (%d failing checks)\n", fails ? "FAILED" : "passed", fails);
+    return fails != 0;
+}
