@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['wn_api.hip', 'wn_pack.hip', 'wn_frontend.hip', 'wn_loss.hip', 'wn_optim.hip', 'wn_train.hip', 'wn_synth.hip', 'wn_synth_pipe.hip', 'wn_f32.hip', 'wn_synth_f32.hip']
-HEADERS = ['wn_common.h', 'wn_tile.h', 'wn_tile8p.h', 'wn_tile_wb.h', 'wn_wgrad.h', 'wn_mulaw_tables.h', os.path.join('..', '..', 'include', 'wavenet_mi355.h')]
+HEADERS = ['wn_common.h', 'wn_tile.h', 'wn_tile8p.h', 'wn_wgrad.h', 'wn_mulaw_tables.h', os.path.join('..', '..', 'include', 'wavenet_mi355.h')]
 LIB = os.path.join(HERE, 'libwavenet_mi355.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-inline-asm']
 

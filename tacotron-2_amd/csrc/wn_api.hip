@@ -227,7 +227,6 @@ extern "C" int wn_create(const wn_config* cfg, wn_ctx** out) {
         else if (v == "bf16" || v == "bfloat16") c->pipe_f16 = false;
         else { delete c; WN_FAIL(z, WN_E_ARG, "WN_PIPE_DTYPE='%s': expected fp16 (f16, half, float16) or bf16 (bfloat16)", ed); }
     }
-    { const char* ew = getenv("WN_GEMM_WB"); c->gemm_wb = ew ? atoi(ew) : 1; }
     { const char* e8 = getenv("WN_GEMM8P"); c->gemm8p = e8 ? atoi(e8) : 0; }      // bit 0: gate, bit 1: d x on the 8-phase kernel (wn_tile8p.h; measured: not faster on any shipped workload)
     c->gin = cfg->gin_channels > 0 ? cfg->gin_channels : 0;
     c->OP = (int)align_up(c->O, 32); c->CP = (int)align_up(c->C, 32);

@@ -154,7 +154,6 @@ struct wn_ctx {
 #define WN_PIPE_F16_DEFAULT true       // storage type of the persistent synthesis pipeline when WN_PIPE_DTYPE is not set: IEEE half (1.2e-3 vs bf16's 8.7e-3 from the fp32 loop, same speed)
     bf16_t* zero_page = nullptr;          // zeros: DMA source for out-of-range rows / k-steps (wn_gemm_lds_kernel: 16 B per lane from one address;
                                           // wn_gemm8p_kernel's SGPR-base form: base + 16 * lane, i.e. 1 KiB)
-    int gemm_wb = 1;                      // WN_GEMM_WB at wn_create (default 1): the HBM-bound 1x1 convolutions on the whole-B kernel (wn_tile_wb.h) where the shape fits it
     int gemm8p = 0;                       // WN_GEMM8P at wn_create, bit 0: gate, bit 1: d x on the 8-phase kernel (wn_tile8p.h) where the model fits it; default 0: the 256 x 128 LDS-DMA ring kernel
     float* scal;                          // device scalars: [0]=loss sum [1]=denominator [2]=1/denominator [3]=count
     // state of the last forward

@@ -1,7 +1,6 @@
 // Training step of the WaveNet stack: forward (wavenet.py:650-721), loss (476-495) and the hand-written
 // backward (replaces tf.gradients / optimizer.compute_gradients, wavenet.py:557).
 #include "wn_tile8p.h"
-#include "wn_tile_wb.h"
 #include "wn_wgrad.h"
 
 int wn_first_conv(wn_ctx* c, hipStream_t st);
@@ -383,21 +382,11 @@ static int fwd_gate(wn_ctx* c, int l, int b0, int nb, hipStream_t st, bool prof)
     if (prof) prof_mark(c, st);
     return rc;
 }
-// HBM-bound 1x1 convolutions with a row-wise epilogue (out conv + residual, final_convolution_1, the head's backward mask GEMMs): the whole-B kernel
-// (wn_tile_wb.h: every HBM request of a workgroup issued up front, bit-identical outputs) where the shape fits it -- K = 256 with 256-row M blocks (paper
-// widths) or K = 128 with 128-row M blocks (hparams.py widths) --, else the ring kernel.  WN_GEMM_WB=0 at wn_create: the ring kernel everywhere (A/B switch).
-template <int EPI> static int launch_conv1x1(wn_ctx* c, GemmArgs& a, int M, hipStream_t st) {
-    if (c->gemm_wb) {
-        if (wn_gemm_wb_fits<4, 2, 4>(a, M)) return wn_launch_gemm_wb<4, 2, 4, EPI>(c, a, M, st);
-        if (wn_gemm_wb_fits<2, 4, 2>(a, M)) return wn_launch_gemm_wb<2, 4, 2, EPI>(c, a, M, st);
-    }
-    return wn_launch_gemm<EPI>(c, a, M, st);
-}
 static int fwd_out(wn_ctx* c, int l, int b0, int nb, hipStream_t st) {
     if (l + 1 >= c->L) return WN_OK;      // the residual output of the last layer is never consumed (wavenet.py:716)
     if (wn_ablate() & 4) return WN_OK;
     GemmArgs o; mk_out(c, l, b0, nb, o);
-    return launch_conv1x1<EPI_STORE_BF16>(c, o, c->packs[l].wo.M, st);
+    return wn_launch_gemm<EPI_STORE_BF16>(c, o, c->packs[l].wo.M, st);
 }
 // skip sum + head of the utterances [b0, b0 + nb) (wavenet.py:716-721)
 static int fwd_tail(wn_ctx* c, int b0, int nb, hipStream_t st) {
@@ -414,7 +403,7 @@ static int fwd_tail(wn_ctx* c, int b0, int nb, hipStream_t st) {
         GemmArgs a; base_args(c, a, c->wh1, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->R1, S, 0, S, 0, 0);
         a.e.bias = c->params_dev + c->fin1_b; a.e.relu = 1; a.e.out0 = c->H2; a.e.ld_out0 = S;
-        if ((rc = launch_conv1x1<EPI_STORE_BF16>(c, a, c->wh1.M, st))) return rc;
+        if ((rc = wn_launch_gemm<EPI_STORE_BF16>(c, a, c->wh1.M, st))) return rc;
     }
     {   // final_convolution_2 -> y_hat [B,O,T] fp32
         GemmArgs a; base_args(c, a, c->wh2, b0, nb);
@@ -502,14 +491,14 @@ static int bwd_head(wn_ctx* c, int b0, int nb, hipStream_t st, int part) {
         GemmArgs a; base_args(c, a, c->wh2T, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->DY, ldDY, 0, c->wh2T.K, 0, 0);
         a.e.in0 = c->H2; a.e.ld_in0 = S; a.e.out0 = c->DPRE1; a.e.ld_out0 = S;
-        if ((rc = launch_conv1x1<EPI_MASK_STORE>(c, a, c->wh2T.M, st))) return rc;
+        if ((rc = wn_launch_gemm<EPI_MASK_STORE>(c, a, c->wh2T.M, st))) return rc;
         WN_HIP(c, hipEventRecord(c->ev_head[part], st));
     }
     {   // d skip = (W1 dpre1) * (skips > 0)
         GemmArgs a; base_args(c, a, c->wh1T, b0, nb);
         a.nseg = 1; a.seg[0] = seg(c->DPRE1, S, 0, S, 0, 0);
         a.e.in0 = c->R1; a.e.ld_in0 = S; a.e.out0 = c->DSKIP; a.e.ld_out0 = S;
-        if ((rc = launch_conv1x1<EPI_MASK_STORE>(c, a, c->wh1T.M, st))) return rc;
+        if ((rc = wn_launch_gemm<EPI_MASK_STORE>(c, a, c->wh1T.M, st))) return rc;
     }
     return WN_OK;
 }

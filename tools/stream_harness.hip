@@ -1,11 +1,11 @@
-// Stand-alone check + timing of the HBM-bound 1x1-convolution launches of a layer: the whole-B kernel (csrc/wn_tile_wb.h) against what
+// Stand-alone check + timing of the HBM-bound 1x1-convolution launches of a layer: the whole-B kernel (tools/wn_tile_wb.h, a rejected alternative) against what
 // wn_launch_gemm (csrc/wn_tile.h: THE product header) launches for the same arguments.
 //   out conv C2     : M = 256, K = 256, residual + scale + dropout copy (EPI_STORE_BF16)       -- 1 KB read + 1 KB written per row
 //   out conv default: M = 128, K = 128 (hparams.py widths)
 //   head mask GEMM  : M = 256, K = 256, EPI_MASK_STORE
 // Outputs must be BIT-IDENTICAL (same products, same order).  Timed alone at full and half batch, and as the step runs them: beside a gate
 // GEMM of the other half batch on a second stream.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc tools/stream_harness.hip -o tools/stream_harness
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc -I tools tools/stream_harness.hip -o tools/stream_harness
 //   tools/stream_harness [B=8] [T=11000] [rounds=3]
 #include "wn_tile_wb.h"
 #include <vector>

@@ -1,13 +1,16 @@
-// "Whole-B" variant of the tile engine for the HBM-bound 1x1 convolutions of the residual stack (out conv + residual, the head's
-// final_convolution_1, the head's backward mask GEMM): small K (<= 256), so the arithmetic is ~10 us of a launch whose bytes take ~30.
+// REJECTED ALTERNATIVE, kept with its harness (tools/stream_harness.hip; includes the PRODUCT headers, nothing here is a fork): a "whole-B" variant of
+// the tile engine for the HBM-bound 1x1 convolutions of the residual stack (out conv + residual, final_convolution_1, the head's backward mask GEMM).
 //
-// Same contraction, operands, fragment layouts and fused epilogue arithmetic as wn_gemm_lds_kernel (wn_tile.h) -- outputs are bit-identical --,
-// what differs is WHEN a workgroup asks HBM for its bytes.  The ring kernel requests an activation tile chunk by chunk, two chunks ahead (8 - 16 KB
-// in flight per workgroup), then the epilogue's residual rows in a second round trip: a workgroup is a chain of 5 - 9 dependent HBM latencies and a
-// launch moves 3.2 TB/s alone (profiles/r7i_serial_kernel_stats.csv: 57 us for 180 MB).  Here a workgroup issues EVERYTHING it will ever read at its
-// first instruction -- the epilogue's residual operand (into registers), the whole [TTILE rows x K] activation tile (LDS-DMA, 32 KB) and the first
-// two weight slots -- 64 KB per workgroup, 128 KB per CU in flight, then waits ONCE; only the weight panel (L2-resident, shared by every
-// workgroup) keeps streaming through a 3-slot ring of 32-channel slices behind the matrix cores.  Two workgroups per CU cover each other's wait.
+// Same contraction, operands, fragment layouts and fused epilogue arithmetic as wn_gemm_lds_kernel (csrc/wn_tile.h) -- outputs are bit-identical --; what
+// differs is WHEN a workgroup asks HBM for its bytes.  The ring kernel requests an activation tile chunk by chunk, one or two chunks ahead (8 - 16 KB in
+// flight per workgroup), then the epilogue's residual rows in a second round trip.  Here a workgroup issues EVERYTHING it will ever read at its first
+// instructions -- the epilogue's residual operand (into registers), the whole [TTILE rows x K] activation tile (LDS-DMA, 32 KB) and the first two weight
+// slots: 64 KB per workgroup, 128 KB per CU in flight --, waits ONCE, and only the weight panel (L2-resident) keeps streaming through a 3-slot ring.
+// Hypothesis (round 6): these launches are latency-bound chains and more bytes in flight lifts them from ~4.5 TB/s towards the 6.3 TB/s a copy reaches.
+// MEASURED (profiles/r9b_stream_harness.txt, r9b_ab_wb.txt): out conv at C2 widths, full batch 41.9 - 44.1 us vs the ring kernel's 38.5 - 42.3 (4.1 - 4.3 vs
+// 4.3 - 4.7 TB/s); half batch 22.8 - 24.0 vs 24.0 - 26.1; hparams.py widths 20.2 - 20.5 vs 18.2 - 18.4 (full), 12.5 - 12.8 vs 13.5 - 14.1 (half); live C2 step
+// 9.805 / 9.832 vs 9.814 / 9.830 ms.  Bytes in flight are NOT what bounds these kernels: with everything requested up front the same ~4.2 - 4.7 TB/s comes
+// out, which is the rate this part sustains for four interleaved row streams (two read, two written).  Not adopted.
 #pragma once
 #include "wn_tile.h"
 #include <utility>
