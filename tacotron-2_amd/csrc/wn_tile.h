@@ -415,12 +415,12 @@ struct LdsGemmCfg {
 template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE_ = 1, int TAPS = 0>
 __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const lds, const int wg_id) {
     using Cfg = LdsGemmCfg<MT, NT, WM, WN, BK, NBUF>;
-    // PIPE_ names the main-loop schedule; the product launches schedule 1 only (every fragment of a chunk is requested from LDS right
-    // after the chunk's barrier, the DMAs of chunk + 2 are issued while those reads fly, then the chunk's MFMAs go back to back).  The
-    // schedules that were measured against it and lost -- fragment reads one k-step ahead (2 / 3), half the waves issuing the DMAs (5),
-    // wave halves half a chunk apart (6 / 7), weight fragments straight into VGPRs (8) -- live in tools/wn_tile_variants.h with the
-    // harness; the template parameter stays so that kernel names in profiles/ keep their meaning.
-    static_assert(PIPE_ == 1, "schedule 1 is the only one in the library (tools/wn_tile_variants.h has the others)");
+    // PIPE_ names the main-loop schedule; the library has schedule 1 only (every fragment of a chunk is requested from LDS right after the chunk's
+    // barrier, the DMAs of chunk + 2 are issued while those reads fly, then the chunk's MFMAs go back to back).  The schedules that were measured against
+    // it in rounds 2 - 4 and lost -- fragment reads one k-step ahead, half the waves issuing the DMAs, wave halves half a chunk apart, weight fragments
+    // straight into VGPRs -- are gone from the tree (round 6; their tables: profiles/r4m_gemm_harness_variants.txt); the template
+    // parameter stays so that kernel names in profiles/ keep their meaning.
+    static_assert(PIPE_ == 1, "schedule 1 is the only one in the library");
     static_assert(TAPS == 0 || (TAPS == 3 && NBUF == 3), "interleaved taps: the tap of a chunk is its ring slot (ring depth 3 == 3 taps)");
 
     const int tid = threadIdx.x, lane = tid & 63;

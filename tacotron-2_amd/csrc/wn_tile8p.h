@@ -44,7 +44,8 @@ __device__ __forceinline__ uint64_t p8_sgpr64(uint64_t v) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
-// ABL (harness only): 1 = main loop alone (the accumulators are kept live, nothing is stored)
+// ABL (harness only): 1 = main loop alone (the accumulators are kept live, nothing is stored); 2 = whole kernel without the prologue's wait for K-tile 0 (results wrong:
+// the upper bound of what a persistent grid that prefetches the next tile under the epilogue could save)
 // SCHED: 0 = LDS-DMAs in the load section of a phase (the guide's template); 1 = between the MFMAs of its matrix block
 template <int EPI, int ABL, int SCHED>
 __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const lds) {
@@ -268,7 +269,7 @@ __device__ __forceinline__ void wn_gemm8p_body(const GemmArgs& a, char* const ld
         // prologue: K-tile 0 whole, K-tile 1 without A-h1 (phase 1 of K-tile 0 stages it); 14 DMAs per wave, the first 8 must have landed
         b_next(); stageB(I0{}, I0{}); stageA(I0{}, I0{}, 0); stageB(I0{}, I1{}); stageA(I0{}, I1{}, 0);
         b_next(); stageB(I1{}, I0{}); stageA(I1{}, I0{}, 1); stageB(I1{}, I1{});
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (ABL != 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // (ABL 2, harness only: start without waiting for K-tile 0 -- wrong results, the time of a kernel whose prologue is hidden)
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();                   // wave row 1 runs one barrier behind row 0
         for (int kt = 0; kt < nkt - 2; kt += 2) { ktile(I0{}, I0{}, kt); ktile(I1{}, I0{}, kt + 1); }

@@ -426,7 +426,7 @@ static int fwd_part(wn_ctx* c, int b0, int nb, hipStream_t st, bool prof) {
 // Two ways of FORCING the complementary pairing of the two half-batches (MFMA-bound gate / d x of one beside HBM-bound out conv / d z of
 // the other) were built and measured in round 3 and are gone from the library: a lockstep chain through cross-stream events (every event
 // costs 15-24 us between the signalling kernel's end and the waiting kernel's start: 11.6 vs 10.06 ms/step, profiles/r4d_ab_lockstep.txt)
-// and both launches in ONE grid (wn_fused_pair_kernel, tools/wn_tile_variants.h: every grid drains before the next starts, 11.2 vs
+// and both launches in ONE grid (wn_fused_pair_kernel, in the repository history up to round 5: every grid drains before the next starts, 11.2 vs
 // 9.9 ms/step, profiles/r4e_ab_fused.txt).  Two free-running streams hide each kernel's tail under the other stream's next launch.
 
 // run f(b0, nb, stream, is_first_part) for every batch part: part 0 on the caller's stream, part 1 on the ctx-owned one, both

@@ -14,7 +14,7 @@
 #   serial       the same with every kernel alone on one stream (exclusive kernel times) -> serial_kernel_stats.csv
 #   pmc          FETCH_SIZE and WRITE_SIZE passes -> pmc_fetch.md, pmc_write.md, traffic.json (bench.py loads the committed copy)
 #   sq           SQ counter passes of the bench step -> pmc_sq.md
-#   harness      tools/gemm_harness + ablation + wgrad harness tables
+#   harness      the stand-alone harnesses on the PRODUCT headers: gemm8p_harness (gate / d x: ring vs 8-phase), stream_harness (out conv, mask GEMM, d z), wgrad_harness
 #   chain        tools/chain_harness: persistent layer-chain prototype vs the two-stream schedule (forward, 6 layers) -> chain_harness.txt
 #   pipetrace    WN_PIPE_TRACE stage trace of the synthesis pipeline (B = 1, 8) -> pipe_trace_b*.txt
 #   other        10-step runs of the other workloads only
@@ -69,8 +69,8 @@ for st in "$@"; do
         rm -rf $OUT/sq$i
       done; cd $R ;;
     harness) cd /tmp
-      for h in gemm_harness gemm_harness_ablate wgrad_harness; do [ -x $R/tools/$h ] && timeout 180 $R/tools/$h > $OUT/$h.txt 2>&1; done
-      cd $R; tail -40 $OUT/gemm_harness.txt ;;
+      for h in gemm8p_harness stream_harness wgrad_harness; do [ -x $R/tools/$h ] && timeout 240 $R/tools/$h > $OUT/$h.txt 2>&1; done
+      cd $R; tail -30 $OUT/gemm8p_harness.txt; tail -20 $OUT/stream_harness.txt ;;
     chain) cd /tmp; [ -x $R/tools/chain_harness ] && timeout 90 $R/tools/chain_harness > $OUT/chain_harness.txt 2>&1; cd $R; tail -16 $OUT/chain_harness.txt ;;
     chaindbg:*) cd /tmp; for f in $(echo ${st#chaindbg:} | tr ',' ' '); do timeout 60 $R/tools/chain_harness $f 2>&1 | grep -v "^    wg" | head -30 > $OUT/chain_dbg_$f.txt; echo "== flags $f"; head -12 $OUT/chain_dbg_$f.txt; done; cd $R ;;
     pipetrace) python tacotron-2_amd/csrc/build.py --pipe-svc > /dev/null 2>&1      # (the stamp sites are a diagnostic build; the box is discarded after the session)

@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -I tacotron-2_amd/csrc -I tools tools/stream_harness.hip -o tools/stream_harness
 //   tools/stream_harness [B=8] [T=11000] [rounds=3]
 #include "wn_tile_wb.h"
+#include "power_sampler.h"
 #include <vector>
 #include <random>
 #include <functional>
@@ -117,6 +118,11 @@ int main(int argc, char** argv) {
                 report(nm, "whole-B <4,2,4>", time_ms([&] { GemmArgs q = w; wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, q, M, 0); }), by);
             }
         }
+        {   // energy per launch, full batch
+            GemmArgs p = mk(0, B, 0), w = mk(1, B, 0);
+            report_power("out conv C2, ring kernel (production)", measure_power([&] { GemmArgs q = p; wn_launch_gemm<EPI_STORE_BF16>(&ctx, q, M, 0); }), 0.0, bytes);
+            report_power("out conv C2, whole-B kernel", measure_power([&] { GemmArgs q = w; wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, q, M, 0); }), 0.0, bytes);
+        }
         // as the step runs it: beside the gate GEMM of the other half batch (second stream)
         if (B >= 2) {
             const int R = 256, G = 512, GH = 256, C = 80, Kg = 3 * R + C, d = 64;
@@ -194,6 +200,23 @@ int main(int argc, char** argv) {
         const double bytes = (double)NT_ * (K + 2.0 * M) * 2;
         report("head mask GEMM", "production (wn_launch_gemm)", time_ms([&] { GemmArgs q = p; wn_launch_gemm<EPI_MASK_STORE>(&ctx, q, M, 0); }), bytes);
         report("head mask GEMM", "whole-B <4,2,4>", time_ms([&] { GemmArgs q = w; wn_launch_gemm_wb<4, 2, 4, EPI_MASK_STORE>(&ctx, q, M, 0); }), bytes);
+    }
+    // ---------------- d z (backward through the 1x1 convs and the gate, modules.py:510-515 differentiated): production timing only -- K = R + S = 512 does not
+    // fit a whole-B tile beside a weight ring at two workgroups per CU (64 KB + 48 KB); the reference number for DESIGN's kernel table
+    {
+        const int M = 256, K = 512, GHh = 256;
+        bf16_t* Apk = to_dev(pack_frag(host_bf16_random((size_t)M * K, 0.05f), M, K));
+        bf16_t* GX = dev_bf16_random(NT_ * 256, 1.0f); bf16_t* DS = dev_bf16_random(NT_ * 256, 1.0f);
+        bf16_t* S_ = dev_bf16_random(NT_ * GHh, 0.9f); bf16_t* U_ = dev_bf16_random(NT_ * GHh, 0.9f); bf16_t* DZ = dev_fill<bf16_t>(NT_ * 2 * GHh);
+        for (int nb : {B, B / 2}) {
+            if (nb < 1) continue;
+            GemmArgs a; base(a, Apk, K, nb, 0); a.nseg = 2; a.seg[0] = mkseg(GX, 256, 0, 256, 0); a.seg[1] = mkseg(DS, 256, 0, 256, 0);
+            a.e.in0 = S_; a.e.in1 = U_; a.e.ld_in0 = GHh; a.e.out0 = DZ; a.e.ld_out0 = 2 * GHh; a.e.M_valid = M; a.e.GH = GHh;
+            const double bytes = (double)nb * T * (2 * 256 + 2 * GHh + 2 * GHh) * 2.0;
+            char nm[64]; snprintf(nm, sizeof nm, "d z, %d utterances", nb);
+            for (int rnd = 0; rnd < rounds; ++rnd) report(nm, "production (wn_launch_gemm)", time_ms([&] { GemmArgs q = a; wn_launch_gemm<EPI_DGATE>(&ctx, q, M, 0); }), bytes);
+            if (nb == B) report_power("d z, ring kernel (production)", measure_power([&] { GemmArgs q = a; wn_launch_gemm<EPI_DGATE>(&ctx, q, M, 0); }), 0.0, bytes);
+        }
     }
     printf("stream harness %s (%d failing checks)\n", fails ? "FAILED" : "passed", fails);
     return fails != 0;
