@@ -446,6 +446,12 @@ def measure_other_workload(key, device, steps=10, warmup=3):
            'gate_kernel': {'achieved_TFLOPs': gate_tf, 'frac_of_peak': (gate_tf / peak_tf) if gate_tf else None, 'launches_timed': int(k_n),
                            'rows_per_launch': rows, 'sclk_in_kernel_mhz': k_mhz or None, 'timing': 'in-kernel stamps (pure kernel time), live in the two-stream step'},
            'bound': 'hbm' if alg_bytes_per_sample(hp, e_act) * peak_tf * 1e12 > 6.0 * mac_per_sample(hp) * 8e12 else 'mfma'}
+    # measured fabric traffic of this workload's step where a committed PMC summary exists (profiles/traffic_<key>.json): the counter ratio next to the
+    # algorithmic fraction, and the rate the memory system really ran at (6.3 TB/s is what a streaming copy reaches on this part)
+    tr = load_traffic(key, B, T, path=os.path.join(ROOT, 'profiles', 'traffic_%s.json' % key))
+    if tr:
+        out['traffic_per_step'] = tr['bytes_per_step']; out['traffic_over_algorithmic'] = tr['bytes_per_step'] / (alg_bytes_per_sample(hp, e_act) * B * T)
+        out['fabric_GBps_at_this_step_time'] = tr['bytes_per_step'] / dt / 1e9; out['traffic_source'] = tr['source'].replace('profiles/traffic.json', 'profiles/traffic_%s.json' % key)
     eng.close()
     if key == 'c5_stress':
         # synthesis at this width (R = S = 512 > the LDS-resident pipeline's 384): the launch-per-layer hipGraph path, 0.1 s of audio
