@@ -9,8 +9,10 @@
 // Hypothesis (round 6): these launches are latency-bound chains and more bytes in flight lifts them from ~4.5 TB/s towards the 6.3 TB/s a copy reaches.
 // MEASURED (profiles/r9b_stream_harness.txt, r9b_ab_wb.txt): out conv at C2 widths, full batch 41.9 - 44.1 us vs the ring kernel's 38.5 - 42.3 (4.1 - 4.3 vs
 // 4.3 - 4.7 TB/s); half batch 22.8 - 24.0 vs 24.0 - 26.1; hparams.py widths 20.2 - 20.5 vs 18.2 - 18.4 (full), 12.5 - 12.8 vs 13.5 - 14.1 (half); live C2 step
-// 9.805 / 9.832 vs 9.814 / 9.830 ms.  Bytes in flight are NOT what bounds these kernels: with everything requested up front the same ~4.2 - 4.7 TB/s comes
-// out, which is the rate this part sustains for four interleaved row streams (two read, two written).  Not adopted.
+// 9.805 / 9.832 vs 9.814 / 9.830 ms.  Bytes in flight at workgroup START are not what bounds these kernels: with everything requested up front the same
+// ~4.2 - 4.7 TB/s comes out -- while a plain streaming kernel with this traffic mix reaches 6.7 TB/s on the same (Infinity-Cache-resident) tensors
+// (profiles/r9f_hbm_streams_probe.txt).  What is between: a workgroup is a load phase, a matrix phase and a store phase, and two per CU do not keep requests
+// in flight CONTINUOUSLY; a persistent kernel with the tile triple-buffered would.  Not adopted.
 #pragma once
 #include "wn_tile.h"
 #include <utility>
