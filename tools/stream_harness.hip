@@ -118,6 +118,21 @@ int main(int argc, char** argv) {
                 report(nm, "whole-B <4,2,4>", time_ms([&] { GemmArgs q = w; wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, q, M, 0); }), by);
             }
         }
+        for (int nb : {B, B / 2}) {   // where does a workgroup's life go?  (phase stamps of the whole-B kernel: harness diagnostics)
+            if (nb < 1) continue;
+            GemmArgs w = mk(1, nb, 0);
+            const int nwg = cdiv((int64_t)cdiv(T, 64) * nb, 8) * 8;
+            unsigned long long* st; CK(hipMalloc(&st, (size_t)nwg * 64)); CK(hipMemset(st, 0, (size_t)nwg * 64));
+            wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, w, M, 0); CK(hipDeviceSynchronize());      // warm
+            w = mk(1, nb, 0); w.kclk = st;
+            wn_launch_gemm_wb<4, 2, 4, EPI_STORE_BF16>(&ctx, w, M, 0); CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h((size_t)nwg * 8); CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+            double d[5] = {0, 0, 0, 0, 0}, life = 0; int n = 0; unsigned long long t_first = ~0ull, t_last = 0;
+            for (int i = 0; i < nwg; ++i) { const unsigned long long* r = &h[(size_t)i * 8]; if (!r[0] || !r[5]) continue; ++n; for (int k = 0; k < 5; ++k) d[k] += (double)(r[k + 1] - r[k]); life += (double)(r[5] - r[0]); t_first = std::min(t_first, r[0]); t_last = std::max(t_last, r[5]); }
+            printf("whole-B out conv, %d utterances, %d workgroups: kernel span %.1f us; mean workgroup life %.2f us = issue %.2f + wait for everything %.2f + main loop %.2f + epilogue to last store issued %.2f + store drain %.2f\n",
+                   nb, n, (double)(t_last - t_first) / 100.0, life / n / 100.0, d[0] / n / 100.0, d[1] / n / 100.0, d[2] / n / 100.0, d[3] / n / 100.0, d[4] / n / 100.0);
+            CK(hipFree(st));
+        }
         {   // energy per launch, full batch
             GemmArgs p = mk(0, B, 0), w = mk(1, B, 0);
             report_power("out conv C2, ring kernel (production)", measure_power([&] { GemmArgs q = p; wn_launch_gemm<EPI_STORE_BF16>(&ctx, q, M, 0); }), 0.0, bytes);

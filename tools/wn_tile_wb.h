@@ -54,6 +54,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void wn_gemm_wb_kernel(c
     const int tile = a.xcd_span > 0 ? xcd * a.xcd_span + q / a.mblocks : (q / a.mblocks) * 8 + xcd;
     if (tile >= a.ntiles) return;
     if (a.kprof && tid == 0) atomicMin(a.kprof, (unsigned long long)wall_clock64());
+    // harness diagnostics: a.kclk != null -> thread 0 of workgroup id stamps the 100 MHz wall clock at the phase boundaries of its life into kclk[id * 8 ..]:
+    // [0] start, [1] every request issued, [2] first wait satisfied (everything landed), [3] main loop done, [4] epilogue stores issued, [5] stores drained
+    unsigned long long* const ph = a.kclk ? a.kclk + (size_t)id * 8 : nullptr;
+    auto stamp = [&](int i) __attribute__((always_inline)) { if (ph && tid == 0) ph[i] = (unsigned long long)wall_clock64(); };
+    stamp(0);
     const int bl = tile / a.tiles_per_utt;
     const int b = bl + a.b0;
     const int t0 = (tile - bl * a.tiles_per_utt) * Cfg::TTILE;
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void wn_gemm_wb_kernel(c
         if constexpr (S + 1 < Cfg::NSTEP) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::A_PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (S == 0) stamp(2);
         bf16x8_t af[2][MT], bfr[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -167,7 +173,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void wn_gemm_wb_kernel(c
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    stamp(1);
     [&]<int... S>(std::integer_sequence<int, S...>) { (step(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, Cfg::NSTEP>{});
+    stamp(3);
 
     // ---- epilogue (wn_gemm_lds_body's, NT = 1, operands already in registers): accumulators -> LDS fp32 [time][channel] -> (row, 8 channels) items
     constexpr int PITCH = Cfg::EPI_PITCH;
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void wn_gemm_wb_kernel(c
             if (valid) *reinterpret_cast<uint4*>(o0 + (uint32_t)(tr * e.ld_out0)) = pack8(v);
         }
     }
+    if (ph) { stamp(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(5); }
     if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
 }
 
