@@ -437,7 +437,15 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
     const int tile = a.xcd_span > 0 ? xcd * a.xcd_span + q / a.mblocks : (q / a.mblocks) * 8 + xcd;
     if (tile >= a.ntiles) return;
     if (a.kprof && tid == 0) atomicMin(a.kprof, (unsigned long long)wall_clock64());
+#ifdef WN_PHASE_STAMPS      // harness diagnostics (tools/stream_harness.hip -DWN_PHASE_STAMPS): kclk is then a per-workgroup stamp table, kclk[id * 8 + i] = 100 MHz wall clock at phase
+                            // boundary i (0 start, 1 set-up done, 2 first chunk landed, 3 main loop done, 4 last store issued, 5 stores drained): profiles/r9i_stream_harness_phases.txt
+    unsigned long long* const ph_ = a.kclk ? a.kclk + (size_t)id * 8 : nullptr;
+#define WN_STAMP(i) do { if (ph_ && tid == 0) ph_[i] = (unsigned long long)wall_clock64(); } while (0)
+    WN_STAMP(0);
+#else
+#define WN_STAMP(i) do { } while (0)
     if (a.kclk && id == 0 && tid == 0) { a.kclk[0] = __builtin_amdgcn_s_memtime(); a.kclk[1] = (unsigned long long)wall_clock64(); }
+#endif
     if (a.stagger > 0 && id < 512) {
         // All tiles cost the same, so co-resident (and neighbouring) workgroups would reach their MFMA-idle, store-heavy
         // epilogues at the same moment.  First-round workgroups therefore start with a placement-dependent delay; later
@@ -633,6 +641,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::LPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (ch == 0) WN_STAMP(2);
         const char* const buf = lds + Cfg::a_base(BUF); const char* const bufb = lds + Cfg::b_base(BUF);
         bf16x8_t af[Cfg::KS][MT], bfr[Cfg::KS][NT];
 #pragma unroll
@@ -657,6 +666,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
     };
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
 
+    WN_STAMP(1);
     // prologue: fill NBUF-1 buffers
     stage(std::integral_constant<int, 0>{});
     if constexpr (NBUF == 3) { if (nchunks > 1) stage(std::integral_constant<int, 1>{}); }
@@ -738,6 +748,7 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         if constexpr (NBUF == 3) { if (ch + 2 < nchunks) ring_step(std::integral_constant<int, 2>{}, ch + 2); }
     }
 
+    WN_STAMP(3);
     if constexpr (EPI == EPI_STORE_F32_BOT) {
         // [B][M][T] fp32 output: lanes are consecutive time steps, already coalesced
         wn_tile_epilogue<MT, NT, EPI>(a, acc, mtile0, t0 + wn * NT * 32, b, T, rowbase, lane);
@@ -810,7 +821,9 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
                 const int mo = mblk * Cfg::MTILE + c8 * 8;
                 // ---- every global load of the pass first (round 2 walked the items in a loop of load -> wait -> load -> wait -> compute ->
                 // store: 8 dependent HBM round trips per workgroup, which is what bounded the HBM-bound launches at ~4 TB/s with 16 waves
-                // per CU each holding 32 B in flight).  Rows past the end of the utterance read the last valid row (never stored).
+                // per CU each holding 32 B in flight).  Rows past the end of the utterance read the last valid row (never stored).  (Round 6: issuing them a PASS
+                // AHEAD -- pass j + 1's while pass j is computed, the one-pass tiles' at kernel start -- is bit-identical and changes nothing: the 4.6 us of a pass
+                // are ~480 VALU instructions per thread behind two barriers, not the round trip; step 9.81 - 9.84 vs 9.79 ms, profiles/r9j_*; not kept.)
                 uint4 l0[NIT], l1[NIT];
                 int trs[NIT];
 #pragma unroll
@@ -908,7 +921,12 @@ __device__ __forceinline__ void wn_gemm_lds_body(const GemmArgs& a, char* const 
         }
     }
     if (a.kprof && tid == 0) atomicMax(a.kprof + 1, (unsigned long long)wall_clock64());
+#ifdef WN_PHASE_STAMPS
+    if (ph_) { WN_STAMP(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WN_STAMP(5); }
+#else
     if (a.kclk && id == 0 && tid == 0) { a.kclk[0] = __builtin_amdgcn_s_memtime() - a.kclk[0]; a.kclk[1] = (unsigned long long)wall_clock64() - a.kclk[1]; }
+#endif
+#undef WN_STAMP
 }
 
 template <int MT, int NT, int WM, int WN, int BK, int NBUF, int EPI, int PIPE = 1, int TAPS = 0>

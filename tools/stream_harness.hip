@@ -58,6 +58,28 @@ static float time_ms(const std::function<void()>& f, int iters = 20) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); return ms / iters;
 }
 
+#ifdef WN_PHASE_STAMPS
+// Phase stamps of the PRODUCT kernels (csrc/wn_tile.h compiled with -DWN_PHASE_STAMPS: a diagnostic build of the same body): where does a workgroup's life go?
+static void phases(const char* what, const std::function<void(unsigned long long*)>& launch) {
+    const int cap = 16384;
+    unsigned long long* st; CK(hipMalloc(&st, (size_t)cap * 64));
+    launch(nullptr); CK(hipDeviceSynchronize());
+    CK(hipMemset(st, 0, (size_t)cap * 64));
+    launch(st); CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)cap * 8); CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+    double d[5] = {0, 0, 0, 0, 0}, life = 0; int n = 0; unsigned long long t_first = ~0ull, t_last = 0;
+    for (int i = 0; i < cap; ++i) {
+        unsigned long long r[6]; for (int k = 0; k < 6; ++k) r[k] = h[(size_t)i * 8 + k];
+        if (!r[0] || !r[5]) continue;
+        if (!r[2]) r[2] = r[1];               // (K-interleaved taps path: no "first chunk landed" stamp)
+        ++n; for (int k = 0; k < 5; ++k) d[k] += (double)(r[k + 1] - r[k]); life += (double)(r[5] - r[0]); t_first = std::min(t_first, r[0]); t_last = std::max(t_last, r[5]);
+    }
+    printf("phases %-34s %5d workgroups, kernel span %6.1f us; mean workgroup life %6.2f us = set-up %5.2f + prologue DMAs and wait for the first chunk %5.2f + main loop %6.2f + epilogue to last store issued %5.2f + store drain %5.2f\n",
+           what, n, (double)(t_last - t_first) / 100.0, life / n / 100.0, d[0] / n / 100.0, d[1] / n / 100.0, d[2] / n / 100.0, d[3] / n / 100.0, d[4] / n / 100.0);
+    CK(hipFree(st));
+}
+#endif
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8, T = argc > 2 ? atoi(argv[2]) : 11000, rounds = argc > 3 ? atoi(argv[3]) : 3;
     const int64_t NT_ = (int64_t)B * T;
@@ -133,6 +155,10 @@ int main(int argc, char** argv) {
                    nb, n, (double)(t_last - t_first) / 100.0, life / n / 100.0, d[0] / n / 100.0, d[1] / n / 100.0, d[2] / n / 100.0, d[3] / n / 100.0, d[4] / n / 100.0);
             CK(hipFree(st));
         }
+#ifdef WN_PHASE_STAMPS
+        for (int nb : {B, B / 2}) { char nm[64]; snprintf(nm, sizeof nm, "out conv C2, %d utterances", nb);
+            phases(nm, [&](unsigned long long* st) { GemmArgs q = mk(0, nb, 0); q.kclk = st; wn_launch_gemm<EPI_STORE_BF16>(&ctx, q, M, 0); }); }
+#endif
         {   // energy per launch, full batch
             GemmArgs p = mk(0, B, 0), w = mk(1, B, 0);
             report_power("out conv C2, ring kernel (production)", measure_power([&] { GemmArgs q = p; wn_launch_gemm<EPI_STORE_BF16>(&ctx, q, M, 0); }), 0.0, bytes);
@@ -148,6 +174,10 @@ int main(int argc, char** argv) {
             g.seg[0] = mkseg(XD, R, 0, R, -2 * d); g.seg[1] = mkseg(XD, R, 0, R, -d); g.seg[2] = mkseg(XD, R, 0, R, 0); g.seg[3] = mkseg(cbt, C, 0, C, 0);
             g.e.bias = bias; g.e.out0 = TS; g.e.ld_out0 = GH; g.e.out1 = Ug; g.e.ld_out1 = GH; g.e.M_valid = G; g.e.GH = GH;
             hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+#ifdef WN_PHASE_STAMPS
+            phases("gate, half batch", [&](unsigned long long* st) { GemmArgs q = g; q.kclk = st; wn_launch_gemm<EPI_GATE>(&ctx, q, G, 0); });
+            { GemmArgs gf = g; gf.B = B; phases("gate, full batch", [&](unsigned long long* st) { GemmArgs q = gf; q.kclk = st; wn_launch_gemm<EPI_GATE>(&ctx, q, G, 0); }); }
+#endif
             GemmArgs p = mk(0, B - B / 2, B / 2), w = mk(1, B - B / 2, B / 2);
             for (int rnd = 0; rnd < rounds; ++rnd) {
                 const float tg = time_ms([&] { GemmArgs q = g; wn_launch_gemm<EPI_GATE>(&ctx, q, G, s1); CK(hipStreamSynchronize(s1)); }, 10);
@@ -230,6 +260,9 @@ int main(int argc, char** argv) {
             const double bytes = (double)nb * T * (2 * 256 + 2 * GHh + 2 * GHh) * 2.0;
             char nm[64]; snprintf(nm, sizeof nm, "d z, %d utterances", nb);
             for (int rnd = 0; rnd < rounds; ++rnd) report(nm, "production (wn_launch_gemm)", time_ms([&] { GemmArgs q = a; wn_launch_gemm<EPI_DGATE>(&ctx, q, M, 0); }), bytes);
+#ifdef WN_PHASE_STAMPS
+            phases(nm, [&](unsigned long long* st) { GemmArgs q = a; q.kclk = st; wn_launch_gemm<EPI_DGATE>(&ctx, q, M, 0); });
+#endif
             if (nb == B) report_power("d z, ring kernel (production)", measure_power([&] { GemmArgs q = a; wn_launch_gemm<EPI_DGATE>(&ctx, q, M, 0); }), 0.0, bytes);
         }
     }
