@@ -171,3 +171,42 @@ def test_pipeline_beside_a_competing_workload_completes_or_falls_back_cleanly():
         assert e < 3e-2                      # bf16 storage on the fallback path vs half on the pipeline
     else:
         assert model.engine.synth_path == 'pipeline' and e < 1e-6      # same kernel, same inputs: the competitor only delays it
+
+
+GEOMETRIES = [(1, 112, [112]), (1, 128, [128]), (3, 144, [144, 129, 2]), (5, 272, [272, 256, 255, 130, 16]), (2, 656, [656, 513]), (7, 64, [64, 63, 48, 33, 32, 17, 3])]
+
+
+@pytest.mark.parametrize('name', ['paper_width_drop', 'wide', 'mol_2d', 'gauss_subpixel'])
+def test_geometry_sweep_forward_and_backward(name):
+    """Batch / time geometries around the tile boundaries of every tile-engine configuration (LDS-DMA 256- and 128-channel kernels, the round-1 kernel of
+    the 64-channel models): one utterance, odd batches (the two-stream split takes 1 + 2, 2 + 3, 3 + 4 utterances), T one hop below / at / above the 128-row tile
+    and the 64-row tile, ragged lengths down to 2 samples (a masked-mean loss over almost nothing), a time axis shorter than one tile.  y_hat against the
+    bf16-emulating oracle, the device loss against the oracle's loss on the device's y_hat, every gradient against autograd -- tolerances of test_hip_parity."""
+    import numpy as np
+    from test_hip_parity import _run_fwd
+    from hip_util import download_grads
+    worst_y, worst_g = 0.0, 0.0
+    for B, T, lengths in GEOMETRIES:
+        r = _run_fwd(name, B=B, T=T, lengths=lengths)
+        cfg, eng = r['cfg'], r['eng']
+        assert r['T'] == T
+        y_em = O.step(r['params'], cfg, r['x_or'], r['c'], dropout_masks=r['masks'], emulate_bf16=True, g=r['g'])
+        ey = rel_err(r['yhat_dev'].cpu(), y_em)
+        loss_same = float(O.training_loss(cfg, r['yhat_dev'].cpu(), r['y_or'], r['lengths']))
+        ld = float(r['loss_dev'].item())
+        assert np.isfinite(ld) and abs(ld - loss_same) <= 2e-4 * max(1.0, abs(loss_same)), (name, B, T, ld, loss_same)
+        grads_dev = torch.empty(eng.n_params, device='cuda')
+        eng.train_bwd(grads_dev)
+        torch.cuda.synchronize()
+        g_dev = download_grads(eng, grads_dev)
+        leaf = {k: v.clone().requires_grad_(True) for k, v in r['params'].items()}
+        y = O.step(leaf, cfg, r['x_or'], r['c'], dropout_masks=r['masks'], emulate_bf16=True, g=r['g'])
+        loss = O.training_loss(cfg, y, r['y_or'], r['lengths'])
+        gs = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
+        g_or = {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(leaf, gs)}
+        eg = rel_err(torch.cat([g_dev[k].flatten() for k in g_or]), torch.cat([g_or[k].flatten() for k in g_or]))
+        print('\n[%s] B = %d, T = %d, lengths %s: y_hat %.2e, all gradients %.2e, loss %.5f' % (name, B, T, lengths, ey, eg, ld))
+        assert ey < 2.4e-2 and eg < 7e-3, (name, B, T, ey, eg)
+        worst_y, worst_g = max(worst_y, ey), max(worst_g, eg)
+        eng.close()
+    print('[%s] worst over %d geometries: y_hat %.2e, gradients %.2e' % (name, len(GEOMETRIES), worst_y, worst_g))
