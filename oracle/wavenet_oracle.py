@@ -92,6 +92,8 @@ class OracleConfig:
             if hasattr(hp, f):
                 kw[f] = getattr(hp, f)
         kw['upsample_scales'] = list(kw.get('upsample_scales', [5, 5, 11]))
+        if kw.get('upsample_activation') == 'None':      # `--hparams upsample_activation=None` arrives as a string (the product's parser accepts that spelling)
+            kw['upsample_activation'] = None
         return OracleConfig(**kw)
 
 
